@@ -1,0 +1,308 @@
+"""TEST INFRASTRUCTURE ONLY.  Mints tests/golden/*.npz from the REAL reference run on CPU.
+
+Run in the build container (needs /root/reference):   python oracle/make_golden.py
+
+What it does
+  1. builds the reference `LlavaLlamaModel` (tiny, seeded random weights) through the reference's own
+     builders (oracle/ref_harness.py), fp32, eager attention;
+  2. runs the reference hot path -- `prepare_inputs_labels_for_multimodal` (llava_arch.py:333) with
+     forward hooks on every stage boundary of SURVEY 8a, `llm(inputs_embeds=...)` for prefill logits /
+     hidden states, and `model.generate(...)` (llava_llama.py:194) greedy;
+  3. asserts that the self-contained restatement oracle/srgpt_oracle.py reproduces every stage and the
+     generated ids from the same weights and inputs  (this is what PINS the oracle);
+  4. writes weights (canonical checkpoint key names), inputs, stage outputs and ids to
+     tests/golden/tiny_fp32.npz, a bf16 run of the same model to tests/golden/tiny_bf16.npz, and
+     model-free MaskPooling / DownSampleBlock / LayerNorm2d / deconv known-answer vectors
+     (reference modules loaded standalone) to tests/golden/region_kat.npz.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_harness as rh  # noqa: E402
+from oracle import srgpt_oracle as so  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+TINY_LLM = dict(vocab_size=128, hidden_size=64, intermediate_size=160, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, max_position_embeddings=2048, rms_norm_eps=1e-5, rope_theta=500000.0,
+                tie_word_embeddings=False, bos_token_id=1, eos_token_id=2, attention_bias=False)
+TINY_VIT = dict(hidden_size=64, intermediate_size=176, num_hidden_layers=3, num_attention_heads=4, image_size=378,
+                patch_size=14, layer_norm_eps=1e-6, hidden_act="gelu_pytorch_tanh")
+
+
+def canonical_state_dict(model) -> dict:
+    """reference in-memory keys -> checkpoint (transformers 4.37.2) key names."""
+    out = {}
+    for k, v in model.state_dict().items():
+        if k.startswith("vision_tower.vision_tower.") and not k.startswith("vision_tower.vision_tower.vision_model."):
+            k = k.replace("vision_tower.vision_tower.", "vision_tower.vision_tower.vision_model.", 1)
+        if ".head." in k or "post_layernorm" in k:
+            continue  # pooling head / post-LN are computed and discarded by the reference
+        out[k] = v.detach().clone()
+    return out
+
+
+def cfg_from(model, tok) -> so.SrgptConfig:
+    lc, vc = model.llm.config, model.get_vision_tower().vision_tower.config
+    return so.SrgptConfig(
+        vit_hidden=vc.hidden_size, vit_inter=vc.intermediate_size, vit_layers=vc.num_hidden_layers,
+        vit_heads=vc.num_attention_heads, image_size=vc.image_size, patch_size=vc.patch_size,
+        vit_eps=vc.layer_norm_eps, select_layer=-2,
+        hidden=lc.hidden_size, inter=lc.intermediate_size, layers=lc.num_hidden_layers,
+        heads=lc.num_attention_heads, kv_heads=lc.num_key_value_heads, vocab=model.llm.get_input_embeddings().weight.shape[0],
+        rms_eps=lc.rms_norm_eps, rope_theta=float(lc.rope_parameters["rope_theta"]) if hasattr(lc, "rope_parameters") else float(lc.rope_theta),
+        mask_token_id=model.get_vision_tower().config.llm_mask_token_id,
+        depth_token_id=model.get_vision_tower().config.llm_depth_token_id,
+        enable_region=True, enable_depth=True,
+        tokenizer_model_max_length=getattr(lc, "tokenizer_model_max_length", None),
+        padding_side=getattr(lc, "tokenizer_padding_side", "right"), eos_token_id=None,
+    )
+
+
+def run_reference(model, ids, images, depths, masks, max_new_tokens):
+    """Run the reference path with hooks; returns dict of stage tensors + generated ids."""
+    st = {}
+    hooks = []
+    vt = model.get_vision_tower()
+    tower_calls = []
+    hooks.append(vt.register_forward_hook(lambda m, i, o: tower_calls.append(o.detach().clone())))
+    rex = model.get_region_extractor()
+    orig_fr = rex.feature_refinement
+
+    def fr(x):
+        h, l = orig_fr(x)
+        st["hres"], st["lres"] = h.detach().clone(), l.detach().clone()
+        return h, l
+
+    rex.feature_refinement = fr
+    hooks.append(rex.register_forward_hook(lambda m, i, o: st.update(
+        mask_embeds=torch.stack([e.detach() for e in o[0]]), depth_embeds=torch.stack([e.detach() for e in o[1]]))))
+    hooks.append(model.get_mm_projector().register_forward_hook(lambda m, i, o: st.update(image_features=o.detach().clone())))
+    with torch.no_grad():
+        (_, pos, am, _, embeds, _) = model.prepare_inputs_labels_for_multimodal(
+            ids, None, None, None, None, images, masks, depths)
+        st["tower_features"], st["depth_features"] = tower_calls[0], tower_calls[1]
+        st["inputs_embeds"] = embeds.detach().clone()
+        out = model.llm(inputs_embeds=embeds.to(model.dtype), output_hidden_states=True, use_cache=False)
+        st["prefill_logits"] = out.logits.float().detach().clone()
+        st["hidden_states"] = torch.stack([h.detach() for h in out.hidden_states])  # last one is post-final-norm
+    for h in hooks:
+        h.remove()
+    rex.feature_refinement = orig_fr
+    with torch.no_grad():
+        gen = model.generate(input_ids=ids, images=images, depths=depths, masks=masks, do_sample=False,
+                             max_new_tokens=max_new_tokens, use_cache=True, eos_token_id=None, pad_token_id=0,
+                             min_new_tokens=max_new_tokens)
+        gen2 = model.generate(input_ids=ids, images=images, depths=depths, masks=masks, do_sample=False,
+                              max_new_tokens=max_new_tokens, use_cache=True, eos_token_id=None, pad_token_id=0,
+                              min_new_tokens=max_new_tokens)
+    assert torch.equal(gen, gen2), "reference generate() is not deterministic"
+    st["new_ids"] = gen
+    return st
+
+
+def check(name, a, b, atol, rtol=0.0):
+    a, b = a.float(), b.float()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    ok = err <= atol + rtol * ref
+    print(f"  {name:18s} max|d|={err:.3e} (ref max {ref:.3e}) {'OK' if ok else 'MISMATCH'}")
+    assert ok, name
+
+
+def tensor_np(t):
+    t = t.detach()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy().view(np.uint16)  # raw bf16 bits
+    return t.numpy()
+
+
+def mint_model_case(dtype: torch.dtype, fname: str, max_new_tokens=12):
+    print(f"== {fname}")
+    with tempfile.TemporaryDirectory() as td:
+        model, tok = rh.build_tiny_reference_model(td, llm=TINY_LLM, vit=TINY_VIT, dtype="torch.float32", seed=0)
+    # make norm gains / biases non-trivial so that parity checks see them
+    g = torch.Generator().manual_seed(123)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("norm.weight") or "layernorm" in n or "layer_norm" in n or n.endswith("module.1.weight") \
+                    or n == "mm_projector.layers.1.weight":
+                if n.endswith("weight"):
+                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif n.endswith(".bias"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    model = model.to(dtype)
+    cfg = cfg_from(model, tok)
+    w = canonical_state_dict(model)
+    ids, images, depths, masks = so.synth_inputs(cfg, batch=1, regions=2, prompt_len=15, seed=1, dtype=dtype)
+    ref = run_reference(model, ids, images, depths, masks, max_new_tokens)
+    # ---- pin the restatement against the reference
+    new_ids, st = so.generate(w, cfg, ids, images, depths, masks, max_new_tokens=max_new_tokens, return_stages=True,
+                              model_dtype=dtype)
+    tol = 1e-5 if dtype == torch.float32 else 0.0
+    rt = 1e-5 if dtype == torch.float32 else 2e-2
+    for k in ("tower_features", "depth_features", "hres", "lres", "image_features", "inputs_embeds"):
+        check(k, st[k], ref[k], tol, rt)
+    check("mask_embeds", torch.stack(st["mask_embeds"]), ref["mask_embeds"], tol, rt)
+    check("depth_embeds", torch.stack(st["depth_embeds"]), ref["depth_embeds"], tol, rt)
+    check("prefill_logits", st["prefill_logits"], ref["prefill_logits"], 1e-4 if dtype == torch.float32 else 0.0, rt)
+    if dtype == torch.float32:
+        assert torch.equal(new_ids, ref["new_ids"]), (new_ids, ref["new_ids"])
+        print("  greedy ids identical:", new_ids.tolist())
+    else:
+        agree = (new_ids == ref["new_ids"]).float().mean().item()
+        print(f"  greedy ids agreement (bf16, informational): {agree:.2f}")
+    assert ref["inputs_embeds"].shape[1] == 15 - 1 + 196
+    # ---- write
+    blob = {"cfg_json": np.frombuffer(json.dumps(cfg.to_dict()).encode(), dtype=np.uint8),
+            "dtype": np.frombuffer(str(dtype).encode(), dtype=np.uint8),
+            "in.input_ids": ids.numpy(),
+            "in.images_q32": (images.float() * 32).round().to(torch.int8).numpy(),   # pixel = q / 32
+            "in.depths_q32": (depths.float()[:, :1] * 32).round().to(torch.int8).numpy(),  # 1 channel, x3
+            "in.masks_u8": torch.stack(masks).float().to(torch.uint8).numpy()}
+    for k, v in w.items():
+        blob["w." + k] = tensor_np(v)
+    for k, v in ref.items():
+        if k == "hres":  # 11664 x C: keep every 7th row (+ the last) to keep the fixture small
+            idx = torch.cat([torch.arange(0, v.shape[1], 7), torch.tensor([v.shape[1] - 1])])
+            blob["ref.hres_rows_idx"] = idx.numpy()
+            blob["ref.hres_rows"] = tensor_np(v[:, idx].contiguous())
+            continue
+        blob["ref." + k] = tensor_np(v)
+    # per-step teacher-forced logits from the restatement (== reference ids in fp32)
+    blob["ref.step_logits"] = tensor_np(st["step_logits"])
+    np.savez_compressed(os.path.join(GOLD, fname), **blob)
+    print("  wrote", fname, f"{os.path.getsize(os.path.join(GOLD, fname)) / 1e6:.2f} MB")
+
+
+def _load_standalone(relpath, name):
+    import importlib.util
+
+    rh.install_shims()
+    spec = importlib.util.spec_from_file_location(name, os.path.join(rh.REFERENCE_ROOT, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def mint_region_kat():
+    """Model-free known-answer vectors straight from the reference modules (SURVEY 8c iii)."""
+    print("== region_kat.npz")
+    be = _load_standalone("llava/model/region_extractor/base_extractor.py", "_ref_base_extractor")
+    bp = _load_standalone("llava/model/multimodal_projector/base_projector.py", "_ref_base_projector")
+    g = torch.Generator().manual_seed(7)
+    blob = {}
+    mp = be.MaskPooling()
+    C = 16
+
+    def case(tag, L, S, masks, dtype=torch.float32):
+        # features = int8 / 64: exact in fp32 and bf16, stored as int8
+        feat_q = torch.randint(-128, 128, (1, L, C), generator=g, dtype=torch.int16).to(torch.int8)
+        feat = (feat_q.float() / 64).to(dtype)
+        with torch.no_grad():
+            out = mp(feat, [masks.to(dtype)], return_list=True)[0]
+        mine = so.mask_pooling(feat, [masks.to(dtype)])[0]
+        check("pool/" + tag, mine, out, 1e-6 if dtype == torch.float32 else 0.0, 0 if dtype == torch.float32 else 1e-2)
+        blob[f"pool.{tag}.feat_q64"] = feat_q[0].numpy()
+        blob[f"pool.{tag}.masks_q16"] = (masks * 16).round().to(torch.uint8).numpy()  # mask = q / 16
+        blob[f"pool.{tag}.out"] = tensor_np(out)
+
+    S = 384
+    boxes = torch.zeros((5, S, S))
+    boxes[0, 10:200, 30:90] = 1
+    boxes[1, 300:384, 0:384] = 1
+    boxes[2, 100:101, 200:201] = 1  # single pixel
+    boxes[3] = 1  # all ones -> mean of features
+    # boxes[4] stays empty -> zeros (denorm = 1e-8)
+    case("rgb108", 108 * 108, S, boxes)
+    case("depth27", 27 * 27, S, boxes)
+    soft = torch.randint(0, 17, (3, 336, 336), generator=g).float() / 16
+    case("soft336_to_108", 108 * 108, 336, soft)
+    case("soft336_to_96", 96 * 96, 336, soft)
+    case("rgb108_bf16", 108 * 108, S, boxes, torch.bfloat16)
+    small = (torch.rand((4, 56, 56), generator=g) > 0.5).float()
+    case("up56_to_108", 108 * 108, 56, small)  # upsampling branch of the bilinear map
+
+    # DownSampleBlock ordering
+    x = torch.randn((2, 729, 8), generator=g)
+    with torch.no_grad():
+        y = bp.DownSampleBlock()(x)
+    n, L, c = x.shape
+    mine = so.flat_square(x.reshape(n, 27, 27, c)).reshape(n, -1, 4 * c)
+    assert torch.equal(mine, y)
+    blob["s2d.in"], blob["s2d.out"] = x.numpy(), y.numpy()
+
+    # feature refinement module (deconv -> LN2d -> GELU -> deconv -> GELU) + adaptive pool, 27->108 and 24->96
+    C = 16
+    for tag, hs in (("27", 27), ("24", 24)):
+        torch.manual_seed(11)
+        frm = be.get_feature_refinement_module(C)
+        with torch.no_grad():
+            frm[1].weight.copy_(1 + 0.1 * torch.randn(C, generator=g))
+            frm[1].bias.copy_(0.1 * torch.randn(C, generator=g))
+        feats = torch.randn((1, hs * hs, C), generator=g)
+        with torch.no_grad():
+            h = frm(feats.reshape(1, hs, hs, C).permute(0, 3, 1, 2))
+            l = torch.nn.AdaptiveAvgPool2d(27)(h)
+        w = {so.RE + "feature_refinement_module." + k: v for k, v in frm.state_dict().items()}
+        mh, ml = so.feature_refinement(w, feats)
+        check("refine/hres" + tag, mh, h.flatten(2).transpose(1, 2), 1e-5)
+        check("refine/lres" + tag, ml, l.flatten(2).transpose(1, 2), 1e-5)
+        blob[f"refine{tag}.in"] = feats.numpy()
+        for k, v in frm.state_dict().items():
+            blob[f"refine{tag}.w.{k}"] = v.numpy()
+        hf = h.flatten(2).transpose(1, 2).contiguous()
+        idx = torch.cat([torch.arange(0, hf.shape[1], 5), torch.tensor([hf.shape[1] - 1])])
+        blob[f"refine{tag}.hres_rows_idx"] = idx.numpy()
+        blob[f"refine{tag}.hres_rows"] = hf[:, idx].contiguous().numpy()
+        blob[f"refine{tag}.lres"] = l.flatten(2).transpose(1, 2).contiguous().numpy()
+    np.savez_compressed(os.path.join(GOLD, "region_kat.npz"), **blob)
+    print("  wrote region_kat.npz", f"{os.path.getsize(os.path.join(GOLD, 'region_kat.npz')) / 1e6:.2f} MB")
+
+
+def mint_tokenizer_kat():
+    """tokenizer_image_token (llava/mm_utils.py:545-570) against a BOS-adding fake tokenizer."""
+    print("== tokenizer_kat.json")
+    rh.install_shims()
+    from llava.mm_utils import tokenizer_image_token
+
+    class FakeTok:
+        bos_token_id = 1
+
+        def __call__(self, text):
+            class R:
+                pass
+
+            r = R()
+            r.input_ids = [1] + [3 + (sum(map(ord, wd)) % 90) for wd in text.split()]
+            return r
+
+    cases = ["aa bbb <image>\ncccc d", "<image>\ncccc <image> d", "no image here", "<image>", "x <image> y <image> z <image>"]
+    out = []
+    for c in cases:
+        out.append({"prompt": c, "ids": tokenizer_image_token(c, FakeTok()),
+                    "ids_lstrip": tokenizer_image_token(c, FakeTok(), lstrip=True)})
+    with open(os.path.join(GOLD, "tokenizer_kat.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    mint_region_kat()
+    mint_tokenizer_kat()
+    mint_model_case(torch.float32, "tiny_fp32.npz")
+    mint_model_case(torch.bfloat16, "tiny_bf16.npz")
+    print("golden vectors written to", GOLD)
