@@ -1,0 +1,248 @@
+/*
+ * srgpt.h -- C ABI of libsrgpt_hip.so: the MI355X (gfx950) kernels behind SpatialRGPT's region-grounded
+ * multimodal forward/generate path.
+ *
+ * The reference (AnjieCheng/SpatialRGPT @ 2024-12-18) is pure Python; it has no FFI/plugin seam of its
+ * own.  Each entry point below therefore names the reference *function* whose
+ * arithmetic it replaces (file:line relative to the reference root).  The Python host
+ * (spatialrgpt_amd/) keeps the reference's call signatures and binds these symbols with ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name starts with `h_`; tensors are dense row-major
+ *   - `dtype` selects the storage type of activations AND weights: SRGPT_F32 or SRGPT_BF16;
+ *     accumulation is always fp32.  bf16 is the parity/benchmark dtype, fp32 exists for tight parity
+ *     checks of the same code path
+ *   - every function only enqueues work on `stream` (a hipStream_t) and returns immediately;
+ *     nothing allocates, nothing synchronises (except srgpt_graph_* creation), no globals
+ *   - return value: 0 on success, negative SRGPT_ERR_* otherwise; srgpt_last_error() gives the text
+ *     (thread-local).  The Python host maps codes to the exceptions the reference raises.
+ */
+#ifndef SRGPT_H_
+#define SRGPT_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* srgpt_stream_t; /* hipStream_t */
+
+enum { SRGPT_F32 = 0, SRGPT_BF16 = 1 };
+enum { SRGPT_ACT_NONE = 0, SRGPT_ACT_GELU_ERF = 1, SRGPT_ACT_GELU_TANH = 2, SRGPT_ACT_SILU = 3 };
+enum {
+  SRGPT_OK = 0,
+  SRGPT_ERR_ARG = -1,      /* -> ValueError */
+  SRGPT_ERR_UNSUPPORTED = -2, /* -> NotImplementedError */
+  SRGPT_ERR_LAUNCH = -3,   /* -> RuntimeError */
+  SRGPT_ERR_STATE = -4     /* -> RuntimeError */
+};
+/* output-row mapping of srgpt_gemm */
+enum {
+  SRGPT_OUT_PLAIN = 0,     /* C[m, n]                                                       */
+  SRGPT_OUT_DECONV2X = 1   /* ConvTranspose2d(k=2,s=2) pixel shuffle, channels-last (see gemm) */
+};
+
+const char* srgpt_last_error(void);
+int srgpt_abi_version(void);
+/* number of compute units of the current device (host query, used to size persistent grids) */
+int srgpt_device_cus(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM family: every nn.Linear / conv-as-GEMM on the path.
+ *   C[M,N] = act(A[M,K] @ W[N,K]^T + bias[N]) + residual
+ * replaces: HF SiglipAttention/SiglipMLP Linear layers (third-party, called from
+ * multimodal_encoder/vision_encoder.py:119-129), region_extractor/base_extractor.py:93-96,125-126
+ * (ConvTranspose2d + connectors), multimodal_projector/base_projector.py:76-79,
+ * transformers_replace/models/llama/modeling_llama.py:300-336 (q/k/v/o), :194-223 (MLP), :1044 (lm_head).
+ *   - A row stride lda, C row stride ldc (elements); W dense [N,K]; K % 8 == 0 (bf16) / K % 4 == 0 (f32)
+ *   - bias may be NULL; bias index is n % bias_mod when bias_mod > 0 (deconv: bias per channel)
+ *   - residual may be NULL; residual row is (m % res_mod) when res_mod > 0 (position embeddings), ld = N
+ *   - out_f32 != 0: C is written as fp32 regardless of dtype (logits.float(), modeling_llama.py:1045)
+ *   - out_mode SRGPT_OUT_DECONV2X: A rows are pixels (img, i, j) of a [n_img, gw, gw] grid, N = 4*Cout
+ *     ordered n = (a*2+b)*Cout + co; C is the channels-last [n_img, 2gw, 2gw, Cout] map and
+ *     element (m,n) lands at pixel (2i+a, 2j+b), channel co.  `gw` passes the grid width.
+ *   - M <= 8 dispatches to the weight-streaming (HBM-bound) path used by decode.
+ * --------------------------------------------------------------------------------------------- */
+int srgpt_gemm(const void* A, const void* W, const void* bias, const void* residual, void* C,
+               int M, int N, int K, int lda, int ldc, int act, int bias_mod, int res_mod,
+               int out_f32, int out_mode, int gw, int dtype, srgpt_stream_t stream);
+
+/* Decode-only fused GEMVs (M = batch <= 4 rows), weights streamed once from HBM:
+ *   norm_w != NULL : x <- RMSNorm(x) * norm_w first (modeling_llama.py:61-75) (rounded to dtype like torch)
+ *   swiglu != 0    : W = [gate rows(N); up rows(N)], out[n] = silu(gate.x) * (up.x) (modeling_llama.py:221)
+ *   residual       : out = residual + (W x)   (decoder layer residual adds, modeling_llama.py:650-684)
+ */
+int srgpt_gemv(const void* x, const void* W, const void* norm_w, float norm_eps, const void* residual,
+               void* out, int batch, int N, int K, int swiglu, int out_f32, int dtype, srgpt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Normalisations.
+ * srgpt_layernorm: nn.LayerNorm over the last dim (+ optional activation) -- HF SigLIP layer_norm1/2,
+ *   base_projector.py:75 LayerNorm(4C), and LayerNorm2d over channels of a channels-last map followed by
+ *   GELU (base_extractor.py:12-24,94-95).
+ * srgpt_rmsnorm: LlamaRMSNorm (modeling_llama.py:61-75).
+ * --------------------------------------------------------------------------------------------- */
+int srgpt_layernorm(const void* x, const void* w, const void* b, void* y, int rows, int cols, float eps,
+                    int act, int dtype, srgpt_stream_t stream);
+int srgpt_rmsnorm(const void* x, const void* w, void* y, int rows, int cols, float eps, int dtype,
+                  srgpt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention.
+ * srgpt_attention: softmax(scale * Q K^T [+ causal]) V with fp32 softmax, GQA by head index division.
+ *   replaces HF SiglipAttention eager/sdpa (non-causal, called via vision_encoder.py:119-129) and
+ *   LlamaFlashAttention2 / flash_attn_func (modeling_llama.py:398-566) for prefill.
+ *   Q[b, t, h, :]  at q  + b*q_bs  + t*q_ts  + h*q_hs ; K/V[b, s, hk, :] likewise; O dense [b, t, h, d].
+ *   causal: key s visible to query t iff s <= t + (Tk - Tq).
+ *   kv_len (device int[B], may be NULL): per-row number of valid keys (right-padded batches).
+ * --------------------------------------------------------------------------------------------- */
+int srgpt_attention(const void* q, const void* k, const void* v, void* o, int B, int Tq, int Tk, int Hq,
+                    int Hkv, int D, int64_t q_bs, int64_t q_ts, int64_t q_hs, int64_t k_bs, int64_t k_ts,
+                    int64_t k_hs, int64_t v_bs, int64_t v_ts, int64_t v_hs, float scale, int causal,
+                    const int* kv_len, int dtype, srgpt_stream_t stream);
+
+/* RoPE + KV-cache append (modeling_llama.py:81-191 rotary, :451-456 cache growth -- here a static cache).
+ *   qkv: [B*T, (Hq+2Hkv)*D] packed projections; q is rotated in place; rotated k and v are written to
+ *   kcache/vcache [B, Hkv, max_pos, D] at positions pos0[b] + t  (pos0: device int[B], NULL = 0).
+ *   cos_tab/sin_tab: [max_pos, D/2] in `dtype`, built ONCE at load time by the host exactly as
+ *   LlamaRotaryEmbedding does (fp32 angle = position * inv_freq, cos/sin, cast to dtype; linear
+ *   scaling of language_model/builder.py:31-38 folded into inv_freq) -- a table, not on-device trig. */
+int srgpt_rope_kv_append(void* qkv, void* kcache, void* vcache, const int* pos0, const void* cos_tab,
+                         const void* sin_tab, int B, int T, int Hq, int Hkv, int D, int max_pos, int dtype,
+                         srgpt_stream_t stream);
+
+/* Decode attention for one new token per sequence against the static cache, fused with RoPE of the new
+ * q/k and the cache append (same reference lines as above + flash-attn decode, modeling_llama.py:540-566).
+ *   qkv [B, (Hq+2Hkv)*D] raw projections of the new token; pos (device int[B]) = tokens already cached.
+ *   ws: fp32 workspace of srgpt_decode_attn_ws_floats(B,Hq,D) floats.  out [B, Hq*D]. */
+int64_t srgpt_decode_attn_ws_floats(int B, int Hq, int D);
+int srgpt_decode_attention(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
+                           const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D,
+                           int max_pos, int dtype, srgpt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Region extractor (SpatialRGPT specific).
+ * srgpt_region_pool: MaskPooling.forward (region_extractor/base_extractor.py:32-84) for ONE image:
+ *   bilinear resample (align_corners=False, no antialias, scale_factor semantics of F.interpolate) of the
+ *   M masks [M, mh, mw] (dtype) to the fw x fw feature grid, cast to dtype, L1-normalise
+ *   (sum + 1e-8), weighted reduce over feat [fw*fw, C] -> out [M, C].  Rounding points follow SURVEY 9.2.
+ *   rscale_h/w = (float)(1.0 / scale_factor) as ATen's upsample kernel receives it (host computes
+ *   scale_factor = sqrt(L / (mh*mw)) in double like base_extractor.py:53-54); M <= 16 per call.
+ *   mask_dtype: storage type of `masks` (SRGPT_F32 or SRGPT_BF16) -- the reference does mask.float().
+ *   ws: fp32 workspace of srgpt_region_pool_ws_floats(M, fw, C) floats.
+ * srgpt_avgpool: AdaptiveAvgPool2d(out_w) on a channels-last map (base_extractor.py:123,145).
+ * srgpt_s2d: DownSampleBlock (multimodal_projector/base_projector.py:32-52) -- zero-pad to even, 2x2
+ *   space-to-depth in the reference's (column-major block) order; [n, g*g, C] -> [n, ceil(g/2)^2, 4C].
+ * srgpt_im2col: patch extraction for the SigLIP patch-embed conv (Conv2d k=s=patch, 'valid'):
+ *   images [n,3,S,S] -> [n*g*g, kp] rows ordered (c, ky, kx), zero-padded from 3*p*p to kp columns.
+ * --------------------------------------------------------------------------------------------- */
+int64_t srgpt_region_pool_ws_floats(int M, int fw, int C);
+int srgpt_region_pool(const void* feat, const void* masks, void* out, float* ws, int M, int mh, int mw,
+                      int fw, int C, float rscale_h, float rscale_w, int mask_dtype, int dtype,
+                      srgpt_stream_t stream);
+int srgpt_avgpool(const void* x, void* y, int n_img, int in_w, int out_w, int C, int dtype,
+                  srgpt_stream_t stream);
+int srgpt_s2d(const void* x, void* y, int n_img, int g, int C, int dtype, srgpt_stream_t stream);
+int srgpt_im2col(const void* images, void* out, int n_img, int S, int patch, int kp, int dtype,
+                 srgpt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Token stream (llava/model/llava_arch.py:434-539).
+ * srgpt_embed_rows: out[i,:] = table[ids[i],:]   (embed_tokens; ids are int64, -200 already mapped to 0)
+ * srgpt_scatter_rows: dst[idx[i],:] = src[src_idx ? src_idx[i] : i,:]  (image / <mask> / <depth> row
+ *   placement; int32 indices; idx[i] < 0 skips the row)
+ * srgpt_silu_mul: out = silu(gate) * up over [rows, inter] from a packed [rows, 2*inter] buffer
+ * srgpt_argmax: ids_out[b] = argmax_v logits[b, v] (fp32 logits; first max wins like torch.argmax)
+ * --------------------------------------------------------------------------------------------- */
+int srgpt_embed_rows(const void* table, const int64_t* ids, void* out, int n, int cols, int dtype,
+                     srgpt_stream_t stream);
+int srgpt_scatter_rows(const void* src, const int* src_idx, const int* idx, void* dst, int n, int cols,
+                       int dtype, srgpt_stream_t stream);
+int srgpt_silu_mul(const void* gu, void* out, int rows, int inter, int dtype, srgpt_stream_t stream);
+int srgpt_argmax(const float* logits, int64_t* ids_out, int B, int V, srgpt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Composite: vision tower (VisionTower.forward, multimodal_encoder/vision_encoder.py:115-132 over HF
+ * SiglipVisionModel; returns hidden_states[select_layer], i.e. runs `n_layers_run` encoder layers).
+ * All weights device pointers in `dtype`; per-layer arrays are HOST arrays of device pointers.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int dtype, hidden, inter, heads, n_layers_run, image_size, patch, kp; /* kp: padded 3*p*p */
+  float eps;
+  const void* patch_w;  /* [hidden, kp] (conv weight flattened (c,ky,kx), zero padded) */
+  const void* patch_b;  /* [hidden] */
+  const void* pos_emb;  /* [grid*grid, hidden] */
+  const void* const* ln1_w; const void* const* ln1_b;
+  const void* const* wqkv;  const void* const* bqkv;   /* [3*hidden, hidden] rows q;k;v */
+  const void* const* wo;    const void* const* bo;
+  const void* const* ln2_w; const void* const* ln2_b;
+  const void* const* w1;    const void* const* b1;     /* [inter, hidden] */
+  const void* const* w2;    const void* const* b2;     /* [hidden, inter] */
+} srgpt_vit_weights;
+
+/* workspace bytes for n_img images */
+int64_t srgpt_vit_ws_bytes(const srgpt_vit_weights* w, int n_img);
+/* images [n_img,3,S,S] -> out [n_img, grid^2, hidden] */
+int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images, void* out, void* ws, int n_img,
+                      srgpt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Composite: Llama decoder (LlamaForCausalLM.forward, modeling_llama.py:972-1110 inference branch,
+ * LlamaModel.forward :824-936, LlamaDecoderLayer :611-684) with a static KV cache.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int dtype, hidden, inter, layers, heads, kv_heads, head_dim, vocab;
+  float rms_eps;
+  const void* rope_cos;    /* [max_pos, head_dim/2] (see srgpt_rope_kv_append) */
+  const void* rope_sin;
+  const void* embed;       /* [vocab, hidden] */
+  const void* final_norm;  /* [hidden] */
+  const void* lm_head;     /* [vocab, hidden] */
+  const void* const* attn_norm; /* per layer [hidden] */
+  const void* const* wqkv;      /* per layer [(heads+2*kv_heads)*head_dim, hidden]  rows q;k;v */
+  const void* const* wo;        /* per layer [hidden, heads*head_dim] */
+  const void* const* mlp_norm;  /* per layer [hidden] */
+  const void* const* wgu;       /* per layer [2*inter, hidden]  rows gate;up */
+  const void* const* wdown;     /* per layer [hidden, inter] */
+} srgpt_llm_weights;
+
+typedef struct {
+  int batch, max_pos;
+  void* kcache;   /* [layers, batch, kv_heads, max_pos, head_dim] */
+  void* vcache;
+  int* pos;       /* device int[batch]: tokens already in the cache */
+  int64_t* tok;   /* device int64[batch]: next input token id (decode) */
+  int64_t* out_ids; /* device int64[batch, max_new]: generated ids, column = *step */
+  int* step;      /* device int[1]: decode step counter */
+  int max_new;
+  int ws_tokens;  /* max prompt tokens per sequence the workspace was sized for */
+  void* ws;       /* workspace, srgpt_llm_ws_bytes(w, batch, ws_tokens) */
+  float* logits;  /* [batch, vocab] fp32 (last position) */
+} srgpt_llm_state;
+
+int64_t srgpt_llm_ws_bytes(const srgpt_llm_weights* w, int batch, int max_tokens);
+/* Prefill: inputs_embeds [B, T, hidden] (already spliced), all rows valid (equal-length prompts).
+ * Fills the cache, sets pos[b] = T, writes last-position logits to st->logits; if all_logits != NULL
+ * also writes fp32 logits for every position [B, T, vocab]; if hidden_out != NULL writes the
+ * (layers+1) pre-norm hidden states [layers+1, B, T, hidden] (parity hook). */
+int srgpt_llm_prefill(const srgpt_llm_weights* w, srgpt_llm_state* st, const void* inputs_embeds, int T,
+                      float* all_logits, void* hidden_out, srgpt_stream_t stream);
+/* One greedy decode step, entirely device-side: embeds st->tok, runs the layers against the cache,
+ * argmax -> st->tok, st->out_ids[:, *step], ++pos, ++*step.  No host sync. */
+int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream);
+/* first token after prefill: argmax(st->logits) -> tok / out_ids[:,0] / step=1 */
+int srgpt_llm_sample_first(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream);
+
+/* hipGraph capture of one decode step (replayed per token; removes per-launch host cost). */
+typedef struct srgpt_graph srgpt_graph;
+int srgpt_llm_decode_graph_create(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream,
+                                  srgpt_graph** out);
+int srgpt_graph_launch(srgpt_graph* g, int times, srgpt_stream_t stream);
+int srgpt_graph_destroy(srgpt_graph* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRGPT_H_ */

@@ -1,0 +1,137 @@
+"""ctypes binding of libsrgpt_hip.so (the C ABI declared in include/srgpt.h).
+
+The product path has NO fallback: if the HIP extension is missing or fails to load, importing any
+compute entry point raises immediately (build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C spatialrgpt_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrgpt_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU = 0, 1, 2, 3
+OUT_PLAIN, OUT_DECONV2X = 0, 1
+ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_STATE = -1, -2, -3, -4
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class VitWeights(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("hidden", i32), ("inter", i32), ("heads", i32), ("n_layers_run", i32),
+        ("image_size", i32), ("patch", i32), ("kp", i32), ("eps", f32),
+        ("patch_w", vp), ("patch_b", vp), ("pos_emb", vp),
+        ("ln1_w", C.POINTER(vp)), ("ln1_b", C.POINTER(vp)),
+        ("wqkv", C.POINTER(vp)), ("bqkv", C.POINTER(vp)),
+        ("wo", C.POINTER(vp)), ("bo", C.POINTER(vp)),
+        ("ln2_w", C.POINTER(vp)), ("ln2_b", C.POINTER(vp)),
+        ("w1", C.POINTER(vp)), ("b1", C.POINTER(vp)),
+        ("w2", C.POINTER(vp)), ("b2", C.POINTER(vp)),
+    ]
+
+
+class LlmWeights(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("hidden", i32), ("inter", i32), ("layers", i32), ("heads", i32), ("kv_heads", i32),
+        ("head_dim", i32), ("vocab", i32), ("rms_eps", f32),
+        ("rope_cos", vp), ("rope_sin", vp), ("embed", vp), ("final_norm", vp), ("lm_head", vp),
+        ("attn_norm", C.POINTER(vp)), ("wqkv", C.POINTER(vp)), ("wo", C.POINTER(vp)),
+        ("mlp_norm", C.POINTER(vp)), ("wgu", C.POINTER(vp)), ("wdown", C.POINTER(vp)),
+    ]
+
+
+class LlmState(C.Structure):
+    _fields_ = [
+        ("batch", i32), ("max_pos", i32), ("kcache", vp), ("vcache", vp), ("pos", vp), ("tok", vp),
+        ("out_ids", vp), ("step", vp), ("max_new", i32), ("ws_tokens", i32), ("ws", vp), ("logits", vp),
+    ]
+
+
+_SIGNATURES = {
+    "srgpt_last_error": (C.c_char_p, []),
+    "srgpt_abi_version": (i32, []),
+    "srgpt_device_cus": (i32, []),
+    "srgpt_gemm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "srgpt_gemv": (i32, [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "srgpt_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, i32, i32, vp]),
+    "srgpt_rmsnorm": (i32, [vp, vp, vp, i32, i32, f32, i32, vp]),
+    "srgpt_attention": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64, i64,
+                              i64, f32, i32, vp, i32, vp]),
+    "srgpt_rope_kv_append": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "srgpt_decode_attn_ws_floats": (i64, [i32, i32, i32]),
+    "srgpt_decode_attention": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "srgpt_region_pool_ws_floats": (i64, [i32, i32, i32]),
+    "srgpt_region_pool": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, i32, i32, vp]),
+    "srgpt_avgpool": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "srgpt_s2d": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "srgpt_im2col": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "srgpt_embed_rows": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "srgpt_scatter_rows": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "srgpt_silu_mul": (i32, [vp, vp, i32, i32, i32, vp]),
+    "srgpt_argmax": (i32, [vp, vp, i32, i32, vp]),
+    "srgpt_vit_ws_bytes": (i64, [C.POINTER(VitWeights), i32]),
+    "srgpt_vit_forward": (i32, [C.POINTER(VitWeights), vp, vp, vp, i32, vp]),
+    "srgpt_llm_ws_bytes": (i64, [C.POINTER(LlmWeights), i32, i32]),
+    "srgpt_llm_prefill": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp, i32, vp, vp, vp]),
+    "srgpt_llm_decode_step": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp]),
+    "srgpt_llm_sample_first": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp]),
+    "srgpt_llm_decode_graph_create": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp, C.POINTER(vp)]),
+    "srgpt_graph_launch": (i32, [vp, i32, vp]),
+    "srgpt_graph_destroy": (i32, [vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib: Optional[C.CDLL] = None
+
+
+class SrgptNativeError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libsrgpt_hip.so (once).  Raises SrgptNativeError if it is missing -- there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SrgptNativeError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+            "`make -C spatialrgpt_amd/csrc` (needs hipcc; cross-compiles for gfx950 without a GPU). "
+            "spatialrgpt_amd has no non-HIP fallback by design.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise SrgptNativeError(f"failed to load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SrgptNativeError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.srgpt_abi_version() != 1:
+        raise SrgptNativeError("libsrgpt_hip.so ABI version mismatch; rebuild the extension")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().srgpt_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Map C return codes to the exception types the reference raises (SURVEY 8b error conventions)."""
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == ERR_ARG:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(f"srgpt native error {rc}: {msg}")

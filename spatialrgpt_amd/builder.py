@@ -1,0 +1,149 @@
+"""`load_pretrained_model` -- the loader every reference caller uses (llava/model/builder.py:36-213, plain
+branch :141-159,183-213) for the reference's on-disk layout (llava_arch.py:181-250):
+
+    <model_path>/config.json                      LlavaConfig (enable_region, enable_depth, mm_* fields)
+    <model_path>/llm/               config.json + *.safetensors + tokenizer files   (HF LlamaForCausalLM)
+    <model_path>/vision_tower/      config.json + *.safetensors + preprocessor_config.json (HF SiglipVisionModel)
+    <model_path>/mm_projector/      *.safetensors   (layers.{1,2,4}.*)
+    <model_path>/region_extractor/  *.safetensors
+
+Differences from the reference, by design: weights are materialised directly in bf16 on the MI355X (the
+reference builds fp16 and its SpatialRGPT callers then cast to bf16, eval_spatial.py:221); 8-bit / 4-bit / LoRA
+/ MPT branches are out of scope and raise.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+
+import torch
+
+from .config import SrgptConfig
+from .constants import DEFAULT_DEPTH_TOKEN, DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_PATCH_TOKEN, DEFAULT_MASK_TOKEN
+from .mm_utils import SrgptImageProcessor
+
+
+def _read_json(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def _load_dir(d, prefix, out):
+    from safetensors.torch import load_file
+
+    files = sorted(glob.glob(os.path.join(d, "*.safetensors")))
+    if not files:
+        bins = sorted(glob.glob(os.path.join(d, "*.bin")))
+        if not bins:
+            raise ValueError(f"no weights found under {d}")
+        for b in bins:
+            for k, v in torch.load(b, map_location="cpu").items():
+                out[prefix + k] = v
+        return
+    for f in files:
+        for k, v in load_file(f).items():
+            out[prefix + k] = v
+
+
+def config_from_checkpoint(model_path: str) -> SrgptConfig:
+    top = _read_json(os.path.join(model_path, "config.json"))
+    lc = _read_json(os.path.join(model_path, "llm", "config.json"))
+    vc = _read_json(os.path.join(model_path, "vision_tower", "config.json"))
+    vc = vc.get("vision_config", vc)
+    arch = (vc.get("architectures") or [vc.get("model_type", "")])[0].lower() if (vc.get("architectures") or vc.get("model_type")) else ""
+    if "siglip" not in arch and "siglip" not in str(top.get("vision_tower_cfg", "")).lower() and "siglip" not in vc.get("model_type", ""):
+        raise ValueError(f"Unknown vision tower: {arch or vc.get('model_type')}")  # multimodal_encoder/builder.py:46
+    if top.get("mm_projector_cfg", {}).get("mm_projector_type", "mlp_downsample") != "mlp_downsample" \
+            if isinstance(top.get("mm_projector_cfg"), dict) else False:
+        raise ValueError(f"Unknown projector type: {top['mm_projector_cfg']}")
+    rs = lc.get("rope_scaling") or {}
+    factor = float(rs.get("factor", 1.0)) if rs.get("type", rs.get("rope_type")) == "linear" else 1.0
+    eos = lc.get("eos_token_id")
+    return SrgptConfig(
+        vit_hidden=vc["hidden_size"], vit_inter=vc["intermediate_size"], vit_layers=vc["num_hidden_layers"],
+        vit_heads=vc["num_attention_heads"], image_size=vc["image_size"], patch_size=vc["patch_size"],
+        vit_eps=vc.get("layer_norm_eps", 1e-6), select_layer=top.get("mm_vision_select_layer", -2) or -2,
+        select_feature=top.get("mm_vision_select_feature", "cls_patch") or "cls_patch",
+        hidden=lc["hidden_size"], inter=lc["intermediate_size"], layers=lc["num_hidden_layers"],
+        heads=lc["num_attention_heads"], kv_heads=lc.get("num_key_value_heads", lc["num_attention_heads"]),
+        vocab=lc["vocab_size"], rms_eps=lc.get("rms_norm_eps", 1e-5), rope_theta=float(lc.get("rope_theta", 10000.0)),
+        rope_factor=factor, max_position_embeddings=int(lc.get("model_max_length") or lc.get("max_position_embeddings", 4096)),
+        enable_region=bool(top.get("enable_region", False)), enable_depth=bool(top.get("enable_depth", False)),
+        tokenizer_model_max_length=lc.get("tokenizer_model_max_length"),
+        padding_side=lc.get("tokenizer_padding_side", "right"),
+        eos_token_id=eos[0] if isinstance(eos, list) else eos, pad_token_id=lc.get("pad_token_id"),
+        image_aspect_ratio=top.get("image_aspect_ratio", "resize") or "resize",
+        mm_use_im_start_end=bool(top.get("mm_use_im_start_end", False)),
+        mm_use_im_patch_token=bool(top.get("mm_use_im_patch_token", True)),
+    )
+
+
+def load_pretrained_model(model_path, model_name, model_base=None, load_8bit=False, load_4bit=False, device_map="auto",
+                          device="cuda", dtype=torch.bfloat16, **kwargs):
+    if load_8bit or load_4bit:
+        raise NotImplementedError("bitsandbytes 8/4-bit loading is out of scope (builder.py:40-60)")
+    if model_base is not None or "lora" in model_name.lower():
+        raise NotImplementedError("LoRA / delta checkpoints are out of scope (builder.py:64-139)")
+    from .model import LlavaLlamaModel
+
+    cfg = config_from_checkpoint(model_path)
+    sd = {}
+    _load_dir(os.path.join(model_path, "llm"), "llm.", sd)
+    _load_dir(os.path.join(model_path, "vision_tower"), "vision_tower.vision_tower.", sd)
+    _load_dir(os.path.join(model_path, "mm_projector"), "mm_projector.", sd)
+    if cfg.enable_region:
+        _load_dir(os.path.join(model_path, "region_extractor"), "region_extractor.", sd)
+
+    tokenizer = None
+    try:
+        from transformers import AutoTokenizer
+
+        tokenizer = AutoTokenizer.from_pretrained(os.path.join(model_path, "llm"), use_fast=False, legacy=False)
+    except Exception as e:  # tokenizer problems must not hide the model; callers that need it fail on use
+        import warnings
+
+        warnings.warn(f"could not load tokenizer from {model_path}/llm: {e}")
+    if tokenizer is not None:
+        if cfg.enable_region:  # builder.py:186-192
+            tokenizer.add_tokens([DEFAULT_MASK_TOKEN, DEFAULT_DEPTH_TOKEN], special_tokens=True)
+            cfg.mask_token_id = tokenizer.convert_tokens_to_ids(DEFAULT_MASK_TOKEN)
+            cfg.depth_token_id = tokenizer.convert_tokens_to_ids(DEFAULT_DEPTH_TOKEN)
+        if cfg.mm_use_im_patch_token:
+            tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
+        if cfg.mm_use_im_start_end:
+            tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
+        # resize_token_embeddings(len(tokenizer)) (builder.py:199): append rows initialised to the mean embedding
+        n_tok, emb = len(tokenizer), sd["llm.model.embed_tokens.weight"]
+        if n_tok > emb.shape[0]:
+            extra = n_tok - emb.shape[0]
+            sd["llm.model.embed_tokens.weight"] = torch.cat([emb, emb.float().mean(0, keepdim=True).to(emb.dtype).expand(extra, -1)], 0)
+            head = sd["llm.lm_head.weight"]
+            sd["llm.lm_head.weight"] = torch.cat([head, head.float().mean(0, keepdim=True).to(head.dtype).expand(extra, -1)], 0)
+        cfg.vocab = sd["llm.model.embed_tokens.weight"].shape[0]
+        if cfg.eos_token_id is None:
+            cfg.eos_token_id = tokenizer.eos_token_id
+        if cfg.pad_token_id is None:
+            cfg.pad_token_id = tokenizer.pad_token_id
+
+    image_processor = None
+    pp = os.path.join(model_path, "vision_tower", "preprocessor_config.json")
+    try:
+        from transformers import SiglipImageProcessor
+
+        image_processor = SiglipImageProcessor.from_pretrained(os.path.join(model_path, "vision_tower"))
+    except Exception:
+        if os.path.exists(pp):
+            j = _read_json(pp)
+            image_processor = SrgptImageProcessor(size=j.get("size", {}).get("height", cfg.image_size),
+                                                  image_mean=j.get("image_mean", (0.5, 0.5, 0.5)),
+                                                  image_std=j.get("image_std", (0.5, 0.5, 0.5)))
+        else:
+            image_processor = SrgptImageProcessor(size=cfg.image_size)
+
+    model = LlavaLlamaModel(cfg, sd, device=device, dtype=dtype, tokenizer=tokenizer, image_processor=image_processor,
+                            consume_state_dict=True)
+    lc = _read_json(os.path.join(model_path, "llm", "config.json"))
+    context_len = _read_json(os.path.join(model_path, "config.json")).get("max_sequence_length", 2048) \
+        if "max_sequence_length" in lc else 2048  # builder.py:207-211
+    return tokenizer, model, image_processor, context_len

@@ -1,0 +1,529 @@
+// Attention kernels.
+//  1. flash_bf16_kernel  -- prefill / ViT: MFMA (v_mfma_f32_16x16x32_bf16) flash attention, online fp32
+//     softmax.  Both products are issued "swapped" (S^T = K Q^T, O^T = V^T P^T) so the softmax row of a
+//     query lives in ONE lane column (col = lane & 15): row max/sum need two cross-lane steps, the
+//     rescale factor is lane-local, and P never leaves registers -- the PV contraction simply runs
+//     over the keys in the order the QK^T accumulator already holds them.
+//  2. simple_attn_kernel -- one wave per (query, head); any dtype / head_dim; fp32 parity path.
+//  3. decode_split/combine -- single new token against the static KV cache, flash-decoding split over
+//     keys, fused RoPE of the new q/k and cache append.  HBM/latency bound.
+#include "common.h"
+
+namespace {
+
+// ================================================================================================
+// 1. MFMA flash attention (bf16)
+// ================================================================================================
+constexpr int QBLK = 64, KVBLK = 64, VT_LD = 68;  // VT_LD: padded key stride of the transposed V tile
+
+struct AttnArgs {
+  const bf16_t *q, *k, *v;
+  bf16_t* o;
+  int Tq, Tk, Hq, Hkv, D;
+  int64_t q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs;
+  float scale;
+  const int* kv_len;
+};
+
+template <int HDP, bool CAUSAL>
+__global__ __launch_bounds__(256) void flash_bf16_kernel(AttnArgs a) {
+  constexpr int NS = HDP / 8;                 // 16-byte slots per K row
+  constexpr int SWM = (NS % 8 == 0) ? 7 : 3;  // swizzle mask (keeps a slot inside its aligned group)
+  constexpr int NKS = HDP / 32;               // k-steps of QK^T
+  constexpr int ND = HDP / 16;                // 16-wide d sub-tiles of the output
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[KVBLK * HDP];
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[HDP * VT_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QBLK;
+  const int hk = h / (a.Hq / a.Hkv);
+  const int klen = a.kv_len ? min(a.kv_len[b], a.Tk) : a.Tk;
+  const int qrow = q0 + wave * 16 + lq;  // query row owned by this lane column
+  const int coff = a.Tk - a.Tq;          // causal offset: key s visible iff s <= t + coff
+
+  // Q fragments (B operand of S^T = K Q^T): lane (n = q, kgroup g) holds Q[q][ks*32 + 8g .. +8]
+  bf16x8 qf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int d = ks * 32 + g * 8;
+    if (qrow < a.Tq && d < a.D)
+      qf[ks] = *reinterpret_cast<const bf16x8*>(a.q + b * a.q_bs + (int64_t)qrow * a.q_ts + h * a.q_hs + d);
+    else
+#pragma unroll
+      for (int i = 0; i < 8; ++i) qf[ks][i] = (bf16_t)0.f;
+  }
+
+  f32x4 o[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+
+  int kend = klen;
+  if (CAUSAL) kend = min(kend, q0 + QBLK + coff);  // keys beyond the last query of the block are masked
+  const bf16_t* kb = a.k + b * a.k_bs + hk * a.k_hs;
+  const bf16_t* vb = a.v + b * a.v_bs + hk * a.v_hs;
+
+  for (int k0 = 0; k0 < kend; k0 += KVBLK) {
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage K (row-major, swizzled slots) ----
+#pragma unroll
+    for (int i = 0; i < NS / 4; ++i) {
+      const int idx = tid + 256 * i;
+      const int key = idx / NS, c = idx - key * NS;
+      u32x4 val = {0, 0, 0, 0};
+      if (k0 + key < klen && c * 8 < a.D)
+        val = *reinterpret_cast<const u32x4*>(kb + (int64_t)(k0 + key) * a.k_ts + c * 8);
+      *reinterpret_cast<u32x4*>(Ks + key * HDP + ((c ^ (key & SWM)) << 3)) = val;
+    }
+    // ---- stage V transposed: Vt[d][key] ----
+#pragma unroll
+    for (int i = 0; i < NS / 4; ++i) {
+      const int idx = tid + 256 * i;
+      const int key = (idx & 15) | (((idx >> 6) & 3) << 4);
+      const int c = ((idx >> 4) & 3) | ((idx >> 8) << 2);
+      bf16x8 val;
+      if (k0 + key < klen && c * 8 < a.D)
+        val = *reinterpret_cast<const bf16x8*>(vb + (int64_t)(k0 + key) * a.v_ts + c * 8);
+      else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) val[j] = (bf16_t)0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VT_LD + key] = val[j];
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T : acc[s][r] = score(key = k0 + 16 s + 4 g + r, query = qrow) ----
+    float p[4][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int key = 16 * s + lq;  // A-operand row of this lane
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + key * HDP + (((ks * 4 + g) ^ (key & SWM)) << 3));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kidx = k0 + 16 * s + 4 * g + r;
+        bool ok = kidx < klen;
+        if (CAUSAL) ok = ok && (kidx <= qrow + coff);
+        const float sv = ok ? acc[r] * a.scale : -INFINITY;
+        p[s][r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m - m_use);  // m = -inf -> 0
+    float rs = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[s][r] = __expf(p[s][r] - m_use);
+        rs += p[s][r];
+      }
+    rs += __shfl_xor(rs, 16);
+    rs += __shfl_xor(rs, 32);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[i] *= alpha;
+
+    // ---- O^T += V^T P^T ; contraction index 8g+i <-> key 32j + 4g + i (i<4), 32j + 16 + 4g + (i-4) ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x8 pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pf[r] = (bf16_t)p[2 * j][r];
+        pf[4 + r] = (bf16_t)p[2 * j + 1][r];
+      }
+#pragma unroll
+      for (int ds = 0; ds < ND; ++ds) {
+        const bf16_t* vrow = Vt + (ds * 16 + lq) * VT_LD + 32 * j + 4 * g;
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 16);
+        bf16x8 vf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vf[r] = lo[r];
+          vf[4 + r] = hi[r];
+        }
+        o[ds] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[ds], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: O[b, q, h, d], d = 16 ds + 4 g + r ----
+  if (qrow < a.Tq) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    bf16_t* orow = a.o + (((int64_t)b * a.Tq + qrow) * a.Hq + h) * a.D;
+#pragma unroll
+    for (int ds = 0; ds < ND; ++ds) {
+      const int d = ds * 16 + 4 * g;
+      if (d < a.D) {  // D % 8 == 0 -> a group of 4 is entirely in or out
+        bf16x4 w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = (bf16_t)(o[ds][r] * inv);
+        *reinterpret_cast<bf16x4*>(orow + d) = w;
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// 2. simple attention: one wave per (query row, head)
+// ================================================================================================
+template <typename T>
+__global__ __launch_bounds__(64) void simple_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                         const T* __restrict__ v, T* __restrict__ o, int Tq, int Tk,
+                                                         int Hq, int Hkv, int D, int64_t q_bs, int64_t q_ts,
+                                                         int64_t q_hs, int64_t k_bs, int64_t k_ts, int64_t k_hs,
+                                                         int64_t v_bs, int64_t v_ts, int64_t v_hs, float scale,
+                                                         int causal, const int* __restrict__ kv_len) {
+  __shared__ float qs[256];
+  const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+  const int hk = h / (Hq / Hkv);
+  const int klen = kv_len ? min(kv_len[b], Tk) : Tk;
+  const T* qp = q + b * q_bs + (int64_t)t * q_ts + h * q_hs;
+  for (int d = lane; d < D; d += 64) qs[d] = to_f(qp[d]);
+  __syncthreads();
+  const T* kb = k + b * k_bs + hk * k_hs;
+  const T* vb = v + b * v_bs + hk * v_hs;
+  const int last = causal ? min(klen - 1, t + (Tk - Tq)) : klen - 1;
+  float m = -INFINITY, l = 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // d = lane + 64 * i, D <= 256
+  for (int k0 = 0; k0 <= last; k0 += 64) {
+    const int key = k0 + lane;
+    float s = -INFINITY;
+    if (key <= last) {
+      const T* kr = kb + (int64_t)key * k_ts;
+      float dot = 0.f;
+      for (int d = 0; d < D; ++d) dot = fmaf(qs[d], to_f(kr[d]), dot);
+      s = dot * scale;
+    }
+    const float m_new = fmaxf(m, wave_max(s));
+    const float alpha = __expf(m - m_new);
+    const float p = (key <= last) ? __expf(s - m_new) : 0.f;
+    l = l * alpha + wave_sum(p);
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] *= alpha;
+    const int nk = min(64, last + 1 - k0);
+    for (int j = 0; j < nk; ++j) {
+      const float pj = __shfl(p, j);
+      const T* vr = vb + (int64_t)(k0 + j) * v_ts;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d = lane + 64 * i;
+        if (d < D) acc[i] = fmaf(pj, to_f(vr[d]), acc[i]);
+      }
+    }
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  T* op = o + (((int64_t)b * Tq + t) * Hq + h) * D;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = lane + 64 * i;
+    if (d < D) op[d] = from_f<T>(acc[i] * inv);
+  }
+}
+
+// ================================================================================================
+// 3. decode attention: split over keys + combine
+// ================================================================================================
+constexpr int DEC_CHUNK_MAX = 256;
+constexpr int DEC_SPLIT_MAX = 64;
+
+static inline int decode_nsplit(int max_pos) {
+  int n = cdiv(max_pos, DEC_CHUNK_MAX);
+  if (n < 16) n = 16;
+  return n;
+}
+
+template <typename T, int D, int G>
+__global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__ qkv, T* __restrict__ kcache,
+                                                           T* __restrict__ vcache, const int* __restrict__ pos,
+                                                           const T* __restrict__ cos_tab, const T* __restrict__ sin_tab,
+                                                           float* __restrict__ ws, int Hq, int Hkv, int max_pos,
+                                                           int nsplit, float scale) {
+  constexpr int VEC = Vec16<T>::N;
+  constexpr int LPK = D / VEC;   // lanes per key
+  constexpr int KPW = 64 / LPK;  // keys per wave-instruction
+  constexpr int HALF = D / 2;
+  __shared__ float qs[G][D];
+  __shared__ float knew[D], vnew[D];
+  __shared__ float sc[G][DEC_CHUNK_MAX];
+  __shared__ float red[4][G][D];
+  __shared__ float stat_m[G], stat_l[G];
+
+  const int hk = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = pos[b];
+  const int total = P + 1;
+  const int chunk = (total + nsplit - 1) / nsplit;
+  const int kbeg = split * chunk, kend = min(kbeg + chunk, total);
+  const T* row = qkv + (size_t)b * (Hq + 2 * Hkv) * D;
+
+  // ---- rotate q (G heads) and the new k; stage v ----
+  for (int w = tid; w < (G + 1) * HALF; w += 256) {
+    const int hh = w / HALF, i = w - hh * HALF;
+    const float c = to_f(cos_tab[(size_t)P * HALF + i]), s = to_f(sin_tab[(size_t)P * HALF + i]);
+    const T* p = (hh < G) ? row + (size_t)(hk * G + hh) * D : row + (size_t)(Hq + hk) * D;
+    const float x1 = to_f(p[i]), x2 = to_f(p[i + HALF]);
+    const float o1 = rnd<T>(rnd<T>(x1 * c) + rnd<T>(-x2 * s));
+    const float o2 = rnd<T>(rnd<T>(x2 * c) + rnd<T>(x1 * s));
+    if (hh < G) {
+      qs[hh][i] = o1;
+      qs[hh][i + HALF] = o2;
+    } else {
+      knew[i] = o1;
+      knew[i + HALF] = o2;
+    }
+  }
+  for (int d = tid; d < D; d += 256) vnew[d] = to_f(row[(size_t)(Hq + Hkv + hk) * D + d]);
+  __syncthreads();
+  T* kc = kcache + ((size_t)b * Hkv + hk) * (size_t)max_pos * D;
+  T* vc = vcache + ((size_t)b * Hkv + hk) * (size_t)max_pos * D;
+  if (split == 0) {  // exactly one block per (b, hk) appends; nobody reads position P from the cache
+    for (int d = tid; d < D; d += 256) {
+      kc[(size_t)P * D + d] = from_f<T>(knew[d]);
+      vc[(size_t)P * D + d] = from_f<T>(vnew[d]);
+    }
+  }
+
+  float* wbase = ws + (((size_t)b * Hkv + hk) * G) * (size_t)DEC_SPLIT_MAX * (D + 2);
+  if (kbeg >= kend) {  // empty split
+    if (tid < G) {
+      float* wp = wbase + ((size_t)tid * DEC_SPLIT_MAX + split) * (D + 2);
+      wp[D] = -INFINITY;
+      wp[D + 1] = 0.f;
+    }
+    return;
+  }
+
+  const int sub = lane / LPK, dl = (lane % LPK) * VEC;
+  // ---- pass 1: scores ----
+  for (int key = kbeg + wave * KPW + sub; key < kend; key += 4 * KPW) {
+    float kv[VEC];
+    if (key == P) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) kv[i] = knew[dl + i];
+    } else {
+      const Vec16<T> t = *reinterpret_cast<const Vec16<T>*>(kc + (size_t)key * D + dl);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) kv[i] = t.get(i);
+    }
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) part = fmaf(kv[i], qs[gq][dl + i], part);
+#pragma unroll
+      for (int off = LPK >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off);
+      if ((lane % LPK) == 0) sc[gq][key - kbeg] = part * scale;
+    }
+  }
+  __syncthreads();
+  // ---- softmax statistics of the chunk, one wave per q head ----
+  const int n = kend - kbeg;
+  for (int gq = wave; gq < G; gq += 4) {
+    float mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sc[gq][i]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = lane; i < n; i += 64) {
+      const float pv = __expf(sc[gq][i] - mx);
+      sc[gq][i] = pv;
+      sum += pv;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) {
+      stat_m[gq] = mx;
+      stat_l[gq] = sum;
+    }
+  }
+  __syncthreads();
+  // ---- pass 2: O = P V ----
+  float acc[G][VEC];
+#pragma unroll
+  for (int gq = 0; gq < G; ++gq)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[gq][i] = 0.f;
+  for (int key = kbeg + wave * KPW + sub; key < kend; key += 4 * KPW) {
+    float vv[VEC];
+    if (key == P) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) vv[i] = vnew[dl + i];
+    } else {
+      const Vec16<T> t = *reinterpret_cast<const Vec16<T>*>(vc + (size_t)key * D + dl);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) vv[i] = t.get(i);
+    }
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+      const float pg = sc[gq][key - kbeg];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[gq][i] = fmaf(pg, vv[i], acc[gq][i]);
+    }
+  }
+#pragma unroll
+  for (int gq = 0; gq < G; ++gq)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float x = acc[gq][i];
+#pragma unroll
+      for (int off = LPK; off < 64; off <<= 1) x += __shfl_xor(x, off);
+      if (sub == 0) red[wave][gq][dl + i] = x;
+    }
+  __syncthreads();
+  for (int w = tid; w < G * D; w += 256) {
+    const int gq = w / D, d = w - gq * D;
+    float* wp = wbase + ((size_t)gq * DEC_SPLIT_MAX + split) * (D + 2);
+    wp[d] = red[0][gq][d] + red[1][gq][d] + red[2][gq][d] + red[3][gq][d];
+    if (d == 0) {
+      wp[D] = stat_m[gq];
+      wp[D + 1] = stat_l[gq];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void decode_combine_kernel(const float* __restrict__ ws, T* __restrict__ out, int Hq,
+                                                            int D, int nsplit) {
+  const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const float* wp = ws + ((size_t)b * Hq + h) * (size_t)DEC_SPLIT_MAX * (D + 2);
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, wp[(size_t)s * (D + 2) + D]);
+  float den = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float ms = wp[(size_t)s * (D + 2) + D];
+    if (ms > -INFINITY) den += __expf(ms - M) * wp[(size_t)s * (D + 2) + D + 1];
+  }
+  const float inv = den > 0.f ? 1.f / den : 0.f;
+  for (int d = lane; d < D; d += 64) {
+    float num = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+      const float ms = wp[(size_t)s * (D + 2) + D];
+      if (ms > -INFINITY) num += __expf(ms - M) * wp[(size_t)s * (D + 2) + d];
+    }
+    out[((size_t)b * Hq + h) * D + d] = from_f<T>(num * inv);
+  }
+}
+
+template <typename T, int D>
+int launch_decode_d(int G, const void* qkv, void* kc, void* vc, const int* pos, const void* ct, const void* st,
+                    float* ws, int B, int Hq, int Hkv, int max_pos, int nsplit, float scale, hipStream_t s) {
+  dim3 grid(Hkv, nsplit, B);
+#define LD(GG)                                                                                                     \
+  hipLaunchKernelGGL((decode_split_kernel<T, D, GG>), grid, dim3(256), 0, s, (const T*)qkv, (T*)kc, (T*)vc, pos, \
+                     (const T*)ct, (const T*)st, ws, Hq, Hkv, max_pos, nsplit, scale)
+  switch (G) {
+    case 1: LD(1); break;
+    case 2: LD(2); break;
+    case 4: LD(4); break;
+    case 8: LD(8); break;
+    default:
+      srgpt_set_error("srgpt_decode_attention: heads/kv_heads = %d not supported (1,2,4,8)", G);
+      return SRGPT_ERR_UNSUPPORTED;
+  }
+#undef LD
+  return SRGPT_OK;
+}
+
+template <typename T>
+int launch_decode(const void* qkv, void* kc, void* vc, const int* pos, const void* ct, const void* st, void* out,
+                  float* ws, int B, int Hq, int Hkv, int D, int max_pos, hipStream_t s) {
+  const int G = Hq / Hkv;
+  const int nsplit = decode_nsplit(max_pos);
+  SRGPT_CHECK(nsplit <= DEC_SPLIT_MAX, SRGPT_ERR_UNSUPPORTED, "srgpt_decode_attention: max_pos %d too large", max_pos);
+  const float scale = 1.0f / sqrtf((float)D);
+  int rc;
+  switch (D) {
+    case 16: rc = launch_decode_d<T, 16>(G, qkv, kc, vc, pos, ct, st, ws, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
+    case 32: rc = launch_decode_d<T, 32>(G, qkv, kc, vc, pos, ct, st, ws, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
+    case 64: rc = launch_decode_d<T, 64>(G, qkv, kc, vc, pos, ct, st, ws, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
+    case 128: rc = launch_decode_d<T, 128>(G, qkv, kc, vc, pos, ct, st, ws, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
+    default:
+      srgpt_set_error("srgpt_decode_attention: head_dim %d not supported (16,32,64,128)", D);
+      return SRGPT_ERR_UNSUPPORTED;
+  }
+  if (rc) return rc;
+  SRGPT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(decode_combine_kernel<T>, dim3(Hq, B), dim3(64), 0, s, ws, (T*)out, Hq, D, nsplit);
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t srgpt_decode_attn_ws_floats(int B, int Hq, int D) {
+  return (int64_t)B * Hq * DEC_SPLIT_MAX * (D + 2);
+}
+
+extern "C" int srgpt_decode_attention(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
+                                      const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D,
+                                      int max_pos, int dtype, srgpt_stream_t stream) {
+  SRGPT_CHECK(qkv && kcache && vcache && pos && cos_tab && sin_tab && out && ws, SRGPT_ERR_ARG,
+              "srgpt_decode_attention: null pointer");
+  SRGPT_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, SRGPT_ERR_ARG, "srgpt_decode_attention: bad heads");
+  if (dtype == SRGPT_BF16)
+    return launch_decode<bf16_t>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos,
+                                 as_stream(stream));
+  if (dtype == SRGPT_F32)
+    return launch_decode<float>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos,
+                                as_stream(stream));
+  srgpt_set_error("srgpt_decode_attention: bad dtype %d", dtype);
+  return SRGPT_ERR_ARG;
+}
+
+extern "C" int srgpt_attention(const void* q, const void* k, const void* v, void* o, int B, int Tq, int Tk, int Hq,
+                               int Hkv, int D, int64_t q_bs, int64_t q_ts, int64_t q_hs, int64_t k_bs, int64_t k_ts,
+                               int64_t k_hs, int64_t v_bs, int64_t v_ts, int64_t v_hs, float scale, int causal,
+                               const int* kv_len, int dtype, srgpt_stream_t stream) {
+  SRGPT_CHECK(q && k && v && o, SRGPT_ERR_ARG, "srgpt_attention: null pointer");
+  SRGPT_CHECK(B > 0 && Tq > 0 && Tk > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && D > 0 && D <= 256, SRGPT_ERR_ARG,
+              "srgpt_attention: bad shape B=%d Tq=%d Tk=%d Hq=%d Hkv=%d D=%d", B, Tq, Tk, Hq, Hkv, D);
+  hipStream_t s = as_stream(stream);
+  const bool vec_ok = D % 8 == 0 && D <= 128 && q_ts % 8 == 0 && q_hs % 8 == 0 && q_bs % 8 == 0 && k_ts % 8 == 0 &&
+                      k_hs % 8 == 0 && k_bs % 8 == 0 && v_ts % 8 == 0 && v_hs % 8 == 0 && v_bs % 8 == 0 &&
+                      ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                      ((uintptr_t)o % 8 == 0);
+  if (dtype == SRGPT_BF16 && vec_ok) {
+    AttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, Tq, Tk, Hq, Hkv, D,
+               q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, scale, kv_len};
+    dim3 grid(cdiv(Tq, QBLK), Hq, B);
+    const int hdp = (D + 31) / 32 * 32;
+#define LF(H)                                                                                  \
+  if (causal)                                                                                  \
+    hipLaunchKernelGGL((flash_bf16_kernel<H, true>), grid, dim3(256), 0, s, a);                \
+  else                                                                                         \
+    hipLaunchKernelGGL((flash_bf16_kernel<H, false>), grid, dim3(256), 0, s, a)
+    switch (hdp) {
+      case 32: LF(32); break;
+      case 64: LF(64); break;
+      case 96: LF(96); break;
+      default: LF(128); break;
+    }
+#undef LF
+  } else if (dtype == SRGPT_BF16) {
+    hipLaunchKernelGGL(simple_attn_kernel<bf16_t>, dim3(Tq, Hq, B), dim3(64), 0, s, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (bf16_t*)o, Tq, Tk, Hq, Hkv, D, q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts,
+                       v_hs, scale, causal, kv_len);
+  } else if (dtype == SRGPT_F32) {
+    hipLaunchKernelGGL(simple_attn_kernel<float>, dim3(Tq, Hq, B), dim3(64), 0, s, (const float*)q, (const float*)k,
+                       (const float*)v, (float*)o, Tq, Tk, Hq, Hkv, D, q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts,
+                       v_hs, scale, causal, kv_len);
+  } else {
+    srgpt_set_error("srgpt_attention: bad dtype %d", dtype);
+    return SRGPT_ERR_ARG;
+  }
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}

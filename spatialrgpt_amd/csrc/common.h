@@ -1,0 +1,128 @@
+// Shared device/host helpers for the srgpt HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/srgpt.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// error reporting across the C ABI (no exceptions, thread-local message)
+// ------------------------------------------------------------------------------------------------
+void srgpt_set_error(const char* fmt, ...);
+
+#define SRGPT_CHECK(cond, code, ...)      \
+  do {                                    \
+    if (!(cond)) {                        \
+      srgpt_set_error(__VA_ARGS__);       \
+      return (code);                      \
+    }                                     \
+  } while (0)
+
+#define SRGPT_LAUNCH_CHECK()                                                       \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      srgpt_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return SRGPT_ERR_LAUNCH;                                                     \
+    }                                                                              \
+  } while (0)
+
+#define SRGPT_TRY(expr)        \
+  do {                         \
+    int rc__ = (expr);         \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+static inline hipStream_t as_stream(srgpt_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline size_t dtype_size(int dtype) { return dtype == SRGPT_BF16 ? 2 : 4; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }
+template <typename T>
+__device__ __forceinline__ T from_f(float x);
+template <>
+__device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <>
+__device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return (bf16_t)x; }  // RNE (v_cvt_pk_bf16_f32)
+
+// round-trip through the storage type: mirrors PyTorch materialising an intermediate in `T`
+template <typename T>
+__device__ __forceinline__ float rnd(float x) { return to_f(from_f<T>(x)); }
+
+__device__ __forceinline__ float bf16lo(unsigned int u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16hi(unsigned int u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` is >= 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// vector of VEC elements of T occupying 16 bytes
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+  static constexpr int N = 4;
+  f32x4 v;
+  __device__ __forceinline__ float get(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <>
+struct Vec16<bf16_t> {
+  static constexpr int N = 8;
+  bf16x8 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  return 0.5f * x * (1.f + tanhf(k0 * (x + k1 * x * x * x)));
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
+
+template <typename T>
+__device__ __forceinline__ float apply_act(float x, int act) {
+  switch (act) {
+    case SRGPT_ACT_GELU_ERF: return gelu_erf(x);
+    case SRGPT_ACT_GELU_TANH: return gelu_tanh(x);
+    case SRGPT_ACT_SILU: return silu(x);
+    default: return x;
+  }
+}

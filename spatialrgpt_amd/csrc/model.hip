@@ -1,0 +1,303 @@
+// Host-side composites over the per-op C ABI: vision tower forward, Llama prefill, device-side greedy
+// decode step and its hipGraph.  Pure launch sequencing in C++ so one request costs a handful of
+// FFI crossings instead of ~10^4 (SURVEY 3.1 hot loops); all state lives in caller-owned buffers.
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(reinterpret_cast<char*>(p)) {}
+  void* take(size_t bytes) {
+    void* r = base ? base + off : nullptr;
+    off += align256(bytes);
+    return r;
+  }
+};
+
+// ---- ViT workspace ----
+struct VitWs {
+  void *col, *h, *qkv, *mlp;
+  size_t total;
+};
+VitWs carve_vit(const srgpt_vit_weights* w, int n_img, void* ws) {
+  const size_t es = dtype_size(w->dtype);
+  const int g = w->image_size / w->patch;
+  const size_t rows = (size_t)n_img * g * g;
+  Carver c(ws);
+  VitWs v;
+  v.col = c.take(rows * w->kp * es);
+  v.h = c.take(rows * w->hidden * es);
+  v.qkv = c.take(rows * 3 * w->hidden * es);
+  v.mlp = c.take(rows * w->inter * es);
+  v.total = c.off;
+  return v;
+}
+
+// ---- LLM workspace ----
+struct LlmWs {
+  void *x, *h, *qkv, *attn, *gu, *act, *last;  // prefill
+  void *xd, *qkvd, *attnd, *actd;              // decode
+  float* dws;
+  size_t total;
+};
+LlmWs carve_llm(const srgpt_llm_weights* w, int batch, int max_tokens, void* ws) {
+  const size_t es = dtype_size(w->dtype);
+  const size_t rows = (size_t)batch * max_tokens;
+  const size_t qkvw = (size_t)(w->heads + 2 * w->kv_heads) * w->head_dim;
+  Carver c(ws);
+  LlmWs l;
+  l.x = c.take(rows * w->hidden * es);
+  l.h = c.take(rows * w->hidden * es);
+  l.qkv = c.take(rows * qkvw * es);
+  l.attn = c.take(rows * (size_t)w->heads * w->head_dim * es);
+  l.gu = c.take(rows * 2 * (size_t)w->inter * es);
+  l.act = c.take(rows * (size_t)w->inter * es);
+  l.last = c.take((size_t)batch * w->hidden * es);
+  l.xd = c.take((size_t)batch * w->hidden * es);
+  l.qkvd = c.take((size_t)batch * qkvw * es);
+  l.attnd = c.take((size_t)batch * w->heads * w->head_dim * es);
+  l.actd = c.take((size_t)batch * w->inter * es);
+  l.dws = reinterpret_cast<float*>(c.take((size_t)srgpt_decode_attn_ws_floats(batch, w->heads, w->head_dim) * 4));
+  l.total = c.off;
+  return l;
+}
+
+__global__ void set_int_kernel(int* p, int n, int v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// tok/out_ids/pos bookkeeping after argmax wrote tok[]
+__global__ void advance_kernel(const int64_t* tok, int64_t* out_ids, int* pos, int* step, int B, int max_new,
+                               int bump_pos) {
+  const int s = *step;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    if (s < max_new) out_ids[(size_t)b * max_new + s] = tok[b];
+    if (bump_pos) pos[b] += 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *step = s + 1;
+}
+
+}  // namespace
+
+struct srgpt_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+// ================================================================================================
+// vision tower
+// ================================================================================================
+extern "C" int64_t srgpt_vit_ws_bytes(const srgpt_vit_weights* w, int n_img) {
+  if (!w || n_img <= 0) return -1;
+  return (int64_t)carve_vit(w, n_img, nullptr).total;
+}
+
+extern "C" int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images, void* out, void* ws, int n_img,
+                                 srgpt_stream_t stream) {
+  SRGPT_CHECK(w && images && out && ws && n_img > 0, SRGPT_ERR_ARG, "srgpt_vit_forward: bad args");
+  SRGPT_CHECK(w->hidden % w->heads == 0 && w->image_size % w->patch == 0, SRGPT_ERR_ARG, "srgpt_vit_forward: bad config");
+  const int dt = w->dtype, C = w->hidden, I = w->inter, H = w->heads, hd = C / H;
+  const int g = w->image_size / w->patch, L = g * g, rows = n_img * L;
+  const VitWs v = carve_vit(w, n_img, ws);
+  void* x = out;  // residual stream lives in the output buffer
+  SRGPT_TRY(srgpt_im2col(images, v.col, n_img, w->image_size, w->patch, w->kp, dt, stream));
+  // conv-as-GEMM + bias, then + position embedding (row m uses pos_emb[m % L])
+  SRGPT_TRY(srgpt_gemm(v.col, w->patch_w, w->patch_b, w->pos_emb, x, rows, C, w->kp, w->kp, C, SRGPT_ACT_NONE, 0, L, 0,
+                       SRGPT_OUT_PLAIN, 0, dt, stream));
+  const float scale = 1.0f / sqrtf((float)hd);
+  const char* qkv = reinterpret_cast<const char*>(v.qkv);
+  const size_t es = dtype_size(dt);
+  for (int l = 0; l < w->n_layers_run; ++l) {
+    SRGPT_TRY(srgpt_layernorm(x, w->ln1_w[l], w->ln1_b[l], v.h, rows, C, w->eps, SRGPT_ACT_NONE, dt, stream));
+    SRGPT_TRY(srgpt_gemm(v.h, w->wqkv[l], w->bqkv[l], nullptr, v.qkv, rows, 3 * C, C, C, 3 * C, SRGPT_ACT_NONE, 0, 0, 0,
+                         SRGPT_OUT_PLAIN, 0, dt, stream));
+    SRGPT_TRY(srgpt_attention(qkv, qkv + (size_t)C * es, qkv + (size_t)2 * C * es, v.h, n_img, L, L, H, H, hd,
+                              (int64_t)L * 3 * C, 3 * C, hd, (int64_t)L * 3 * C, 3 * C, hd, (int64_t)L * 3 * C, 3 * C, hd,
+                              scale, 0, nullptr, dt, stream));
+    SRGPT_TRY(srgpt_gemm(v.h, w->wo[l], w->bo[l], x, x, rows, C, C, C, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, dt,
+                         stream));
+    SRGPT_TRY(srgpt_layernorm(x, w->ln2_w[l], w->ln2_b[l], v.h, rows, C, w->eps, SRGPT_ACT_NONE, dt, stream));
+    SRGPT_TRY(srgpt_gemm(v.h, w->w1[l], w->b1[l], nullptr, v.mlp, rows, I, C, C, I, SRGPT_ACT_GELU_TANH, 0, 0, 0,
+                         SRGPT_OUT_PLAIN, 0, dt, stream));
+    SRGPT_TRY(srgpt_gemm(v.mlp, w->w2[l], w->b2[l], x, x, rows, C, I, I, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, dt,
+                         stream));
+  }
+  return SRGPT_OK;
+}
+
+// ================================================================================================
+// Llama decoder
+// ================================================================================================
+extern "C" int64_t srgpt_llm_ws_bytes(const srgpt_llm_weights* w, int batch, int max_tokens) {
+  if (!w || batch <= 0 || max_tokens <= 0) return -1;
+  return (int64_t)carve_llm(w, batch, max_tokens, nullptr).total;
+}
+
+static int check_llm(const srgpt_llm_weights* w, const srgpt_llm_state* st) {
+  SRGPT_CHECK(w && st, SRGPT_ERR_ARG, "llm: null weights/state");
+  SRGPT_CHECK(st->kcache && st->vcache && st->pos && st->tok && st->out_ids && st->step && st->ws && st->logits,
+              SRGPT_ERR_ARG, "llm: state has null buffers");
+  SRGPT_CHECK(w->heads % w->kv_heads == 0 && w->head_dim % 2 == 0, SRGPT_ERR_ARG, "llm: bad head config");
+  SRGPT_CHECK(st->batch > 0 && st->max_pos > 0 && st->ws_tokens > 0 && st->max_new > 0, SRGPT_ERR_ARG, "llm: bad state sizes");
+  return SRGPT_OK;
+}
+
+extern "C" int srgpt_llm_prefill(const srgpt_llm_weights* w, srgpt_llm_state* st, const void* inputs_embeds, int T,
+                                 float* all_logits, void* hidden_out, srgpt_stream_t stream) {
+  SRGPT_TRY(check_llm(w, st));
+  SRGPT_CHECK(inputs_embeds && T > 0 && T <= st->max_pos, SRGPT_ERR_ARG, "srgpt_llm_prefill: T=%d exceeds max_pos=%d", T,
+              st->max_pos);
+  const int dt = w->dtype, Hd = w->hidden, I = w->inter, Hq = w->heads, Hkv = w->kv_heads, D = w->head_dim;
+  const int B = st->batch, rows = B * T, QW = (Hq + 2 * Hkv) * D;
+  const size_t es = dtype_size(dt);
+  hipStream_t s = as_stream(stream);
+  SRGPT_CHECK(T <= st->ws_tokens, SRGPT_ERR_ARG, "srgpt_llm_prefill: T=%d exceeds ws_tokens=%d", T, st->ws_tokens);
+  const LlmWs l = carve_llm(w, B, st->ws_tokens, st->ws);
+  const size_t layer_kv = (size_t)B * Hkv * st->max_pos * D * es;
+  const size_t hid_bytes = (size_t)rows * Hd * es;
+  if (hipMemcpyAsync(l.x, inputs_embeds, hid_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    srgpt_set_error("srgpt_llm_prefill: memcpy failed");
+    return SRGPT_ERR_LAUNCH;
+  }
+  if (hidden_out) hipMemcpyAsync(hidden_out, l.x, hid_bytes, hipMemcpyDeviceToDevice, s);
+  const float scale = 1.0f / sqrtf((float)D);
+  for (int i = 0; i < w->layers; ++i) {
+    char* kc = reinterpret_cast<char*>(st->kcache) + (size_t)i * layer_kv;
+    char* vc = reinterpret_cast<char*>(st->vcache) + (size_t)i * layer_kv;
+    SRGPT_TRY(srgpt_rmsnorm(l.x, w->attn_norm[i], l.h, rows, Hd, w->rms_eps, dt, stream));
+    SRGPT_TRY(srgpt_gemm(l.h, w->wqkv[i], nullptr, nullptr, l.qkv, rows, QW, Hd, Hd, QW, SRGPT_ACT_NONE, 0, 0, 0,
+                         SRGPT_OUT_PLAIN, 0, dt, stream));
+    SRGPT_TRY(srgpt_rope_kv_append(l.qkv, kc, vc, nullptr, w->rope_cos, w->rope_sin, B, T, Hq, Hkv, D, st->max_pos, dt,
+                                   stream));
+    SRGPT_TRY(srgpt_attention(l.qkv, kc, vc, l.attn, B, T, T, Hq, Hkv, D, (int64_t)T * QW, QW, D,
+                              (int64_t)Hkv * st->max_pos * D, D, (int64_t)st->max_pos * D,
+                              (int64_t)Hkv * st->max_pos * D, D, (int64_t)st->max_pos * D, scale, 1, nullptr, dt, stream));
+    SRGPT_TRY(srgpt_gemm(l.attn, w->wo[i], nullptr, l.x, l.x, rows, Hd, Hq * D, Hq * D, Hd, SRGPT_ACT_NONE, 0, 0, 0,
+                         SRGPT_OUT_PLAIN, 0, dt, stream));
+    SRGPT_TRY(srgpt_rmsnorm(l.x, w->mlp_norm[i], l.h, rows, Hd, w->rms_eps, dt, stream));
+    SRGPT_TRY(srgpt_gemm(l.h, w->wgu[i], nullptr, nullptr, l.gu, rows, 2 * I, Hd, Hd, 2 * I, SRGPT_ACT_NONE, 0, 0, 0,
+                         SRGPT_OUT_PLAIN, 0, dt, stream));
+    SRGPT_TRY(srgpt_silu_mul(l.gu, l.act, rows, I, dt, stream));
+    SRGPT_TRY(srgpt_gemm(l.act, w->wdown[i], nullptr, l.x, l.x, rows, Hd, I, I, Hd, SRGPT_ACT_NONE, 0, 0, 0,
+                         SRGPT_OUT_PLAIN, 0, dt, stream));
+    if (hidden_out)
+      hipMemcpyAsync(reinterpret_cast<char*>(hidden_out) + (size_t)(i + 1) * hid_bytes, l.x, hid_bytes,
+                     hipMemcpyDeviceToDevice, s);
+  }
+  if (all_logits) {
+    SRGPT_TRY(srgpt_rmsnorm(l.x, w->final_norm, l.h, rows, Hd, w->rms_eps, dt, stream));
+    SRGPT_TRY(srgpt_gemm(l.h, w->lm_head, nullptr, nullptr, all_logits, rows, w->vocab, Hd, Hd, w->vocab, SRGPT_ACT_NONE,
+                         0, 0, 1, SRGPT_OUT_PLAIN, 0, dt, stream));
+  }
+  // last position of every sequence -> logits (final norm fused into the GEMV prologue)
+  if (hipMemcpy2DAsync(l.last, (size_t)Hd * es, reinterpret_cast<char*>(l.x) + (size_t)(T - 1) * Hd * es,
+                       (size_t)T * Hd * es, (size_t)Hd * es, B, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    srgpt_set_error("srgpt_llm_prefill: gather of last rows failed");
+    return SRGPT_ERR_LAUNCH;
+  }
+  SRGPT_TRY(srgpt_gemv(l.last, w->lm_head, w->final_norm, w->rms_eps, nullptr, st->logits, B, w->vocab, Hd, 0, 1, dt,
+                       stream));
+  hipLaunchKernelGGL(set_int_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, st->pos, B, T);
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
+
+extern "C" int srgpt_llm_sample_first(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream) {
+  SRGPT_TRY(check_llm(w, st));
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, s, st->step, 1, 0);
+  SRGPT_TRY(srgpt_argmax(st->logits, st->tok, st->batch, w->vocab, stream));
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, st->tok, st->out_ids, st->pos, st->step, st->batch,
+                     st->max_new, 0);
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
+
+extern "C" int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream) {
+  SRGPT_TRY(check_llm(w, st));
+  const int dt = w->dtype, Hd = w->hidden, I = w->inter, Hq = w->heads, Hkv = w->kv_heads, D = w->head_dim;
+  const int B = st->batch, QW = (Hq + 2 * Hkv) * D;
+  const size_t es = dtype_size(dt);
+  hipStream_t s = as_stream(stream);
+  const LlmWs d = carve_llm(w, B, st->ws_tokens, st->ws);  // same carve as prefill (sized by ws_tokens)
+  const size_t layer_kv = (size_t)B * Hkv * st->max_pos * D * es;
+  SRGPT_TRY(srgpt_embed_rows(w->embed, st->tok, d.xd, B, Hd, dt, stream));
+  for (int i = 0; i < w->layers; ++i) {
+    char* kc = reinterpret_cast<char*>(st->kcache) + (size_t)i * layer_kv;
+    char* vc = reinterpret_cast<char*>(st->vcache) + (size_t)i * layer_kv;
+    SRGPT_TRY(srgpt_gemv(d.xd, w->wqkv[i], w->attn_norm[i], w->rms_eps, nullptr, d.qkvd, B, QW, Hd, 0, 0, dt, stream));
+    SRGPT_TRY(srgpt_decode_attention(d.qkvd, kc, vc, st->pos, w->rope_cos, w->rope_sin, d.attnd, d.dws, B, Hq, Hkv, D,
+                                     st->max_pos, dt, stream));
+    SRGPT_TRY(srgpt_gemv(d.attnd, w->wo[i], nullptr, 0.f, d.xd, d.xd, B, Hd, Hq * D, 0, 0, dt, stream));
+    SRGPT_TRY(srgpt_gemv(d.xd, w->wgu[i], w->mlp_norm[i], w->rms_eps, nullptr, d.actd, B, I, Hd, 1, 0, dt, stream));
+    SRGPT_TRY(srgpt_gemv(d.actd, w->wdown[i], nullptr, 0.f, d.xd, d.xd, B, Hd, I, 0, 0, dt, stream));
+  }
+  SRGPT_TRY(srgpt_gemv(d.xd, w->lm_head, w->final_norm, w->rms_eps, nullptr, st->logits, B, w->vocab, Hd, 0, 1, dt, stream));
+  SRGPT_TRY(srgpt_argmax(st->logits, st->tok, B, w->vocab, stream));
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, st->tok, st->out_ids, st->pos, st->step, B, st->max_new, 1);
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
+
+// ================================================================================================
+// hipGraph of one decode step
+// ================================================================================================
+extern "C" int srgpt_llm_decode_graph_create(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream,
+                                             srgpt_graph** out) {
+  SRGPT_CHECK(out, SRGPT_ERR_ARG, "srgpt_llm_decode_graph_create: null out");
+  SRGPT_TRY(check_llm(w, st));
+  hipStream_t s = as_stream(stream);
+  (void)srgpt_device_cus();  // make sure no device query happens inside the capture
+  hipGraph_t graph = nullptr;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    srgpt_set_error("hipStreamBeginCapture failed");
+    return SRGPT_ERR_STATE;
+  }
+  const int rc = srgpt_llm_decode_step(w, st, stream);
+  const hipError_t ee = hipStreamEndCapture(s, &graph);
+  if (rc != SRGPT_OK) {
+    if (graph) hipGraphDestroy(graph);
+    return rc;
+  }
+  if (ee != hipSuccess || !graph) {
+    srgpt_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ee));
+    return SRGPT_ERR_STATE;
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (ei != hipSuccess) {
+    hipGraphDestroy(graph);
+    srgpt_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+    return SRGPT_ERR_STATE;
+  }
+  *out = new srgpt_graph{graph, exec};
+  return SRGPT_OK;
+}
+
+extern "C" int srgpt_graph_launch(srgpt_graph* g, int times, srgpt_stream_t stream) {
+  SRGPT_CHECK(g && times >= 0, SRGPT_ERR_ARG, "srgpt_graph_launch: bad args");
+  for (int i = 0; i < times; ++i) {
+    const hipError_t e = hipGraphLaunch(g->exec, as_stream(stream));
+    if (e != hipSuccess) {
+      srgpt_set_error("hipGraphLaunch failed: %s", hipGetErrorString(e));
+      return SRGPT_ERR_LAUNCH;
+    }
+  }
+  return SRGPT_OK;
+}
+
+extern "C" int srgpt_graph_destroy(srgpt_graph* g) {
+  if (!g) return SRGPT_OK;
+  hipGraphExecDestroy(g->exec);
+  hipGraphDestroy(g->graph);
+  delete g;
+  return SRGPT_OK;
+}

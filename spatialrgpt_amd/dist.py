@@ -1,0 +1,84 @@
+"""Data-parallel sharding of independent requests over the GPUs of one node.
+
+The reference shards inference by process fan-out over dataset chunks and merges JSONL files
+(scripts/srgpt/eval/srgpt_bench.sh:9-45, llava/eval/eval_spatial.py:72-80: `split_list`/`get_chunk`, chunk
+size ceil(len/n)).  Here: one rank per GPU under torchrun, the same contiguous ceil(len/n) chunking, and ONE
+exchange step -- an all-gather of the generated ids over RCCL/xGMI (backend "nccl" on ROCm; "gloo" in CPU tests).
+No collective sits on the per-token path."""
+from __future__ import annotations
+
+import math
+import os
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None) -> tuple:
+    """Initialise from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  Returns (rank, world, local)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def split_list(lst: Sequence, n: int) -> List[Sequence]:
+    """eval_spatial.py:72-75: chunks of size ceil(len/n) (the last ranks may get fewer / none)."""
+    chunk = math.ceil(len(lst) / n) if len(lst) else 1
+    return [lst[i:i + chunk] for i in range(0, len(lst), chunk)]
+
+
+def get_chunk(lst: Sequence, n: int, k: int) -> Sequence:
+    """eval_spatial.py:78-80, but ranks beyond the last chunk get an empty shard instead of IndexError."""
+    chunks = split_list(lst, n)
+    return chunks[k] if k < len(chunks) else lst[0:0]
+
+
+def gather_ids(local_ids: torch.Tensor, pad_id: int = 0, group=None) -> torch.Tensor:
+    """All-gather generated ids [B_local, G_local] (int64) from every rank -> [sum B_local, max G] in rank order.
+    Shapes may differ per rank (ragged shards, early EOS): sizes are exchanged first, payloads padded."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_ids
+    world = dist.get_world_size(group)
+    dev = local_ids.device
+    shape = torch.tensor(list(local_ids.shape) if local_ids.dim() == 2 else [0, 0], dtype=torch.int64, device=dev)
+    shapes = [torch.zeros_like(shape) for _ in range(world)]
+    dist.all_gather(shapes, shape, group=group)
+    mb = max(int(s[0]) for s in shapes)
+    mg = max(int(s[1]) for s in shapes)
+    buf = torch.full((mb, mg), pad_id, dtype=torch.int64, device=dev)
+    if local_ids.numel():
+        buf[:local_ids.shape[0], :local_ids.shape[1]] = local_ids
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    rows = [b[:int(s[0])] for b, s in zip(bufs, shapes)]
+    return torch.cat(rows, dim=0) if rows else buf[:0]
+
+
+def generate_data_parallel(model, requests: Sequence[dict], group=None, pad_id: int = 0, **gen_kwargs) -> torch.Tensor:
+    """Run `model.generate` on this rank's contiguous shard of `requests` (dicts of generate() kwargs) and
+    all-gather the ids.  Every rank returns the ids of ALL requests in request order."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = get_chunk(list(requests), world, rank)
+    outs = [model.generate(**req, **gen_kwargs) for req in mine]
+    dev = outs[0].device if outs else (model.device if hasattr(model, "device") else "cpu")
+    if outs:
+        g = max(o.shape[1] for o in outs)
+        local = torch.full((sum(o.shape[0] for o in outs), g), pad_id, dtype=torch.int64, device=dev)
+        r = 0
+        for o in outs:
+            local[r:r + o.shape[0], :o.shape[1]] = o
+            r += o.shape[0]
+    else:
+        local = torch.zeros((0, 0), dtype=torch.int64, device=dev)
+    return gather_ids(local, pad_id, group)

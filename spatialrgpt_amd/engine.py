@@ -1,0 +1,394 @@
+"""SrgptEngine: the region-grounded forward/generate path on one MI355X.
+
+Stage map (reference file:line -> method):
+  A1  VisionTower.forward            multimodal_encoder/vision_encoder.py:115-132   -> vit()
+  A2  feature_refinement             region_extractor/base_extractor.py:137-147     -> feature_refinement()
+  A3/4 MaskPooling + connectors      region_extractor/base_extractor.py:32-84,149-173 -> region_extractor()
+  A5  mlp_downsample projector       multimodal_projector/base_projector.py:32-94   -> mm_projector()
+  A6  token-stream splice            llava_arch.py:333-650                           -> prepare_inputs()
+  A7-13 Llama prefill + greedy loop  modeling_llama.py + HF GenerationMixin          -> prefill()/generate_ids()
+Every arithmetic step is a HIP kernel (spatialrgpt_amd/ops.py -> libsrgpt_hip.so); torch allocates buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .config import SrgptConfig
+from .constants import IMAGE_TOKEN_INDEX
+from .weights import PreparedWeights
+
+
+class DecodeState:
+    """Static KV cache + device-side decode bookkeeping for a (batch, max_pos) geometry."""
+
+    def __init__(self, eng: "SrgptEngine", batch: int, max_pos: int, ws_tokens: int, max_new: int):
+        cfg, dev, dt = eng.cfg, eng.device, eng.dtype
+        self.batch, self.max_pos, self.ws_tokens, self.max_new = batch, max_pos, ws_tokens, max_new
+        shape = (cfg.layers, batch, cfg.kv_heads, max_pos, cfg.head_dim)
+        self.kcache = torch.empty(shape, device=dev, dtype=dt)
+        self.vcache = torch.empty(shape, device=dev, dtype=dt)
+        self.pos = torch.zeros((batch,), device=dev, dtype=torch.int32)
+        self.tok = torch.zeros((batch,), device=dev, dtype=torch.int64)
+        self.out_ids = torch.zeros((batch, max_new), device=dev, dtype=torch.int64)
+        self.step = torch.zeros((1,), device=dev, dtype=torch.int32)
+        self.logits = torch.empty((batch, eng.w.vocab), device=dev, dtype=torch.float32)
+        lib = L.load()
+        nbytes = lib.srgpt_llm_ws_bytes(C.byref(eng.w.llm), batch, ws_tokens)
+        if nbytes < 0:
+            raise RuntimeError("srgpt_llm_ws_bytes failed")
+        self.ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+        st = L.LlmState()
+        st.batch, st.max_pos, st.max_new, st.ws_tokens = batch, max_pos, max_new, ws_tokens
+        st.kcache, st.vcache = self.kcache.data_ptr(), self.vcache.data_ptr()
+        st.pos, st.tok, st.out_ids, st.step = self.pos.data_ptr(), self.tok.data_ptr(), self.out_ids.data_ptr(), self.step.data_ptr()
+        st.ws, st.logits = self.ws.data_ptr(), self.logits.data_ptr()
+        self.c = st
+        self.graph = None
+        self._eng = eng
+
+    def ensure_graph(self):
+        if self.graph is None:
+            g = L.vp()
+            L.check(L.load().srgpt_llm_decode_graph_create(C.byref(self._eng.w.llm), C.byref(self.c), ops._stream(), C.byref(g)))
+            self.graph = g
+        return self.graph
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                L.load().srgpt_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+
+class SrgptEngine:
+    def __init__(self, cfg: SrgptConfig, state_dict: Dict[str, torch.Tensor], device="cuda", dtype=torch.bfloat16,
+                 rope_positions: int = 0, consume_state_dict: bool = False):
+        L.load()  # fail loudly if the HIP extension is missing
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        if self.device.type != "cuda":
+            raise RuntimeError("SrgptEngine runs on an MI355X (torch device 'cuda'); there is no CPU path")
+        if cfg.mm_projector_type != "mlp_downsample":
+            raise ValueError(f"Unknown projector type: {cfg.mm_projector_type}")
+        if cfg.enable_region and cfg.region_extractor_type != "regiongpt":
+            raise NotImplementedError(f"{cfg.region_extractor_type} not implemented")  # base_extractor.py:160-161
+        if cfg.select_feature not in ("cls_patch", "patch"):
+            raise ValueError(f"Unexpected select feature: {cfg.select_feature}")
+        self.w = PreparedWeights(cfg, state_dict, self.device, dtype, rope_positions, consume=consume_state_dict)
+        self._state: Optional[DecodeState] = None
+        self._vit_ws: Optional[torch.Tensor] = None
+        self.use_graph = True
+
+    # ------------------------------------------------------------------ A1
+    def vit(self, images: torch.Tensor) -> torch.Tensor:
+        """[n,3,S,S] -> hidden_states[select_layer] [n, grid^2, C], returned in images.dtype."""
+        in_dtype = images.dtype
+        x = images.to(device=self.device, dtype=self.dtype).contiguous()  # vision_encoder.py:127
+        n, ch, S, S2 = x.shape
+        if ch != 3 or S != self.cfg.image_size or S2 != S:
+            raise ValueError(f"vision tower expects [n,3,{self.cfg.image_size},{self.cfg.image_size}] images, got {tuple(x.shape)}")
+        lib = L.load()
+        need = lib.srgpt_vit_ws_bytes(C.byref(self.w.vit), n)
+        if self._vit_ws is None or self._vit_ws.numel() < need:
+            self._vit_ws = torch.empty((need,), device=self.device, dtype=torch.uint8)
+        out = torch.empty((n, self.cfg.grid ** 2, self.cfg.vit_hidden), device=self.device, dtype=self.dtype)
+        L.check(lib.srgpt_vit_forward(C.byref(self.w.vit), x.data_ptr(), out.data_ptr(), self._vit_ws.data_ptr(), n, ops._stream()))
+        return out.to(in_dtype)  # vision_encoder.py:130
+
+    # ------------------------------------------------------------------ A2
+    def feature_refinement(self, tower: torch.Tensor):
+        n, HW, Cc = tower.shape
+        g = int(HW ** 0.5)
+        if g * g != HW:
+            raise ValueError(f"feature_refinement needs a square token grid, got {HW} tokens")  # einops error in the reference
+        w = self.w
+        x = tower.reshape(n * HW, Cc)
+        # ConvT(2,2) -> LayerNorm2d -> GELU -> ConvT(2,2) -> GELU, all channels-last
+        y = ops.gemm(x, w.dc1_w, w.dc1_b, bias_mod=Cc, out_mode=L.OUT_DECONV2X, gw=g, out_shape=(n * 4 * HW, Cc))
+        y = ops.layernorm(y, w.ln2d_w, w.ln2d_b, 1e-6, act=L.ACT_GELU_ERF)
+        hres = ops.gemm(y, w.dc2_w, w.dc2_b, act=L.ACT_GELU_ERF, bias_mod=Cc, out_mode=L.OUT_DECONV2X, gw=2 * g,
+                        out_shape=(n * 16 * HW, Cc))
+        lres = ops.avgpool(hres, n, 4 * g, 27)  # AdaptiveAvgPool2d(27) is hard-coded (base_extractor.py:123)
+        return hres.reshape(n, 16 * HW, Cc), lres
+
+    # ------------------------------------------------------------------ A3 / A4
+    def mask_pooling(self, feats: torch.Tensor, masks: Optional[Sequence[Optional[torch.Tensor]]]):
+        n = feats.shape[0]
+        if masks is None:
+            masks = [None] * n
+        out = []
+        for i in range(n):
+            m = masks[i]
+            out.append(None if m is None else ops.region_pool(feats[i], m.to(self.device)))
+        return out
+
+    def region_extractor(self, hres, depth_features, masks):
+        w = self.w
+
+        def connect(pooled, W, b):
+            return [None if p is None else ops.gemm(p, W, b) for p in pooled]
+
+        mask_embeds = connect(self.mask_pooling(hres, masks), w.rgb_w, w.rgb_b)
+        depth_embeds = None
+        if depth_features is not None:
+            depth_embeds = connect(self.mask_pooling(depth_features, masks), w.depth_w, w.depth_b)
+        return mask_embeds, depth_embeds
+
+    # ------------------------------------------------------------------ A5
+    def mm_projector(self, lres: torch.Tensor) -> torch.Tensor:
+        w = self.w
+        n = lres.shape[0]
+        x = ops.s2d(lres)
+        tokens = x.shape[1]
+        x = ops.layernorm(x.reshape(n * tokens, -1), w.mp_ln_w, w.mp_ln_b, 1e-5)
+        x = ops.gemm(x, w.mp_w1, w.mp_b1, act=L.ACT_GELU_ERF)
+        x = ops.gemm(x, w.mp_w2, w.mp_b2)
+        return x.reshape(n, tokens, -1)
+
+    # ------------------------------------------------------------------ llava_arch.py:387-411
+    def encode_visual(self, images, depths, masks, stages: Optional[dict] = None):
+        cfg = self.cfg
+        if isinstance(images, (list, tuple)):
+            images = torch.cat(list(images), dim=0)
+        elif images.ndim == 5:
+            images = images.flatten(0, 1)
+        if depths is not None:
+            if isinstance(depths, (list, tuple)):
+                depths = torch.cat(list(depths), dim=0)
+            elif depths.ndim == 5:
+                depths = depths.flatten(0, 1)
+        n = images.shape[0]
+        use_depth = cfg.enable_region and cfg.enable_depth and depths is not None
+        # RGB and depth go through the tower as ONE batch of 2n images (same weights)
+        both = torch.cat([images, depths.to(images.dtype)], dim=0) if use_depth else images
+        feats = self.vit(both)
+        tower = feats[:n]
+        mask_embeds = depth_embeds = None
+        if cfg.enable_region:
+            hres, lres = self.feature_refinement(tower.contiguous())
+            depth_features = feats[n:].contiguous() if use_depth else None
+            mask_embeds, depth_embeds = self.region_extractor(hres, depth_features, masks)
+            if stages is not None:
+                stages.update(hres=hres, lres=lres, depth_features=depth_features)
+        else:
+            lres = tower
+        image_features = self.mm_projector(lres)
+        if stages is not None:
+            stages.update(tower_features=tower, image_features=image_features, mask_embeds=mask_embeds,
+                          depth_embeds=depth_embeds)
+        return image_features, mask_embeds, depth_embeds
+
+    # ------------------------------------------------------------------ A6
+    def splice(self, input_ids: torch.Tensor, attention_mask, image_features, mask_embeds, depth_embeds, have_depths):
+        """Token-stream splice (llava_arch.py:420-611).  Index arithmetic on the host from the (tiny) id
+        tensor -- ONE device->host copy -- then four row gather/scatter kernels.
+        Returns (inputs_embeds [B,T,H], attention_mask|None, lengths list)."""
+        cfg = self.cfg
+        ids_cpu = input_ids.detach().to("cpu")
+        B, P = ids_cpu.shape
+        am_cpu = torch.ones_like(ids_cpu, dtype=torch.bool) if attention_mask is None else attention_mask.detach().to("cpu").bool()
+        nimg_feat = image_features.shape[1]
+        rows_tok: List[int] = []      # flat output row of each kept text token
+        ids_tok: List[int] = []
+        img_src: List[int] = []
+        img_dst: List[int] = []
+        m_src: List[int] = []
+        m_dst: List[int] = []
+        d_src: List[int] = []
+        d_dst: List[int] = []
+        seqs = []  # per sample: list of ("t", id) / ("i", image_idx, r)
+        cur_image_idx = 0
+        mask_off, n_me = [], 0
+        if mask_embeds is not None:
+            for e in mask_embeds:
+                mask_off.append(n_me)
+                n_me += 0 if e is None else e.shape[0]
+        for b in range(B):
+            cur = ids_cpu[b][am_cpu[b]].tolist()
+            n_images = sum(1 for t in cur if t == IMAGE_TOKEN_INDEX)
+            seq = []
+            if n_images == 0:
+                seqs.append([("t", t) for t in cur])
+                continue
+            first_img = cur_image_idx
+            nm = nd = 0
+            n_mask_tok = sum(1 for t in cur if t == cfg.mask_token_id)
+            n_depth_tok = sum(1 for t in cur if t == cfg.depth_token_id)
+            me = mask_embeds[first_img] if (cfg.enable_region and mask_embeds is not None) else None
+            de = depth_embeds[first_img] if (cfg.enable_region and cfg.enable_depth and have_depths and depth_embeds is not None) else None
+            if cfg.enable_region and me is None and n_mask_tok > 0:
+                print("Error: mask embed is None, but the num of <mask> is not 0!!!")
+            if cfg.enable_region and cfg.enable_depth and have_depths and de is None and n_depth_tok > 0:
+                print("Error: depth embed is None, but the num of <depth> is not 0!!!")
+            if me is not None and n_mask_tok > me.shape[0]:
+                raise RuntimeError(f"shape mismatch: {n_mask_tok} <mask> tokens but only {me.shape[0]} mask embeddings")
+            if de is not None and n_depth_tok > de.shape[0]:
+                raise RuntimeError(f"shape mismatch: {n_depth_tok} <depth> tokens but only {de.shape[0]} depth embeddings")
+            for t in cur:
+                if t == IMAGE_TOKEN_INDEX:
+                    seq.extend(("i", cur_image_idx, r) for r in range(nimg_feat))
+                    cur_image_idx += 1
+                elif me is not None and t == cfg.mask_token_id:
+                    seq.append(("m", mask_off[first_img] + nm))
+                    nm += 1
+                elif de is not None and t == cfg.depth_token_id:
+                    seq.append(("d", mask_off[first_img] + nd))
+                    nd += 1
+                else:
+                    seq.append(("t", t))
+            seqs.append(seq)
+        mx = cfg.tokenizer_model_max_length
+        if mx is not None:
+            if any(len(s) > mx for s in seqs):
+                warnings.warn("Inputs truncated!")
+            seqs = [s[:mx] for s in seqs]
+        lens = [len(s) for s in seqs]
+        T = max(lens)
+        left = cfg.padding_side == "left"
+        ragged = any(n != T for n in lens)
+        for b, seq in enumerate(seqs):
+            off = b * T + (T - len(seq) if left else 0)
+            for j, item in enumerate(seq):
+                r = off + j
+                if item[0] == "t":
+                    rows_tok.append(r)
+                    ids_tok.append(0 if item[1] == IMAGE_TOKEN_INDEX else item[1])
+                elif item[0] == "i":
+                    img_src.append(item[1] * nimg_feat + item[2])
+                    img_dst.append(r)
+                elif item[0] == "m":
+                    m_src.append(item[1])
+                    m_dst.append(r)
+                else:
+                    d_src.append(item[1])
+                    d_dst.append(r)
+        H = cfg.hidden
+        dev = self.device
+        out = (torch.zeros if ragged else torch.empty)((B * T, H), device=dev, dtype=self.dtype)
+
+        def place(src2d, src_rows, dst_rows):
+            if not dst_rows:
+                return
+            ops.scatter_rows(src2d.contiguous(), torch.tensor(dst_rows, device=dev, dtype=torch.int32), out,
+                             src_idx=torch.tensor(src_rows, device=dev, dtype=torch.int32))
+
+        if ids_tok:
+            emb = ops.embed_rows(self.w.embed, torch.tensor(ids_tok, device=dev, dtype=torch.int64))
+            place(emb, list(range(len(ids_tok))), rows_tok)
+        place(image_features.reshape(-1, H), img_src, img_dst)
+        if m_dst:
+            place(torch.cat([e for e in mask_embeds if e is not None], 0), m_src, m_dst)
+        if d_dst:
+            place(torch.cat([e for e in depth_embeds if e is not None], 0), d_src, d_dst)
+        am_out = None
+        if attention_mask is not None:
+            am = torch.zeros((B, T), dtype=torch.bool)
+            for b, n in enumerate(lens):
+                if left:
+                    am[b, T - n:] = True
+                else:
+                    am[b, :n] = True
+            am_out = am.to(device=dev, dtype=attention_mask.dtype)
+        return out.reshape(B, T, H), am_out, lens
+
+    def prepare_inputs(self, input_ids, images, depths=None, masks=None, attention_mask=None, stages=None):
+        image_features, mask_embeds, depth_embeds = self.encode_visual(images, depths, masks, stages)
+        embeds, am, lens = self.splice(input_ids, attention_mask, image_features, mask_embeds, depth_embeds,
+                                       have_depths=depths is not None)
+        if stages is not None:
+            stages["inputs_embeds"] = embeds
+        return embeds, am, lens
+
+    def embed_tokens(self, input_ids: torch.Tensor) -> torch.Tensor:
+        B, P = input_ids.shape
+        return ops.embed_rows(self.w.embed, input_ids.to(self.device)).reshape(B, P, -1)
+
+    # ------------------------------------------------------------------ A7-A13
+    def _get_state(self, batch: int, T: int, max_new: int) -> DecodeState:
+        need_pos = T + max_new
+        if need_pos > self.w.rope_len:
+            raise ValueError(f"sequence of {need_pos} positions exceeds the RoPE table ({self.w.rope_len})")
+        s = self._state
+        if s is None or s.batch != batch or s.max_pos < need_pos or s.ws_tokens < T or s.max_new < max_new:
+            max_pos = (need_pos + 127) // 128 * 128
+            self._state = None
+            s = DecodeState(self, batch, max_pos, max(T, 1), max_new)
+            self._state = s
+        return s
+
+    def prefill(self, inputs_embeds: torch.Tensor, max_new: int = 1, all_logits: bool = False, hidden_states: bool = False):
+        """inputs_embeds [B,T,H] (equal-length rows).  Returns (state, logits_all|None, hiddens|None)."""
+        B, T, H = inputs_embeds.shape
+        x = inputs_embeds.to(device=self.device, dtype=self.dtype).contiguous()
+        st = self._get_state(B, T, max_new)
+        al = torch.empty((B, T, self.w.vocab), device=self.device, dtype=torch.float32) if all_logits else None
+        hs = torch.empty((self.cfg.layers + 1, B, T, H), device=self.device, dtype=self.dtype) if hidden_states else None
+        L.check(L.load().srgpt_llm_prefill(C.byref(self.w.llm), C.byref(st.c), x.data_ptr(), T,
+                                           None if al is None else al.data_ptr(), None if hs is None else hs.data_ptr(),
+                                           ops._stream()))
+        return st, al, hs
+
+    def greedy_decode(self, st: DecodeState, max_new_tokens: int, eos_token_id=None, pad_token_id=None,
+                      stopping_criteria=None, prompt_ids=None, check_every: int = 8) -> torch.Tensor:
+        """HF greedy loop semantics (new ids only, finished rows padded), device-side steps via hipGraph."""
+        lib = L.load()
+        stream = ops._stream()
+        L.check(lib.srgpt_llm_sample_first(C.byref(self.w.llm), C.byref(st.c), stream))
+        eos = None
+        if eos_token_id is not None:
+            eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else {int(eos_token_id)}
+        interactive = stopping_criteria is not None and len(stopping_criteria) > 0
+        chunk = 1 if interactive else (check_every if eos else max_new_tokens)
+        done_step = 1
+        graph = st.ensure_graph() if self.use_graph and max_new_tokens > 1 else None
+        B = st.batch
+        finished = [False] * B
+        n_keep = max_new_tokens
+
+        def scan(lo, hi):
+            """host-side EOS / stopping-criteria scan of steps [lo, hi); returns stop step or None."""
+            ids = st.out_ids[:, :hi].to("cpu")
+            for s_ in range(lo, hi):
+                for b in range(B):
+                    if eos and not finished[b] and int(ids[b, s_]) in eos:
+                        finished[b] = True
+                if eos and all(finished):
+                    return s_ + 1
+                if interactive:
+                    # HF passes only the generated ids when generate() was fed inputs_embeds
+                    full = ids[:, :s_ + 1]
+                    for crit in stopping_criteria:
+                        r = crit(full, None)
+                        if bool(r.all()) if isinstance(r, torch.Tensor) else bool(r):
+                            return s_ + 1
+            return None
+
+        stop = scan(0, 1) if (eos or interactive) else None
+        while stop is None and done_step < max_new_tokens:
+            n = min(chunk, max_new_tokens - done_step)
+            if graph is not None:
+                L.check(lib.srgpt_graph_launch(graph, n, stream))
+            else:
+                for _ in range(n):
+                    L.check(lib.srgpt_llm_decode_step(C.byref(self.w.llm), C.byref(st.c), stream))
+            if eos or interactive:
+                stop = scan(done_step, done_step + n)
+            done_step += n
+        if stop is not None:
+            n_keep = stop
+        out = st.out_ids[:, :n_keep].clone()
+        if eos:
+            # rows that finished early are padded with pad_token_id (HF behaviour)
+            pad = pad_token_id if pad_token_id is not None else next(iter(eos))
+            ids = out.to("cpu")
+            for b in range(B):
+                hit = [i for i in range(n_keep) if int(ids[b, i]) in eos]
+                if hit and hit[0] + 1 < n_keep:
+                    out[b, hit[0] + 1:] = pad
+        return out

@@ -1,0 +1,332 @@
+"""Drop-in Python surface of the reference VLM wrapper.
+
+Mirrors `LlavaLlamaModel` (llava/model/language_model/llava_llama.py:48-213) and the accessor /
+`prepare_inputs_labels_for_multimodal` surface of llava/model/llava_arch.py:252-650 -- same method names,
+argument meaning and error behaviour -- on top of SrgptEngine (HIP kernels).  `LlavaLlamaForCausalLM`, the
+name BASELINE.json uses, is an alias (the reference never defines it: SURVEY section 0).
+"""
+from __future__ import annotations
+
+import warnings
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+
+from .config import SrgptConfig
+from .engine import SrgptEngine
+
+
+class LlavaLlamaConfig(SrgptConfig):
+    model_type = "llava_llama"
+
+
+class _Facade:
+    """nn.Module-looking handle (callers only use .to/.eval/.config/.is_loaded on sub-modules)."""
+
+    is_loaded = True
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def cuda(self):
+        return self
+
+
+class _VisionTower(_Facade):
+    def __init__(self, eng: SrgptEngine, image_processor=None):
+        self._eng = eng
+        self.image_processor = image_processor
+        c = eng.cfg
+        # the loader records the special-token ids here (llava/model/builder.py:186-192)
+        self.config = SimpleNamespace(hidden_size=c.vit_hidden, image_size=c.image_size, patch_size=c.patch_size,
+                                      llm_mask_token_id=c.mask_token_id, llm_depth_token_id=c.depth_token_id)
+
+    def __call__(self, images):
+        if isinstance(images, list):
+            return [self._eng.vit(im.unsqueeze(0)) for im in images]
+        return self._eng.vit(images)
+
+    @property
+    def device(self):
+        return self._eng.device
+
+    @property
+    def dtype(self):
+        return self._eng.dtype
+
+
+class _RegionExtractor(_Facade):
+    def __init__(self, eng: SrgptEngine):
+        self._eng = eng
+        self.config = SimpleNamespace(region_extractor_type=eng.cfg.region_extractor_type)
+
+    def feature_refinement(self, tower_features):
+        return self._eng.feature_refinement(tower_features.to(self._eng.dtype).contiguous())
+
+    def __call__(self, image_features, depth_features, masks, *a, **k):
+        return self._eng.region_extractor(image_features, depth_features, masks)
+
+    forward = __call__
+
+
+class _Projector(_Facade):
+    def __init__(self, eng: SrgptEngine):
+        self._eng = eng
+        self.config = SimpleNamespace(mm_projector_type=eng.cfg.mm_projector_type)
+
+    def __call__(self, x, *a, **k):
+        return self._eng.mm_projector(x.to(self._eng.dtype).contiguous())
+
+    forward = __call__
+
+
+class _Llm(_Facade):
+    def __init__(self, model: "LlavaLlamaModel"):
+        self._m = model
+        c = model.engine.cfg
+        self.config = SimpleNamespace(hidden_size=c.hidden, vocab_size=c.vocab, num_hidden_layers=c.layers,
+                                      tokenizer_model_max_length=c.tokenizer_model_max_length,
+                                      tokenizer_padding_side=c.padding_side, eos_token_id=c.eos_token_id,
+                                      pad_token_id=c.pad_token_id)
+
+    def generate(self, inputs_embeds=None, attention_mask=None, **kw):
+        return self._m._generate_from_embeds(inputs_embeds, attention_mask, **kw)
+
+    def get_input_embeddings(self):
+        return self._m.get_input_embeddings()
+
+
+class LlavaLlamaModel:
+    config_class = LlavaLlamaConfig
+    main_input_name = "input_embeds"
+
+    def __init__(self, config: SrgptConfig, state_dict: Dict[str, torch.Tensor], device="cuda",
+                 dtype=torch.bfloat16, tokenizer=None, image_processor=None, rope_positions: int = 0,
+                 consume_state_dict: bool = False):
+        self.config = config
+        self.engine = SrgptEngine(config, state_dict, device=device, dtype=dtype, rope_positions=rope_positions,
+                                  consume_state_dict=consume_state_dict)
+        self.tokenizer = tokenizer
+        self.vision_tower = _VisionTower(self.engine, image_processor)
+        self.region_extractor = _RegionExtractor(self.engine) if config.enable_region else None
+        self.mm_projector = _Projector(self.engine)
+        self.llm = _Llm(self)
+        self.is_loaded = True
+        self.training = False
+
+    # ---- nn.Module / PreTrainedModel look-alikes used by the reference's callers ----
+    @property
+    def device(self):
+        return self.engine.device
+
+    @property
+    def dtype(self):
+        return self.engine.dtype
+
+    def eval(self):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    def to(self, *args, **kwargs):
+        dtype = kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+        if dtype is not None and dtype != self.engine.dtype:
+            raise NotImplementedError(
+                f"this engine was built in {self.engine.dtype}; re-load with dtype={dtype} (supported: bfloat16, float32)")
+        return self
+
+    def get_llm(self):
+        return self.llm
+
+    def get_lm_head(self):
+        return self.engine.w.lm_head
+
+    def get_vision_tower(self):
+        return self.vision_tower
+
+    def get_mm_projector(self):
+        return self.mm_projector
+
+    def get_region_extractor(self):
+        return self.region_extractor
+
+    def get_input_embeddings(self):
+        return self.engine.embed_tokens
+
+    def resize_token_embeddings(self, embed_size):
+        if embed_size != self.engine.w.vocab:
+            raise NotImplementedError("resize_token_embeddings after load is not supported; the loader sizes the "
+                                      "embedding for the added <mask>/<depth> tokens")
+
+    def freezed_module_patch(self):
+        return None
+
+    def encode_images(self, images):
+        return self.mm_projector(self.vision_tower(images))
+
+    # ---- llava_arch.py:333-650 ----
+    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
+                                             images, masks=None, depths=None):
+        if images is None or input_ids.shape[1] == 1:
+            if past_key_values is not None and images is not None and input_ids.shape[1] == 1:
+                target = past_key_values.seq_len() + 1  # llava_arch.py:355-385
+                attention_mask = torch.cat((attention_mask, torch.ones(
+                    (attention_mask.shape[0], target - attention_mask.shape[1]), dtype=attention_mask.dtype,
+                    device=attention_mask.device)), dim=1)
+                position_ids = torch.sum(attention_mask, dim=1).unsqueeze(-1) - 1
+            return input_ids, position_ids, attention_mask, past_key_values, None, labels
+        if getattr(self.config, "turn_mm_projector", False) and self.config.mm_use_im_start_end:
+            raise NotImplementedError
+        embeds, am, lens = self.engine.prepare_inputs(input_ids, images, depths, masks, attention_mask)
+        pos = None
+        if position_ids is not None:
+            T = embeds.shape[1]
+            pos = torch.zeros((len(lens), T), dtype=torch.long, device=embeds.device)
+            for b, n in enumerate(lens):
+                if self.config.padding_side == "left":
+                    pos[b, T - n:] = torch.arange(n, device=embeds.device)
+                else:
+                    pos[b, :n] = torch.arange(n, device=embeds.device)
+        new_labels = None
+        if labels is not None:
+            raise NotImplementedError("labels (training) are outside the inference hot path")
+        return None, pos, am, past_key_values, embeds, new_labels
+
+    # ---- llava_llama.py:100-192 (inference branch) ----
+    def forward(self, input_ids=None, images=None, masks=None, depths=None, attention_mask=None, position_ids=None,
+                past_key_values=None, seqlens_in_batch=None, inputs_embeds=None, labels=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, return_dict=None, dpo_forward=False):
+        if labels is not None:
+            raise NotImplementedError("labels / loss are outside the inference hot path")
+        if inputs_embeds is None:
+            if images is None:
+                inputs_embeds = self.engine.embed_tokens(input_ids)
+            else:
+                (_, position_ids, attention_mask, past_key_values, inputs_embeds, _) = \
+                    self.prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, past_key_values,
+                                                              None, images, masks, depths)
+        if attention_mask is None:
+            # reference: `attention_mask.sum(-1)` on None -> AttributeError (SURVEY 3.2 gotcha)
+            raise AttributeError("'NoneType' object has no attribute 'sum'")
+        if past_key_values is not None:
+            raise NotImplementedError("incremental forward() with an external cache: use generate()")
+        if not bool(attention_mask.bool().all()):
+            raise NotImplementedError("padded (ragged) batches in forward(): run the rows separately")
+        st, logits, hs = self.engine.prefill(inputs_embeds, max_new=1, all_logits=True,
+                                             hidden_states=bool(output_hidden_states))
+        out = SimpleNamespace(loss=None, logits=logits, past_key_values=st,
+                              hidden_states=None if hs is None else tuple(hs[i] for i in range(hs.shape[0])),
+                              attentions=None)
+        if dpo_forward:
+            return out.logits, None
+        return out
+
+    __call__ = forward
+
+    # ---- llava_llama.py:194-213 ----
+    @torch.no_grad()
+    def generate(self, input_ids=None, images=None, depths=None, masks=None, attention_mask=None, **generation_kwargs):
+        if images is not None:
+            (_, _, attention_mask, _, inputs_embeds, _) = self.prepare_inputs_labels_for_multimodal(
+                input_ids, None, attention_mask, None, None, images, masks, depths)
+        else:
+            inputs_embeds = self.engine.embed_tokens(input_ids)
+        inputs_embeds = inputs_embeds.to(self.dtype)
+        return self.llm.generate(inputs_embeds=inputs_embeds, attention_mask=attention_mask, **generation_kwargs)
+
+    def _generate_from_embeds(self, inputs_embeds, attention_mask=None, do_sample=False, temperature=1.0, top_p=None,
+                              top_k=None, num_beams=1, max_new_tokens=None, max_length=None, min_new_tokens=None,
+                              use_cache=True, stopping_criteria=None, pad_token_id=None, eos_token_id="default",
+                              **unused):
+        if num_beams != 1:
+            raise NotImplementedError("beam search is not implemented (the reference's callers use num_beams=1)")
+        if max_new_tokens is None:
+            max_new_tokens = 20 if max_length is None else max(1, max_length)
+        if eos_token_id == "default":
+            eos_token_id = self.config.eos_token_id
+        if min_new_tokens is not None and min_new_tokens >= max_new_tokens:
+            eos_token_id = None
+        if pad_token_id is None:
+            pad_token_id = self.config.pad_token_id
+        B, T, _ = inputs_embeds.shape
+        if attention_mask is not None and not bool(attention_mask.bool().all()):
+            # ragged batch: the reference right-pads and relies on varlen flash-attn; here rows run one by one
+            outs = []
+            for b in range(B):
+                keep = attention_mask[b].bool()
+                outs.append(self._generate_from_embeds(inputs_embeds[b:b + 1][:, keep], None, do_sample, temperature,
+                                                       top_p, top_k, num_beams, max_new_tokens, None, min_new_tokens,
+                                                       use_cache, stopping_criteria, pad_token_id, eos_token_id))
+            G = max(o.shape[1] for o in outs)
+            pad = pad_token_id if pad_token_id is not None else (eos_token_id if isinstance(eos_token_id, int) else 0)
+            res = torch.full((B, G), pad, dtype=torch.int64, device=self.device)
+            for b, o in enumerate(outs):
+                res[b, :o.shape[1]] = o[0]
+            return res
+        st, _, _ = self.engine.prefill(inputs_embeds, max_new=max_new_tokens)
+        if do_sample and temperature is not None and temperature > 0:
+            return self._sample_loop(st, max_new_tokens, temperature, top_p, top_k, eos_token_id, pad_token_id,
+                                     stopping_criteria)
+        return self.engine.greedy_decode(st, max_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
+                                         stopping_criteria=stopping_criteria)
+
+    def _sample_loop(self, st, max_new_tokens, temperature, top_p, top_k, eos_token_id, pad_token_id, stopping_criteria):
+        """temperature / top-p sampling (demo path, gradio_web_server_multi.py:202-213).  Outside the timed greedy
+        path: the transformer steps are the HIP decode step; only the categorical draw over the final
+        logits uses torch."""
+        import ctypes as C
+
+        from . import _lib as L
+        from . import ops
+
+        eng, lib = self.engine, L.load()
+        eos = None if eos_token_id is None else ({int(eos_token_id)} if isinstance(eos_token_id, int) else set(eos_token_id))
+        B = st.batch
+        finished = torch.zeros(B, dtype=torch.bool, device=self.device)
+        out = []
+        for step in range(max_new_tokens):
+            if step > 0:
+                L.check(lib.srgpt_llm_decode_step(C.byref(eng.w.llm), C.byref(st.c), ops._stream()))
+            logits = st.logits / temperature
+            if top_k:
+                kth = torch.topk(logits, int(top_k), dim=-1).values[:, -1:]
+                logits = logits.masked_fill(logits < kth, float("-inf"))
+            if top_p is not None and top_p < 1.0:
+                sl, si = torch.sort(logits, descending=False, dim=-1)
+                cp = sl.softmax(-1).cumsum(-1)
+                rm = cp <= (1 - top_p)
+                rm[..., -1:] = False
+                logits = logits.masked_fill(rm.scatter(1, si, rm), float("-inf"))
+            tok = torch.multinomial(logits.softmax(-1), 1).squeeze(1)
+            if eos:
+                padv = pad_token_id if pad_token_id is not None else next(iter(eos))
+                tok = torch.where(finished, torch.full_like(tok, padv), tok)
+            st.tok.copy_(tok)  # the next decode step embeds this token
+            if step == 0:
+                st.step.zero_()
+            out.append(tok)
+            if eos:
+                for e in eos:
+                    finished |= tok == e
+            ids = torch.stack(out, dim=1)
+            if stopping_criteria:
+                stop = False
+                for crit in stopping_criteria:
+                    r = crit(ids.cpu(), None)
+                    stop |= bool(r.all()) if isinstance(r, torch.Tensor) else bool(r)
+                if stop:
+                    break
+            if eos and bool(finished.all()):
+                break
+        return torch.stack(out, dim=1)
+
+
+LlavaLlamaForCausalLM = LlavaLlamaModel

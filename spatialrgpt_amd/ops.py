@@ -1,0 +1,212 @@
+"""Tensor-level wrappers over the C ABI (include/srgpt.h).  torch is used only for device memory and
+streams: every arithmetic op below is a HIP kernel from libsrgpt_hip.so, launched on the caller's
+current torch stream.  Inputs must be CUDA(HIP) tensors; there is no CPU path."""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+
+
+def dt_code(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise ValueError(f"srgpt kernels support float32 and bfloat16 tensors, got {t.dtype}") from None
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("srgpt ops need tensors on the GPU (no CPU fallback)")
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def gemm(a, w, bias=None, residual=None, act=L.ACT_NONE, out=None, out_f32=False, bias_mod=0, res_mod=0,
+         out_mode=L.OUT_PLAIN, gw=0, out_shape=None):
+    """act(a @ w.T + bias) + residual.  a [M,K] (row stride may exceed K), w [N,K]."""
+    _dev(a, w, bias, residual)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.stride(1) == 1 and w.is_contiguous()
+    if out is None:
+        shape = out_shape if out_shape is not None else (M, N)
+        out = torch.empty(shape, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    ldc = N if out_mode != L.OUT_PLAIN else out.stride(0) if out.dim() == 2 else N
+    L.check(L.load().srgpt_gemm(_p(a), _p(w), _p(bias), _p(residual), _p(out), M, N, K, a.stride(0), ldc, act,
+                                bias_mod, res_mod, int(out_f32), out_mode, gw, dt_code(a), _stream()))
+    return out
+
+
+def gemv(x, w, norm_w=None, eps=0.0, residual=None, swiglu=False, out=None, out_f32=False):
+    """decode GEMV: x [B,K], w [N(,2N if swiglu),K] -> [B,N]."""
+    _dev(x, w, norm_w, residual)
+    B, K = x.shape
+    N = w.shape[0] // 2 if swiglu else w.shape[0]
+    if out is None:
+        out = torch.empty((B, N), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    L.check(L.load().srgpt_gemv(_p(_c(x)), _p(w), _p(norm_w), float(eps), _p(residual), _p(out), B, N, K, int(swiglu),
+                                int(out_f32), dt_code(x), _stream()))
+    return out
+
+
+def layernorm(x, w, b, eps, act=L.ACT_NONE, out=None):
+    _dev(x, w, b)
+    x = _c(x)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.load().srgpt_layernorm(_p(x), _p(w), _p(b), _p(out), rows, cols, float(eps), act, dt_code(x), _stream()))
+    return out
+
+
+def rmsnorm(x, w, eps, out=None):
+    _dev(x, w)
+    x = _c(x)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.load().srgpt_rmsnorm(_p(x), _p(w), _p(out), rows, cols, float(eps), dt_code(x), _stream()))
+    return out
+
+
+def attention(q, k, v, causal=False, scale=None, kv_len=None):
+    """q [B,Tq,Hq,D], k/v [B,Tk,Hkv,D] (arbitrary strides with unit last stride) -> [B,Tq,Hq,D]."""
+    _dev(q, k, v)
+    B, Tq, Hq, D = q.shape
+    Tk, Hkv = k.shape[1], k.shape[2]
+    assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    o = torch.empty((B, Tq, Hq, D), device=q.device, dtype=q.dtype)
+    L.check(L.load().srgpt_attention(_p(q), _p(k), _p(v), _p(o), B, Tq, Tk, Hq, Hkv, D, q.stride(0), q.stride(1),
+                                     q.stride(2), k.stride(0), k.stride(1), k.stride(2), v.stride(0), v.stride(1),
+                                     v.stride(2), float(scale), int(causal), _p(kv_len), dt_code(q), _stream()))
+    return o
+
+
+def rope_kv_append(qkv, kcache, vcache, cos_tab, sin_tab, B, T, Hq, Hkv, D, pos0=None):
+    _dev(qkv, kcache, vcache, cos_tab, sin_tab)
+    max_pos = kcache.shape[-2]
+    L.check(L.load().srgpt_rope_kv_append(_p(qkv), _p(kcache), _p(vcache), _p(pos0), _p(cos_tab), _p(sin_tab), B, T, Hq,
+                                          Hkv, D, max_pos, dt_code(qkv), _stream()))
+
+
+def decode_attention(qkv, kcache, vcache, pos, cos_tab, sin_tab, Hq, Hkv, D):
+    _dev(qkv, kcache, vcache, pos)
+    B = qkv.shape[0]
+    max_pos = kcache.shape[-2]
+    out = torch.empty((B, Hq * D), device=qkv.device, dtype=qkv.dtype)
+    ws = torch.empty((L.load().srgpt_decode_attn_ws_floats(B, Hq, D),), device=qkv.device, dtype=torch.float32)
+    L.check(L.load().srgpt_decode_attention(_p(qkv), _p(kcache), _p(vcache), _p(pos), _p(cos_tab), _p(sin_tab), _p(out),
+                                            _p(ws), B, Hq, Hkv, D, max_pos, dt_code(qkv), _stream()))
+    return out
+
+
+def region_pool(feat, masks, fw: Optional[int] = None):
+    """MaskPooling for one image: feat [L,C], masks [M,mh,mw] (float32 or bfloat16) -> [M,C]."""
+    _dev(feat, masks)
+    Lf, Cc = feat.shape
+    M, mh, mw = masks.shape
+    sf = (Lf / (mh * mw)) ** 0.5  # base_extractor.py:53-54 (python float = double)
+    oh, ow = int(math.floor(mh * sf)), int(math.floor(mw * sf))  # F.interpolate(scale_factor=...) output size
+    if oh * ow != Lf or oh != ow:
+        raise RuntimeError(f"mask of size {mh}x{mw} resamples to {oh}x{ow}, which does not match {Lf} feature tokens")
+    if masks.dtype not in (torch.float32, torch.bfloat16):
+        masks = masks.float()  # reference: mask.float()
+    masks = _c(masks)
+    rs = 1.0 / sf  # ATen passes static_cast<float>(1.0 / scale_factor)
+    outs = []
+    lib = L.load()
+    for m0 in range(0, M, 16):
+        mm = min(16, M - m0)
+        out = torch.empty((mm, Cc), device=feat.device, dtype=feat.dtype)
+        ws = torch.empty((lib.srgpt_region_pool_ws_floats(mm, oh, Cc),), device=feat.device, dtype=torch.float32)
+        L.check(lib.srgpt_region_pool(_p(_c(feat)), _p(masks[m0:m0 + mm]), _p(out), _p(ws), mm, mh, mw, oh, Cc, rs, rs,
+                                      _DT[masks.dtype], dt_code(feat), _stream()))
+        outs.append(out)
+    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+
+def avgpool(x, n_img, in_w, out_w):
+    _dev(x)
+    Cc = x.shape[-1]
+    y = torch.empty((n_img, out_w * out_w, Cc), device=x.device, dtype=x.dtype)
+    L.check(L.load().srgpt_avgpool(_p(_c(x)), _p(y), n_img, in_w, out_w, Cc, dt_code(x), _stream()))
+    return y
+
+
+def s2d(x):
+    """DownSampleBlock: [n, g*g, C] -> [n, ceil(g/2)^2, 4C]."""
+    _dev(x)
+    n, Lx, Cc = x.shape
+    g = int(Lx ** 0.5)
+    hb = (g + 1) // 2
+    y = torch.empty((n, hb * hb, 4 * Cc), device=x.device, dtype=x.dtype)
+    L.check(L.load().srgpt_s2d(_p(_c(x)), _p(y), n, g, Cc, dt_code(x), _stream()))
+    return y
+
+
+def im2col(images, patch, kp):
+    _dev(images)
+    n, ch, S, _ = images.shape
+    assert ch == 3
+    g = S // patch
+    out = torch.empty((n * g * g, kp), device=images.device, dtype=images.dtype)
+    L.check(L.load().srgpt_im2col(_p(_c(images)), _p(out), n, S, patch, kp, dt_code(images), _stream()))
+    return out
+
+
+def embed_rows(table, ids):
+    _dev(table, ids)
+    ids = _c(ids.to(torch.int64)).reshape(-1)
+    out = torch.empty((ids.numel(), table.shape[1]), device=table.device, dtype=table.dtype)
+    L.check(L.load().srgpt_embed_rows(_p(table), _p(ids), _p(out), ids.numel(), table.shape[1], dt_code(table), _stream()))
+    return out
+
+
+def scatter_rows(src, idx, dst, src_idx=None):
+    """dst[idx[i]] = src[src_idx[i] if src_idx is given else i]"""
+    _dev(src, idx, dst, src_idx)
+    assert idx.dtype == torch.int32 and src.is_contiguous() and dst.is_contiguous()
+    assert src_idx is None or (src_idx.dtype == torch.int32 and src_idx.numel() == idx.numel())
+    n = idx.numel()
+    if n == 0:
+        return dst
+    L.check(L.load().srgpt_scatter_rows(_p(src), _p(src_idx), _p(idx), _p(dst), n, src.shape[-1], dt_code(src), _stream()))
+    return dst
+
+
+def silu_mul(gu):
+    _dev(gu)
+    rows, two_i = gu.shape
+    out = torch.empty((rows, two_i // 2), device=gu.device, dtype=gu.dtype)
+    L.check(L.load().srgpt_silu_mul(_p(_c(gu)), _p(out), rows, two_i // 2, dt_code(gu), _stream()))
+    return out
+
+
+def argmax(logits):
+    _dev(logits)
+    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    B, V = logits.shape
+    out = torch.empty((B,), device=logits.device, dtype=torch.int64)
+    L.check(L.load().srgpt_argmax(_p(logits), _p(out), B, V, _stream()))
+    return out

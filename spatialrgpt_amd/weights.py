@@ -1,0 +1,220 @@
+"""Weight layout in HBM.
+
+Input: a state dict with the reference's checkpoint key names (llava/model/llava_arch.py:181-250:
+sub-dirs llm/ vision_tower/ mm_projector/ region_extractor/; HF 4.37.2 key names inside).
+Output: device tensors arranged for the kernels --
+  * q/k/v rows concatenated ([q;k;v], one GEMM / one weight stream per layer), gate/up rows concatenated
+  * patch-embed conv flattened to [C, 3*p*p] and zero-padded to a 16-byte multiple
+  * ConvTranspose2d(k=2,s=2) weights [Cin,Cout,2,2] re-laid as [(a,b,co), ci] so the deconv is a GEMM whose
+    output columns are contiguous channels of one output pixel
+  * RoPE cos/sin tables (fp32 angle, cast to the model dtype -- modeling_llama.py:81-130)
+and the ctypes structs (include/srgpt.h) that point at them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List
+
+import torch
+
+from . import _lib as L
+from .config import SrgptConfig
+
+VT = "vision_tower.vision_tower.vision_model."
+RE = "region_extractor."
+MP = "mm_projector.layers."
+LM = "llm."
+
+
+def _ptr_array(tensors: List[torch.Tensor]):
+    arr = (L.vp * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def rope_tables(cfg: SrgptConfig, n_pos: int, dtype, device):
+    d = cfg.head_dim
+    inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
+    if cfg.rope_factor != 1.0:
+        inv_freq = inv_freq / cfg.rope_factor
+    pos = torch.arange(n_pos, dtype=torch.int64).float()
+    freqs = pos[:, None] * inv_freq[None, :]  # fp32, as LlamaRotaryEmbedding (autocast disabled)
+    return freqs.cos().to(dtype).to(device).contiguous(), freqs.sin().to(dtype).to(device).contiguous()
+
+
+class PreparedWeights:
+    """Owns the device tensors and the C structs pointing at them."""
+
+    def __init__(self, cfg: SrgptConfig, sd: Dict[str, torch.Tensor], device, dtype, rope_positions: int = 0,
+                 consume: bool = False):
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self._keep: List[object] = []
+        code = {torch.float32: L.F32, torch.bfloat16: L.BF16}[dtype]
+
+        def get(name):
+            t = sd.pop(name) if consume else sd[name]
+            return t.to(device=self.device, dtype=dtype).contiguous()
+
+        # ---------------- vision tower ----------------
+        C_, p = cfg.vit_hidden, cfg.patch_size
+        kk = 3 * p * p
+        self.kp = (kk + 7) // 8 * 8
+        pw = get(VT + "embeddings.patch_embedding.weight").reshape(C_, kk)
+        patch_w = torch.zeros((C_, self.kp), device=self.device, dtype=dtype)
+        patch_w[:, :kk] = pw
+        self.patch_w = patch_w
+        self.patch_b = get(VT + "embeddings.patch_embedding.bias")
+        self.pos_emb = get(VT + "embeddings.position_embedding.weight")
+        n_run = cfg.vit_layers_run
+        v = {k: [] for k in ("ln1_w", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")}
+        for i in range(n_run):
+            q = f"{VT}encoder.layers.{i}."
+            v["ln1_w"].append(get(q + "layer_norm1.weight"))
+            v["ln1_b"].append(get(q + "layer_norm1.bias"))
+            v["wqkv"].append(torch.cat([get(q + f"self_attn.{n}_proj.weight") for n in "qkv"], 0).contiguous())
+            v["bqkv"].append(torch.cat([get(q + f"self_attn.{n}_proj.bias") for n in "qkv"], 0).contiguous())
+            v["wo"].append(get(q + "self_attn.out_proj.weight"))
+            v["bo"].append(get(q + "self_attn.out_proj.bias"))
+            v["ln2_w"].append(get(q + "layer_norm2.weight"))
+            v["ln2_b"].append(get(q + "layer_norm2.bias"))
+            v["w1"].append(get(q + "mlp.fc1.weight"))
+            v["b1"].append(get(q + "mlp.fc1.bias"))
+            v["w2"].append(get(q + "mlp.fc2.weight"))
+            v["b2"].append(get(q + "mlp.fc2.bias"))
+        self.vit_t = v
+        vw = L.VitWeights()
+        vw.dtype, vw.hidden, vw.inter, vw.heads = code, C_, cfg.vit_inter, cfg.vit_heads
+        vw.n_layers_run, vw.image_size, vw.patch, vw.kp, vw.eps = n_run, cfg.image_size, p, self.kp, cfg.vit_eps
+        vw.patch_w, vw.patch_b, vw.pos_emb = self.patch_w.data_ptr(), self.patch_b.data_ptr(), self.pos_emb.data_ptr()
+        for k, ts in v.items():
+            arr = _ptr_array(ts)
+            self._keep.append(arr)
+            setattr(vw, k, arr)
+        self.vit = vw
+
+        # ---------------- region extractor ----------------
+        if cfg.enable_region:
+            fr = RE + "feature_refinement_module."
+
+            def deconv_w(name):
+                w = get(name)  # [Cin, Cout, 2, 2]
+                cin, cout = w.shape[0], w.shape[1]
+                return w.permute(2, 3, 1, 0).reshape(4 * cout, cin).contiguous()
+
+            self.dc1_w, self.dc1_b = deconv_w(fr + "0.weight"), get(fr + "0.bias")
+            self.ln2d_w, self.ln2d_b = get(fr + "1.weight"), get(fr + "1.bias")
+            self.dc2_w, self.dc2_b = deconv_w(fr + "3.weight"), get(fr + "3.bias")
+            self.rgb_w, self.rgb_b = get(RE + "rgb_projector.weight"), get(RE + "rgb_projector.bias")
+            self.depth_w, self.depth_b = get(RE + "depth_projector.weight"), get(RE + "depth_projector.bias")
+
+        # ---------------- projector (mlp_downsample) ----------------
+        self.mp_ln_w, self.mp_ln_b = get(MP + "1.weight"), get(MP + "1.bias")
+        self.mp_w1, self.mp_b1 = get(MP + "2.weight"), get(MP + "2.bias")
+        self.mp_w2, self.mp_b2 = get(MP + "4.weight"), get(MP + "4.bias")
+
+        # ---------------- language model ----------------
+        self.embed = get(LM + "model.embed_tokens.weight")
+        self.final_norm = get(LM + "model.norm.weight")
+        self.lm_head = get(LM + "lm_head.weight")
+        lt = {k: [] for k in ("attn_norm", "wqkv", "wo", "mlp_norm", "wgu", "wdown")}
+        for i in range(cfg.layers):
+            q = f"{LM}model.layers.{i}."
+            lt["attn_norm"].append(get(q + "input_layernorm.weight"))
+            lt["wqkv"].append(torch.cat([get(q + f"self_attn.{n}_proj.weight") for n in "qkv"], 0).contiguous())
+            lt["wo"].append(get(q + "self_attn.o_proj.weight"))
+            lt["mlp_norm"].append(get(q + "post_attention_layernorm.weight"))
+            lt["wgu"].append(torch.cat([get(q + "mlp.gate_proj.weight"), get(q + "mlp.up_proj.weight")], 0).contiguous())
+            lt["wdown"].append(get(q + "mlp.down_proj.weight"))
+        self.llm_t = lt
+        n_pos = rope_positions or cfg.max_position_embeddings
+        self.rope_len = n_pos
+        self.rope_cos, self.rope_sin = rope_tables(cfg, n_pos, dtype, self.device)
+        lw = L.LlmWeights()
+        lw.dtype, lw.hidden, lw.inter, lw.layers = code, cfg.hidden, cfg.inter, cfg.layers
+        lw.heads, lw.kv_heads, lw.head_dim, lw.vocab, lw.rms_eps = cfg.heads, cfg.kv_heads, cfg.head_dim, self.embed.shape[0], cfg.rms_eps
+        lw.rope_cos, lw.rope_sin = self.rope_cos.data_ptr(), self.rope_sin.data_ptr()
+        lw.embed, lw.final_norm, lw.lm_head = self.embed.data_ptr(), self.final_norm.data_ptr(), self.lm_head.data_ptr()
+        for k, ts in lt.items():
+            arr = _ptr_array(ts)
+            self._keep.append(arr)
+            setattr(lw, k, arr)
+        self.llm = lw
+        self.vocab = self.embed.shape[0]
+
+    def llm_weight_bytes(self) -> int:
+        """bytes streamed from HBM per decoded token at batch 1 (everything but embed_tokens)."""
+        n = self.final_norm.numel() + self.lm_head.numel()
+        for ts in self.llm_t.values():
+            n += sum(t.numel() for t in ts)
+        return n * self.embed.element_size()
+
+
+def weight_shapes(cfg: SrgptConfig) -> Dict[str, tuple]:
+    C_, I, H, F_, V, d = cfg.vit_hidden, cfg.vit_inter, cfg.hidden, cfg.inter, cfg.vocab, cfg.head_dim
+    s: Dict[str, tuple] = {}
+    s[VT + "embeddings.patch_embedding.weight"] = (C_, 3, cfg.patch_size, cfg.patch_size)
+    s[VT + "embeddings.patch_embedding.bias"] = (C_,)
+    s[VT + "embeddings.position_embedding.weight"] = (cfg.grid ** 2, C_)
+    for i in range(cfg.vit_layers_run):  # layers past select_layer never influence the output
+        p = f"{VT}encoder.layers.{i}."
+        for n in ("layer_norm1", "layer_norm2"):
+            s[p + n + ".weight"] = (C_,)
+            s[p + n + ".bias"] = (C_,)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[p + f"self_attn.{n}.weight"] = (C_, C_)
+            s[p + f"self_attn.{n}.bias"] = (C_,)
+        s[p + "mlp.fc1.weight"] = (I, C_)
+        s[p + "mlp.fc1.bias"] = (I,)
+        s[p + "mlp.fc2.weight"] = (C_, I)
+        s[p + "mlp.fc2.bias"] = (C_,)
+    p = RE + "feature_refinement_module."
+    s[p + "0.weight"] = (C_, C_, 2, 2)
+    s[p + "0.bias"] = (C_,)
+    s[p + "1.weight"] = (C_,)
+    s[p + "1.bias"] = (C_,)
+    s[p + "3.weight"] = (C_, C_, 2, 2)
+    s[p + "3.bias"] = (C_,)
+    for n in ("rgb_projector", "depth_projector"):
+        s[RE + n + ".weight"] = (H, C_)
+        s[RE + n + ".bias"] = (H,)
+    s[MP + "1.weight"] = (4 * C_,)
+    s[MP + "1.bias"] = (4 * C_,)
+    s[MP + "2.weight"] = (H, 4 * C_)
+    s[MP + "2.bias"] = (H,)
+    s[MP + "4.weight"] = (H, H)
+    s[MP + "4.bias"] = (H,)
+    s[LM + "model.embed_tokens.weight"] = (V, H)
+    for i in range(cfg.layers):
+        p = f"{LM}model.layers.{i}."
+        s[p + "input_layernorm.weight"] = (H,)
+        s[p + "post_attention_layernorm.weight"] = (H,)
+        s[p + "self_attn.q_proj.weight"] = (cfg.heads * d, H)
+        s[p + "self_attn.k_proj.weight"] = (cfg.kv_heads * d, H)
+        s[p + "self_attn.v_proj.weight"] = (cfg.kv_heads * d, H)
+        s[p + "self_attn.o_proj.weight"] = (H, cfg.heads * d)
+        s[p + "mlp.gate_proj.weight"] = (F_, H)
+        s[p + "mlp.up_proj.weight"] = (F_, H)
+        s[p + "mlp.down_proj.weight"] = (H, F_)
+    s[LM + "model.norm.weight"] = (H,)
+    s[LM + "lm_head.weight"] = (V, H)
+    return s
+
+
+def synth_state_dict(cfg: SrgptConfig, seed: int, dtype, device, std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """Seeded random weights of the named architecture, generated on `device` (no checkpoints exist offline).
+    Matrices/biases ~ N(0, std), norm gains 1 + N(0, std), embeddings ~ N(0, 0.5)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, shape in weight_shapes(cfg).items():
+        t = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+        is_gain = name.endswith(("norm.weight", "layernorm.weight", "layer_norm1.weight", "layer_norm2.weight")) or \
+            name in (RE + "feature_refinement_module.1.weight", MP + "1.weight")
+        if "position_embedding" in name or "embed_tokens" in name:
+            t = t * 0.5
+        elif is_gain:
+            t = 1.0 + t * std
+        else:
+            t = t * std
+        sd[name] = t.to(dtype)
+    return sd

@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library builds/loads here (hipcc cross-compiles) and exports every symbol include/srgpt.h
+declares.  No compute call is made (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from tests.util import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "srgpt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(srgpt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    from spatialrgpt_amd import _lib
+
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/srgpt.h but not exported"
+    assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
+    assert lib.srgpt_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    """field order of the ctypes mirrors == field order in the header (guards silent ABI drift)."""
+    from spatialrgpt_amd import _lib
+
+    src = open(os.path.join(ROOT, "include", "srgpt.h")).read()
+
+    def fields(struct_name):
+        body = re.search(r"typedef struct \{([^}]*)\} " + struct_name + ";", src).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                out.append(re.findall(r"([A-Za-z_0-9]+)\s*$", part.strip())[0])
+        return out
+
+    assert fields("srgpt_vit_weights") == [f[0] for f in _lib.VitWeights._fields_]
+    assert fields("srgpt_llm_weights") == [f[0] for f in _lib.LlmWeights._fields_]
+    assert fields("srgpt_llm_state") == [f[0] for f in _lib.LlmState._fields_]
+
+
+def test_error_code_mapping():
+    from spatialrgpt_amd import _lib
+
+    _lib.check(0)
+    for code, exc in ((_lib.ERR_ARG, ValueError), (_lib.ERR_UNSUPPORTED, NotImplementedError), (_lib.ERR_LAUNCH, RuntimeError)):
+        with pytest.raises(exc):
+            _lib.check(code)
+
+
+def test_argument_validation_without_gpu():
+    """argument errors are detected on the host before any launch -> safe to exercise without a GPU."""
+    from spatialrgpt_amd import _lib
+
+    lib = _lib.load()
+    rc = lib.srgpt_gemm(None, None, None, None, None, 1, 1, 8, 8, 1, 0, 0, 0, 0, 0, 0, _lib.BF16, None)
+    assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
+    rc = lib.srgpt_gemm(16, 16, None, None, 16, 4, 4, 7, 7, 4, 0, 0, 0, 0, 0, 0, _lib.BF16, None)
+    assert rc == _lib.ERR_ARG and b"multiples" in lib.srgpt_last_error()
+    rc = lib.srgpt_gemv(16, 16, None, 0.0, None, 16, 9, 8, 8, 0, 0, _lib.BF16, None)
+    assert rc == _lib.ERR_UNSUPPORTED
+    assert lib.srgpt_decode_attn_ws_floats(1, 32, 128) == 32 * 64 * 130
+    assert lib.srgpt_region_pool_ws_floats(8, 108, 1152) == 8 * 11664 + 92 * 8 * 1152

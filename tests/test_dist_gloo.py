@@ -1,0 +1,62 @@
+"""CPU, world_size 2 over gloo: request sharding + the all-gather exchange step."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeModel:
+    """generate() returns ids derived from the request so that ordering can be checked."""
+    device = "cpu"
+
+    def generate(self, input_ids=None, n_new=3, **kw):
+        base = int(input_ids[0, 0])
+        return torch.arange(base, base + n_new, dtype=torch.int64)[None]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from spatialrgpt_amd.dist import gather_ids, generate_data_parallel, init_distributed
+
+    r, w, _ = init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    # ragged shards: rank 0 has 2 rows x 4 ids, rank 1 has 1 row x 2 ids
+    local = torch.full((2, 4), 10, dtype=torch.int64) if rank == 0 else torch.full((1, 2), 20, dtype=torch.int64)
+    allids = gather_ids(local, pad_id=-1)
+    assert allids.shape == (3, 4)
+    assert allids[:2].eq(10).all() and allids[2, :2].eq(20).all() and allids[2, 2:].eq(-1).all()
+    reqs = [dict(input_ids=torch.tensor([[100 * i]]), n_new=2 + (i % 2)) for i in range(5)]
+    out = generate_data_parallel(_FakeModel(), reqs, pad_id=-1)
+    exp = torch.full((5, 3), -1, dtype=torch.int64)
+    for i in range(5):
+        n = 2 + (i % 2)
+        exp[i, :n] = torch.arange(100 * i, 100 * i + n)
+    assert torch.equal(out, exp), (out, exp)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+@pytest.mark.timeout(120)
+def test_shard_and_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(100)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]

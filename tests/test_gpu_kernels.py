@@ -1,0 +1,303 @@
+"""GPU parity tests, one per kernel family, through the C ABI (spatialrgpt_amd.ops -> libsrgpt_hip.so).
+Checker = the oracle's functions / plain fp32 torch on the CPU.  Tolerances: fp32 path 1e-4 (accumulation
+order), bf16 path 2e-2 relative to the tensor scale (one bf16 ulp = 0.4 %, chained roundings)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close, load_kat
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from spatialrgpt_amd import _lib, ops
+    return ops, _lib
+
+
+def _rand(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def _tol(ref, dtype, k=1.0):
+    s = float(ref.float().abs().max()) + 1e-6
+    return (2e-2 if dtype == torch.bfloat16 else 2e-5) * s * k
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(130, 200, 136), (259, 512, 1024), (64, 64, 64), (729, 1152, 592), (100, 264, 4304),
+                                   (8, 4096, 1152), (300, 1000, 72)])
+def test_gemm_plain(dtype, M, N, K):
+    ops, L = _ops()
+    if dtype == torch.float32 and K % 4:
+        pytest.skip("K % 4")
+    a, w = _rand((M, K), dtype, 1), _rand((N, K), dtype, 2, 0.05)
+    b, r = _rand((N,), dtype, 3), _rand((M, N), dtype, 4)
+    ref = a.float() @ w.float().T
+    out = ops.gemm(a.to(DEV), w.to(DEV))
+    assert_close(out, ref, _tol(ref, dtype), 0, "gemm")
+    # asymmetric epilogue: bias, tanh-gelu, residual
+    ref2 = F.gelu((ref + b.float()).to(dtype).float(), approximate="tanh").to(dtype).float() + r.float()
+    out2 = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV), act=L.ACT_GELU_TANH)
+    assert_close(out2, ref2, _tol(ref2, dtype), 0, "gemm+bias+gelu+res")
+    out3 = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), act=L.ACT_GELU_ERF, out_f32=True)
+    assert out3.dtype == torch.float32
+    assert_close(out3, F.gelu((ref + b.float()).to(dtype).float()), _tol(ref, dtype), 0, "gemm f32 out")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_strided_a_and_row_modulo_residual(dtype):
+    ops, L = _ops()
+    big = _rand((96, 3 * 64), dtype, 5)
+    a = big[:, 64:128]  # row stride 192, K = 64
+    w, pos = _rand((80, 64), dtype, 6, 0.1), _rand((32, 80), dtype, 7)
+    ref = a.float() @ w.float().T
+    ref = ref.to(dtype).float() + pos.float().repeat(3, 1)
+    out = ops.gemm(big.to(DEV)[:, 64:128], w.to(DEV), residual=pos.to(DEV), res_mod=32)
+    assert_close(out, ref, _tol(ref, dtype), 0, "strided A + residual row modulo")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("n_img,g,C", [(1, 27, 64), (2, 6, 32), (1, 24, 48)])
+def test_gemm_deconv2x(dtype, n_img, g, C):
+    """ConvTranspose2d(C,C,2,2) as GEMM + pixel shuffle, channels-last."""
+    ops, L = _ops()
+    x = _rand((n_img, g * g, C), dtype, 8)
+    wt, b = _rand((C, C, 2, 2), dtype, 9, 0.1), _rand((C,), dtype, 10)
+    ref = F.conv_transpose2d(x.float().reshape(n_img, g, g, C).permute(0, 3, 1, 2), wt.float(), b.float(), stride=2)
+    ref = F.gelu(ref.to(dtype).float()).flatten(2).transpose(1, 2)  # N (H W) C
+    w2 = wt.permute(2, 3, 1, 0).reshape(4 * C, C).contiguous()
+    out = ops.gemm(x.reshape(-1, C).to(DEV), w2.to(DEV), b.to(DEV), act=L.ACT_GELU_ERF, bias_mod=C,
+                   out_mode=L.OUT_DECONV2X, gw=g, out_shape=(n_img * 4 * g * g, C))
+    assert_close(out.reshape(n_img, 4 * g * g, C), ref, _tol(ref, dtype), 0, "deconv2x")
+
+
+# ------------------------------------------------------------------------------------------------ GEMV
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,N,K", [(1, 1000, 4096), (1, 1001, 4096), (2, 512, 11008), (4, 300, 1024), (1, 128, 64),
+                                   (3, 77, 2560)])
+def test_gemv_variants(dtype, B, N, K):
+    ops, L = _ops()
+    x, w = _rand((B, K), dtype, 11), _rand((N, K), dtype, 12, 0.03)
+    g, r = (1 + 0.1 * _rand((K,), torch.float32, 13)).to(dtype), _rand((B, N), dtype, 14)
+    ref = x.float() @ w.float().T
+    assert_close(ops.gemv(x.to(DEV), w.to(DEV)), ref, _tol(ref, dtype), 0, "gemv")
+    assert_close(ops.gemv(x.to(DEV), w.to(DEV), residual=r.to(DEV)), ref.to(dtype).float() + r.float(), _tol(ref, dtype, 2), 0, "gemv+res")
+    lo = ops.gemv(x.to(DEV), w.to(DEV), out_f32=True)
+    assert lo.dtype == torch.float32
+    assert_close(lo, ref, _tol(ref, dtype), 0, "gemv f32")
+    # fused RMSNorm prologue (LlamaRMSNorm rounding points)
+    xf = x.float()
+    xn = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(dtype)
+    xn = (g * xn)
+    refn = xn.float() @ w.float().T
+    assert_close(ops.gemv(x.to(DEV), w.to(DEV), norm_w=g.to(DEV), eps=1e-5), refn, _tol(refn, dtype), 0, "rmsnorm+gemv")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,N,K", [(1, 1024, 4096), (2, 333, 512)])
+def test_gemv_swiglu(dtype, B, N, K):
+    ops, L = _ops()
+    x, w = _rand((B, K), dtype, 15), _rand((2 * N, K), dtype, 16, 0.03)
+    gate = (x.float() @ w[:N].float().T).to(dtype)
+    up = (x.float() @ w[N:].float().T).to(dtype)
+    ref = (F.silu(gate.float()).to(dtype).float() * up.float())
+    assert_close(ops.gemv(x.to(DEV), w.to(DEV), swiglu=True), ref, _tol(ref, dtype), 0, "swiglu gemv")
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,cols", [(7, 1152), (3, 4608), (5, 64), (2, 72)])
+def test_layernorm_rmsnorm(dtype, rows, cols):
+    ops, L = _ops()
+    if dtype == torch.bfloat16 and cols % 8:
+        pytest.skip("cols % 8")
+    x = _rand((rows, cols), dtype, 17) + 0.3
+    w, b = (1 + 0.1 * _rand((cols,), torch.float32, 18)).to(dtype), _rand((cols,), dtype, 19, 0.1)
+    ref = F.layer_norm(x.float(), (cols,), w.float(), b.float(), 1e-6)
+    assert_close(ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6), ref, _tol(ref, dtype), 0, "layernorm")
+    assert_close(ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, act=L.ACT_GELU_ERF), F.gelu(ref.to(dtype).float()),
+                 _tol(ref, dtype), 0, "layernorm+gelu")
+    xf = x.float()
+    refr = w.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(dtype).float()
+    assert_close(ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-5), refr, _tol(refr, dtype), 0, "rmsnorm")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, causal, kv_len=None):
+    B, Tq, Hq, D = q.shape
+    Tk, Hkv = k.shape[1], k.shape[2]
+    qf, kf, vf = q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)
+    rep = Hq // Hkv
+    kf, vf = kf.repeat_interleave(rep, 1), vf.repeat_interleave(rep, 1)
+    s = qf @ kf.transpose(-1, -2) / math.sqrt(D)
+    mask = torch.ones((B, 1, Tq, Tk), dtype=torch.bool)
+    if causal:
+        mask &= (torch.arange(Tk)[None, :] <= torch.arange(Tq)[:, None] + (Tk - Tq))[None, None]
+    if kv_len is not None:
+        mask &= (torch.arange(Tk)[None, :] < kv_len[:, None])[:, None, None, :]
+    s = s.masked_fill(~mask, float("-inf"))
+    return (s.softmax(-1) @ vf).transpose(1, 2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,Tq,Tk,Hq,Hkv,D,causal", [
+    (2, 729, 729, 3, 3, 72, False),    # SigLIP geometry (head_dim 72 -> padded to 96)
+    (1, 259, 259, 8, 2, 128, True),    # Llama-3 GQA prefill
+    (1, 130, 130, 4, 4, 16, True),     # tiny config
+    (2, 65, 200, 4, 2, 64, True),      # Tq != Tk causal offset
+    (1, 64, 64, 2, 1, 32, False),
+])
+def test_attention(dtype, B, Tq, Tk, Hq, Hkv, D, causal):
+    ops, L = _ops()
+    q, k, v = _rand((B, Tq, Hq, D), dtype, 20), _rand((B, Tk, Hkv, D), dtype, 21), _rand((B, Tk, Hkv, D), dtype, 22)
+    ref = _attn_ref(q, k, v, causal)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal)
+    assert_close(out, ref, _tol(ref, dtype), 0, "attention")
+
+
+def test_attention_packed_qkv_and_kvlen():
+    """strided views (packed ViT qkv), per-row kv_len, and a softmax spike that forces the online rescale."""
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    B, T, H, D = 2, 150, 4, 72
+    qkv = _rand((B, T, 3, H, D), dtype, 23)
+    qkv[0, 140, 1, 2] *= 12.0  # one key far above the rest, late in the sequence (rule: force the rare branch)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    kv_len = torch.tensor([150, 97], dtype=torch.int32)
+    ref = _attn_ref(q, k, v, False, kv_len)
+    g = qkv.to(DEV)
+    out = ops.attention(g[:, :, 0], g[:, :, 1], g[:, :, 2], causal=False, kv_len=kv_len.to(DEV))
+    assert_close(out, ref, _tol(ref, dtype), 0, "attention packed + kv_len")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,Hq,Hkv,D,P", [(1, 32, 8, 128, 300), (2, 4, 2, 16, 0), (1, 8, 8, 64, 17), (1, 20, 20, 128, 700),
+                                          (3, 8, 1, 32, 129)])
+def test_rope_append_and_decode_attention(dtype, B, Hq, Hkv, D, P):
+    """prefill RoPE+append of P tokens, then one decode step; both against the oracle's rotary + softmax."""
+    from oracle import srgpt_oracle as so
+    ops, L = _ops()
+    max_pos = 1024
+    QW = (Hq + 2 * Hkv) * D
+    cfg = so.SrgptConfig(hidden=Hq * D, heads=Hq, kv_heads=Hkv, rope_theta=10000.0)
+    from spatialrgpt_amd.weights import rope_tables
+    from spatialrgpt_amd.config import SrgptConfig as PC
+    cos_t, sin_t = rope_tables(PC(hidden=Hq * D, heads=Hq, kv_heads=Hkv, rope_theta=10000.0), max_pos, dtype, DEV)
+    kc = torch.zeros((B, Hkv, max_pos, D), device=DEV, dtype=dtype)
+    vc = torch.zeros_like(kc)
+    allq = _rand((B, P + 1, QW), dtype, 24)
+
+    def split(x):
+        T = x.shape[1]
+        return (x[..., :Hq * D].reshape(B, T, Hq, D), x[..., Hq * D:(Hq + Hkv) * D].reshape(B, T, Hkv, D),
+                x[..., (Hq + Hkv) * D:].reshape(B, T, Hkv, D))
+
+    q_all, k_all, v_all = split(allq)
+    pos = torch.arange(P + 1)[None].expand(B, -1)
+    c, s = so.rope_cos_sin(cfg, pos, dtype)
+    q_rot, k_rot = so.apply_rope(q_all.transpose(1, 2), k_all.transpose(1, 2), c, s)  # [B,H,T,D]
+    if P > 0:
+        pre = allq[:, :P].contiguous().to(DEV)
+        ops.rope_kv_append(pre, kc, vc, cos_t, sin_t, B, P, Hq, Hkv, D)
+        assert_close(pre[..., :Hq * D].reshape(B, P, Hq, D), q_rot[:, :, :P].transpose(1, 2), _tol(q_rot, dtype, 0.5), 0, "rope q")
+        assert_close(kc[:, :, :P], k_rot[:, :, :P], _tol(k_rot, dtype, 0.5), 0, "rope k -> cache")
+        assert_close(vc[:, :, :P], v_all[:, :P].transpose(1, 2), 0, 0, "v -> cache")
+    # decode step for the token at position P
+    posd = torch.full((B,), P, dtype=torch.int32, device=DEV)
+    out = ops.decode_attention(allq[:, P].contiguous().to(DEV), kc, vc, posd, cos_t, sin_t, Hq, Hkv, D)
+    ref = _attn_ref(q_rot[:, :, P:P + 1].transpose(1, 2), k_rot.transpose(1, 2), v_all, True)
+    assert_close(out.reshape(B, 1, Hq, D), ref, _tol(ref, dtype), 0, "decode attention")
+    assert_close(kc[:, :, P], k_rot[:, :, P], _tol(k_rot, dtype, 0.5), 0, "decode appended k")
+    assert_close(vc[:, :, P], v_all[:, P], 0, 0, "decode appended v")
+
+
+# ------------------------------------------------------------------------------------------------ region extractor
+def test_region_pool_golden_kats():
+    """MaskPooling known-answer vectors minted from the reference module itself."""
+    ops, L = _ops()
+    z = load_kat()
+    for tag in ["rgb108", "depth27", "soft336_to_108", "soft336_to_96", "up56_to_108"]:
+        feat = torch.from_numpy(z[f"pool.{tag}.feat_q64"].astype(np.float32) / 64)
+        masks = torch.from_numpy(z[f"pool.{tag}.masks_q16"].astype(np.float32) / 16)
+        out = ops.region_pool(feat.to(DEV), masks.to(DEV))
+        assert_close(out, torch.from_numpy(z[f"pool.{tag}.out"]), 2e-6, 1e-5, tag)
+    feat = torch.from_numpy(z["pool.rgb108_bf16.feat_q64"].astype(np.float32) / 64).bfloat16()
+    masks = torch.from_numpy(z["pool.rgb108_bf16.masks_q16"].astype(np.float32) / 16).bfloat16()
+    ref = torch.from_numpy(z["pool.rgb108_bf16.out"].view(np.int16).copy()).view(torch.bfloat16)
+    out = ops.region_pool(feat.to(DEV), masks.to(DEV))
+    assert_close(out, ref, _tol(ref, torch.bfloat16, 0.5), 0, "bf16 KAT")
+    assert float(out[4].float().abs().max()) == 0.0  # empty mask -> exact zeros, no NaN
+    out_f32mask = ops.region_pool(feat.to(DEV), masks.float().to(DEV))  # mask.float() contract
+    assert torch.equal(out_f32mask, out)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,S,fw,C", [(8, 384, 108, 1152), (16, 336, 108, 256), (3, 384, 27, 1152), (17, 96, 24, 64)])
+def test_region_pool_true_shape_vs_oracle(dtype, M, S, fw, C):
+    from oracle import srgpt_oracle as so
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(30)
+    feat = _rand((fw * fw, C), dtype, 31)
+    masks = torch.zeros((M, S, S))
+    for m in range(M):
+        y0, x0 = int(torch.randint(0, S // 2, (1,), generator=g)), int(torch.randint(0, S // 2, (1,), generator=g))
+        h, w = int(torch.randint(S // 8, S // 2, (1,), generator=g)), int(torch.randint(S // 8, S // 2, (1,), generator=g))
+        masks[m, y0:y0 + h, x0:x0 + w] = 1
+    masks = masks.to(dtype)
+    ref = so.mask_pooling(feat[None], [masks])[0]
+    out = ops.region_pool(feat.to(DEV), masks.to(DEV))
+    assert_close(out, ref, _tol(ref, dtype), 0, "region_pool")
+    # linearity in the features (size-independent property): pool(2f) == 2 pool(f) exactly in binary fp
+    out2 = ops.region_pool((feat * 2).to(DEV), masks.to(DEV))
+    assert torch.equal(out2.float(), out.float() * 2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_avgpool_s2d_im2col(dtype):
+    ops, L = _ops()
+    for in_w, C in [(108, 64), (96, 32)]:
+        x = _rand((2, in_w * in_w, C), dtype, 32)
+        ref = F.adaptive_avg_pool2d(x.float().reshape(2, in_w, in_w, C).permute(0, 3, 1, 2), 27).flatten(2).transpose(1, 2)
+        assert_close(ops.avgpool(x.to(DEV), 2, in_w, 27), ref, _tol(ref, dtype), 0, f"avgpool {in_w}")
+    z = load_kat()
+    x = torch.from_numpy(z["s2d.in"]).to(dtype)
+    assert torch.equal(ops.s2d(x.to(DEV)).cpu(), torch.from_numpy(z["s2d.out"]).to(dtype))
+    x = _rand((1, 24 * 24, 16), dtype, 33)  # even grid: no padding
+    from oracle import srgpt_oracle as so
+    assert torch.equal(ops.s2d(x.to(DEV)).cpu(), so.flat_square(x.reshape(1, 24, 24, 16)).reshape(1, -1, 64))
+    img = _rand((2, 3, 56, 56), dtype, 34)
+    kp = 592
+    col = ops.im2col(img.to(DEV), 14, kp).cpu()
+    ref = F.unfold(img.float(), kernel_size=14, stride=14).transpose(1, 2).reshape(-1, 588).to(dtype)
+    assert torch.equal(col[:, :588], ref) and float(col[:, 588:].float().abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ token stream
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_embed_scatter_silu_argmax(dtype):
+    ops, L = _ops()
+    table = _rand((50, 64), dtype, 35)
+    ids = torch.tensor([3, 49, 0, 3, 7])
+    assert torch.equal(ops.embed_rows(table.to(DEV), ids.to(DEV)).cpu(), table[ids])
+    dst = torch.zeros((10, 64), dtype=dtype, device=DEV)
+    src = _rand((4, 64), dtype, 36)
+    ops.scatter_rows(src.to(DEV), torch.tensor([9, -1, 0, 4], dtype=torch.int32, device=DEV), dst,
+                     src_idx=torch.tensor([3, 2, 1, 0], dtype=torch.int32, device=DEV))
+    exp = torch.zeros((10, 64), dtype=dtype)
+    exp[9], exp[0], exp[4] = src[3], src[1], src[0]
+    assert torch.equal(dst.cpu(), exp)
+    gu = _rand((5, 2 * 96), dtype, 37)
+    ref = F.silu(gu[:, :96].float()).to(dtype).float() * gu[:, 96:].float()
+    assert_close(ops.silu_mul(gu.to(DEV)), ref, _tol(ref, dtype), 0, "silu_mul")
+    logits = _rand((3, 128258), torch.float32, 38)
+    logits[1, 77] = logits[1, 90000] = 50.0  # tie -> first index wins, like torch.argmax
+    logits[2, 128257] = 60.0
+    assert torch.equal(ops.argmax(logits.to(DEV)).cpu(), torch.tensor([int(logits[0].argmax()), 77, 128257]))

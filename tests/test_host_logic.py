@@ -1,0 +1,126 @@
+"""CPU: host-side logic of the product package (no kernels): tokenizer_image_token against the reference's own
+outputs (golden), mask preprocessing, config, sharding helpers, weight naming."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import GOLD
+
+
+class FakeTok:
+    bos_token_id = 1
+
+    def __call__(self, text):
+        class R:
+            pass
+
+        r = R()
+        r.input_ids = [1] + [3 + (sum(map(ord, wd)) % 90) for wd in text.split()]
+        return r
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [" ".join(str(int(i)) for i in row) for row in ids]
+
+
+def test_tokenizer_image_token_matches_reference():
+    from spatialrgpt_amd import tokenizer_image_token
+
+    cases = json.load(open(os.path.join(GOLD, "tokenizer_kat.json")))
+    assert len(cases) >= 5
+    for c in cases:
+        assert tokenizer_image_token(c["prompt"], FakeTok()) == c["ids"], c["prompt"]
+        assert tokenizer_image_token(c["prompt"], FakeTok(), lstrip=True) == c["ids_lstrip"], c["prompt"]
+    t = tokenizer_image_token("a <image> b", FakeTok(), return_tensors="pt")
+    assert t.dtype == torch.long and t.tolist().count(-200) == 1
+    with pytest.raises(ValueError):
+        tokenizer_image_token("a", FakeTok(), return_tensors="np")
+
+
+def test_keywords_stopping_criteria():
+    from spatialrgpt_amd import KeywordsStoppingCriteria
+
+    tok = FakeTok()
+    prompt = torch.zeros((1, 50), dtype=torch.long)
+    kw = "stop now"
+    crit = KeywordsStoppingCriteria([kw], tok, prompt)
+    kid = tok(kw).input_ids[1:]
+    assert crit(torch.tensor([[5, 6] + kid]), None) is True
+    assert crit(torch.tensor([[5, 6, 7, 8]]), None) is False
+
+
+def test_process_regions_nearest_and_processor():
+    from types import SimpleNamespace
+
+    from spatialrgpt_amd.mm_utils import SrgptImageProcessor, _nearest_resize, process_regions
+
+    m = np.zeros((100, 50), np.uint8)
+    m[10:60, 5:20] = 1
+    r = _nearest_resize(m, 384, 384)
+    assert r.shape == (384, 384) and set(np.unique(r)) == {0, 1}
+    assert r[int(10 * 3.84) + 1, int(5 * 7.68) + 1] == 1 and r[0, 0] == 0
+    proc = SrgptImageProcessor(size=384)
+    out = process_regions([m, m], proc, SimpleNamespace(image_aspect_ratio="resize", image_processor=proc))
+    assert out.shape == (2, 384, 384) and out.dtype == torch.float32
+    assert set(out.unique().tolist()) == {0.0, 1.0}
+
+
+def test_config_geometry():
+    from spatialrgpt_amd import SrgptConfig
+
+    c = SrgptConfig.vila15_8b()
+    assert c.head_dim == 128 and c.grid == 27 and c.vit_layers_run == 26
+    assert SrgptConfig.sheared_3b().head_dim == 128 and SrgptConfig.llama2_7b().kv_heads == 32
+    assert SrgptConfig.from_dict(c.to_dict()) == c
+
+
+def test_weight_shapes_cover_checkpoint_names():
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.weights import weight_shapes
+
+    from tests.util import load_tiny
+
+    cfgd, dtype, w, inp, ref = load_tiny("tiny_fp32.npz")
+    shapes = weight_shapes(SrgptConfig.from_dict(cfgd))
+    for k, s in shapes.items():
+        assert k in w and tuple(w[k].shape) == tuple(s), k
+    n = sum(int(np.prod(s)) for k, s in weight_shapes(SrgptConfig.vila15_8b()).items() if k.startswith("llm.") and "embed" not in k)
+    assert abs(n - 7.50e9) < 0.02e9  # 7.50 B streamed params per token
+
+
+def test_chunking_matches_reference_semantics():
+    from spatialrgpt_amd.dist import get_chunk, split_list
+
+    lst = list(range(10))
+    assert split_list(lst, 4) == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]]
+    assert get_chunk(lst, 4, 3) == [9] and get_chunk(lst, 8, 7) == []
+    assert sum((get_chunk(lst, 3, k) for k in range(3)), []) == lst
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    from spatialrgpt_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsrgpt_hip.so")
+    with pytest.raises(_lib.SrgptNativeError):
+        _lib.load()
+
+
+def test_no_cpu_fallback():
+    from spatialrgpt_amd import ops
+
+    with pytest.raises(RuntimeError):
+        ops.rmsnorm(torch.zeros(2, 8), torch.ones(8), 1e-5)
+
+
+def test_product_does_not_import_oracle():
+    import re
+
+    root = os.path.join(os.path.dirname(GOLD), "..", "spatialrgpt_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f

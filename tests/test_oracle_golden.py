@@ -1,0 +1,75 @@
+"""CPU: pins oracle/srgpt_oracle.py against the golden vectors minted from the REAL reference
+(oracle/make_golden.py).  If this fails the oracle is not a faithful restatement and no GPU parity claim holds."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import srgpt_oracle as so
+from tests.util import assert_close, load_kat, load_tiny
+
+
+def _cfg(d):
+    names = so.SrgptConfig.__dataclass_fields__
+    return so.SrgptConfig(**{k: v for k, v in d.items() if k in names})
+
+
+@pytest.mark.parametrize("name,atol,rtol", [("tiny_fp32.npz", 1e-5, 1e-5), ("tiny_bf16.npz", 0.0, 2e-2)])
+def test_oracle_reproduces_reference_stages(name, atol, rtol):
+    cfgd, dtype, w, inp, ref = load_tiny(name)
+    cfg = _cfg(cfgd)
+    ids, st = so.generate(w, cfg, inp["input_ids"], inp["images"], inp["depths"], inp["masks"], max_new_tokens=12,
+                          return_stages=True, model_dtype=dtype)
+    for k in ("tower_features", "depth_features", "lres", "image_features", "inputs_embeds"):
+        assert_close(st[k], ref[k], atol, rtol, k)
+    idx = ref["hres_rows_idx"].long()
+    assert_close(st["hres"][:, idx], ref["hres_rows"], atol, rtol, "hres rows")
+    assert_close(torch.stack(st["mask_embeds"]), ref["mask_embeds"], atol, rtol, "mask_embeds")
+    assert_close(torch.stack(st["depth_embeds"]), ref["depth_embeds"], atol, rtol, "depth_embeds")
+    assert_close(st["prefill_logits"], ref["prefill_logits"], 1e-4 if dtype == torch.float32 else 2e-2, rtol, "prefill_logits")
+    if dtype == torch.float32:
+        assert torch.equal(ids, ref["new_ids"]), (ids, ref["new_ids"])  # greedy ids bit-exact
+    assert st["inputs_embeds"].shape[1] == inp["input_ids"].shape[1] - 1 + 196  # T = P - 1 + 196
+
+
+def test_oracle_region_kats():
+    z = load_kat()
+    for tag, fw in [("rgb108", 108), ("depth27", 27), ("soft336_to_108", 108), ("soft336_to_96", 96), ("up56_to_108", 108)]:
+        feat = torch.from_numpy(z[f"pool.{tag}.feat_q64"].astype(np.float32) / 64)
+        masks = torch.from_numpy(z[f"pool.{tag}.masks_q16"].astype(np.float32) / 16)
+        out = so.mask_pooling(feat[None], [masks])[0]
+        assert_close(out, torch.from_numpy(z[f"pool.{tag}.out"]), 1e-6, 0, tag)
+    # closed forms: all-ones mask = mean of features; empty mask = zeros (denorm = 1e-8)
+    feat = torch.from_numpy(z["pool.rgb108.feat_q64"].astype(np.float32) / 64)
+    out = torch.from_numpy(z["pool.rgb108.out"])
+    assert_close(out[3], feat.mean(0), 1e-5, 0, "all-ones mask == feature mean")
+    assert float(out[4].abs().max()) == 0.0
+
+
+def test_oracle_s2d_and_refinement():
+    z = load_kat()
+    x = torch.from_numpy(z["s2d.in"])
+    n, L, c = x.shape
+    assert torch.equal(so.flat_square(x.reshape(n, 27, 27, c)).reshape(n, -1, 4 * c), torch.from_numpy(z["s2d.out"]))
+    for tag in ("27", "24"):
+        w = {so.RE + "feature_refinement_module." + k[len(f"refine{tag}.w."):]: torch.from_numpy(z[k])
+             for k in z.files if k.startswith(f"refine{tag}.w.")}
+        h, l = so.feature_refinement(w, torch.from_numpy(z[f"refine{tag}.in"]))
+        idx = torch.from_numpy(z[f"refine{tag}.hres_rows_idx"]).long()
+        assert_close(h[:, idx], torch.from_numpy(z[f"refine{tag}.hres_rows"]), 1e-5, 0, "hres")
+        assert_close(l, torch.from_numpy(z[f"refine{tag}.lres"]), 1e-5, 0, "lres")
+
+
+def test_oracle_kv_cache_equals_full_forward():
+    """size-independent property: incremental decode == teacher-forced full forward."""
+    cfgd, dtype, w, inp, ref = load_tiny("tiny_fp32.npz")
+    cfg = _cfg(cfgd)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((1, 9, cfg.hidden), generator=g)
+    pos = torch.arange(9)[None]
+    full = so.llama_forward(w, cfg, x, pos, so.KVCache(cfg.layers))
+    kv = so.KVCache(cfg.layers)
+    a = so.llama_forward(w, cfg, x[:, :6], pos[:, :6], kv)
+    outs = [a]
+    for t in range(6, 9):
+        outs.append(so.llama_forward(w, cfg, x[:, t:t + 1], pos[:, t:t + 1], kv))
+    assert_close(torch.cat(outs, 1), full, 2e-5, 0, "incremental vs full")
