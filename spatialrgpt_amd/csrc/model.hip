@@ -103,7 +103,8 @@ extern "C" int64_t srgpt_vit_ws_bytes(const srgpt_vit_weights* w, int n_img) {
 extern "C" int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images, void* out, void* ws, int n_img,
                                  srgpt_stream_t stream) {
   SRGPT_CHECK(w && images && out && ws && n_img > 0, SRGPT_ERR_ARG, "srgpt_vit_forward: bad args");
-  SRGPT_CHECK(w->hidden % w->heads == 0 && w->image_size % w->patch == 0, SRGPT_ERR_ARG, "srgpt_vit_forward: bad config");
+  // image_size need not be a multiple of patch: a 'valid' conv drops the remainder (384 px / 14 -> 27 patches)
+  SRGPT_CHECK(w->hidden % w->heads == 0 && w->image_size >= w->patch, SRGPT_ERR_ARG, "srgpt_vit_forward: bad config");
   const int dt = w->dtype, C = w->hidden, I = w->inter, H = w->heads, hd = C / H;
   const int g = w->image_size / w->patch, L = g * g, rows = n_img * L;
   const VitWs v = carve_vit(w, n_img, ws);

@@ -84,6 +84,8 @@ class SrgptEngine:
         self._state: Optional[DecodeState] = None
         self._vit_ws: Optional[torch.Tensor] = None
         self.use_graph = True
+        # the decode loop runs on its own stream: hipGraph capture is illegal on the legacy default stream
+        self.stream = torch.cuda.Stream(device=self.device)
 
     # ------------------------------------------------------------------ A1
     def vit(self, images: torch.Tensor) -> torch.Tensor:
@@ -335,8 +337,25 @@ class SrgptEngine:
         return st, al, hs
 
     def greedy_decode(self, st: DecodeState, max_new_tokens: int, eos_token_id=None, pad_token_id=None,
-                      stopping_criteria=None, prompt_ids=None, check_every: int = 8) -> torch.Tensor:
+                      stopping_criteria=None, check_every: int = 8) -> torch.Tensor:
         """HF greedy loop semantics (new ids only, finished rows padded), device-side steps via hipGraph."""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            n_keep, eos = self._decode_loop(st, max_new_tokens, eos_token_id, stopping_criteria, check_every)
+        cur.wait_stream(self.stream)
+        out = st.out_ids[:, :n_keep].clone()
+        if eos:
+            # rows that finished early are padded with pad_token_id (HF behaviour)
+            pad = pad_token_id if pad_token_id is not None else next(iter(eos))
+            ids = out.to("cpu")
+            for b in range(st.batch):
+                hit = [i for i in range(n_keep) if int(ids[b, i]) in eos]
+                if hit and hit[0] + 1 < n_keep:
+                    out[b, hit[0] + 1:] = pad
+        return out
+
+    def _decode_loop(self, st: DecodeState, max_new_tokens: int, eos_token_id, stopping_criteria, check_every: int):
         lib = L.load()
         stream = ops._stream()
         L.check(lib.srgpt_llm_sample_first(C.byref(self.w.llm), C.byref(st.c), stream))
@@ -382,13 +401,4 @@ class SrgptEngine:
             done_step += n
         if stop is not None:
             n_keep = stop
-        out = st.out_ids[:, :n_keep].clone()
-        if eos:
-            # rows that finished early are padded with pad_token_id (HF behaviour)
-            pad = pad_token_id if pad_token_id is not None else next(iter(eos))
-            ids = out.to("cpu")
-            for b in range(B):
-                hit = [i for i in range(n_keep) if int(ids[b, i]) in eos]
-                if hit and hit[0] + 1 < n_keep:
-                    out[b, hit[0] + 1:] = pad
-        return out
+        return n_keep, eos
