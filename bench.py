@@ -93,7 +93,9 @@ def cpu_baseline(cfg, sd_cpu, regions, prompt_len, n_llm, n_vit):
     d = {k: v for k, v in cfg.to_dict().items() if k in names}
     d.update(layers=n_llm, vit_layers=n_vit + 1)  # select_layer=-2 -> runs n_vit layers
     ocfg = so.SrgptConfig(**d)
-    torch.set_num_threads(os.cpu_count() or 1)
+    # thread count: probed on the 256-core bench host (scripts/cpu_probe.py) -- torch's CPU bf16 path is fastest
+    # at 16 threads (22.9 ms / 2-layer decode step) and collapses beyond 64 (5.1 s at 256 threads)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     ids, images, depths, masks = so.synth_inputs(ocfg, batch=1, regions=regions, prompt_len=prompt_len, seed=1, dtype=torch.bfloat16)
     t = {}
     with torch.no_grad():

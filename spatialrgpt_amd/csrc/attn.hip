@@ -257,6 +257,8 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   constexpr int LPK = D / VEC;   // lanes per key
   constexpr int KPW = 64 / LPK;  // keys per wave-instruction
   constexpr int HALF = D / 2;
+  constexpr int STRIDE = 4 * KPW;  // keys per block iteration
+  constexpr int PF = 2;            // key iterations whose K/V rows are fetched up front (covers T <= 16*2*STRIDE)
   __shared__ float qs[G][D];
   __shared__ float knew[D], vnew[D];
   __shared__ float sc[G][DEC_CHUNK_MAX];
@@ -270,6 +272,21 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   const int chunk = (total + nsplit - 1) / nsplit;
   const int kbeg = split * chunk, kend = min(kbeg + chunk, total);
   const T* row = qkv + (size_t)b * (Hq + 2 * Hkv) * D;
+  T* kc = kcache + ((size_t)b * Hkv + hk) * (size_t)max_pos * D;
+  T* vc = vcache + ((size_t)b * Hkv + hk) * (size_t)max_pos * D;
+  const int sub = lane / LPK, dl = (lane % LPK) * VEC;
+  const int key0 = kbeg + wave * KPW + sub;
+
+  // ---- all cache rows of the first PF iterations go out before anything depends on q: one memory latency ----
+  Vec16<T> kreg[PF], vreg[PF];
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    const int key = key0 + j * STRIDE;
+    if (key < kend && key != P) {
+      kreg[j] = *reinterpret_cast<const Vec16<T>*>(kc + (size_t)key * D + dl);
+      vreg[j] = *reinterpret_cast<const Vec16<T>*>(vc + (size_t)key * D + dl);
+    }
+  }
 
   // ---- rotate q (G heads) and the new k; stage v ----
   for (int w = tid; w < (G + 1) * HALF; w += 256) {
@@ -289,8 +306,6 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   }
   for (int d = tid; d < D; d += 256) vnew[d] = to_f(row[(size_t)(Hq + Hkv + hk) * D + d]);
   __syncthreads();
-  T* kc = kcache + ((size_t)b * Hkv + hk) * (size_t)max_pos * D;
-  T* vc = vcache + ((size_t)b * Hkv + hk) * (size_t)max_pos * D;
   if (split == 0) {  // exactly one block per (b, hk) appends; nobody reads position P from the cache
     for (int d = tid; d < D; d += 256) {
       kc[(size_t)P * D + d] = from_f<T>(knew[d]);
@@ -299,27 +314,16 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   }
 
   float* wbase = ws + (((size_t)b * Hkv + hk) * G) * (size_t)DEC_SPLIT_MAX * (D + 2);
-  if (kbeg >= kend) {  // empty split
-    if (tid < G) {
-      float* wp = wbase + ((size_t)tid * DEC_SPLIT_MAX + split) * (D + 2);
-      wp[D] = -INFINITY;
-      wp[D + 1] = 0.f;
+  if (kbeg >= kend) {  // empty split: neutral partial (zeros, m = -inf, l = 0)
+    for (int w = tid; w < G * (D + 2); w += 256) {
+      const int gq = w / (D + 2), d = w - gq * (D + 2);
+      wbase[((size_t)gq * DEC_SPLIT_MAX + split) * (D + 2) + d] = (d == D) ? -INFINITY : 0.f;
     }
     return;
   }
 
-  const int sub = lane / LPK, dl = (lane % LPK) * VEC;
   // ---- pass 1: scores ----
-  for (int key = kbeg + wave * KPW + sub; key < kend; key += 4 * KPW) {
-    float kv[VEC];
-    if (key == P) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) kv[i] = knew[dl + i];
-    } else {
-      const Vec16<T> t = *reinterpret_cast<const Vec16<T>*>(kc + (size_t)key * D + dl);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) kv[i] = t.get(i);
-    }
+  auto score = [&](int key, const float* kv) {
 #pragma unroll
     for (int gq = 0; gq < G; ++gq) {
       float part = 0.f;
@@ -329,6 +333,28 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
       for (int off = LPK >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off);
       if ((lane % LPK) == 0) sc[gq][key - kbeg] = part * scale;
     }
+  };
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    const int key = key0 + j * STRIDE;
+    if (key < kend) {
+      float kv[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) kv[i] = (key == P) ? knew[dl + i] : kreg[j].get(i);
+      score(key, kv);
+    }
+  }
+  for (int key = key0 + PF * STRIDE; key < kend; key += STRIDE) {
+    float kv[VEC];
+    if (key == P) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) kv[i] = knew[dl + i];
+    } else {
+      const Vec16<T> t = *reinterpret_cast<const Vec16<T>*>(kc + (size_t)key * D + dl);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) kv[i] = t.get(i);
+    }
+    score(key, kv);
   }
   __syncthreads();
   // ---- softmax statistics of the chunk, one wave per q head ----
@@ -356,7 +382,25 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   for (int gq = 0; gq < G; ++gq)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[gq][i] = 0.f;
-  for (int key = kbeg + wave * KPW + sub; key < kend; key += 4 * KPW) {
+  auto accum = [&](int key, const float* vv) {
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+      const float pg = sc[gq][key - kbeg];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[gq][i] = fmaf(pg, vv[i], acc[gq][i]);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    const int key = key0 + j * STRIDE;
+    if (key < kend) {
+      float vv[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) vv[i] = (key == P) ? vnew[dl + i] : vreg[j].get(i);
+      accum(key, vv);
+    }
+  }
+  for (int key = key0 + PF * STRIDE; key < kend; key += STRIDE) {
     float vv[VEC];
     if (key == P) {
 #pragma unroll
@@ -366,12 +410,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
 #pragma unroll
       for (int i = 0; i < VEC; ++i) vv[i] = t.get(i);
     }
-#pragma unroll
-    for (int gq = 0; gq < G; ++gq) {
-      const float pg = sc[gq][key - kbeg];
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[gq][i] = fmaf(pg, vv[i], acc[gq][i]);
-    }
+    accum(key, vv);
   }
 #pragma unroll
   for (int gq = 0; gq < G; ++gq)
@@ -394,26 +433,37 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   }
 }
 
+// merge the per-split partials of one (head, batch row): every load is independent of the others
 template <typename T>
-__global__ __launch_bounds__(64) void decode_combine_kernel(const float* __restrict__ ws, T* __restrict__ out, int Hq,
-                                                            int D, int nsplit) {
-  const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(128) void decode_combine_kernel(const float* __restrict__ ws, T* __restrict__ out, int Hq,
+                                                             int D, int nsplit) {
+  __shared__ float wgt[DEC_SPLIT_MAX];
+  __shared__ float inv_s;
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const float* wp = ws + ((size_t)b * Hq + h) * (size_t)DEC_SPLIT_MAX * (D + 2);
-  float M = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, wp[(size_t)s * (D + 2) + D]);
-  float den = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float ms = wp[(size_t)s * (D + 2) + D];
-    if (ms > -INFINITY) den += __expf(ms - M) * wp[(size_t)s * (D + 2) + D + 1];
+  if (tid < 64) {  // wave 0: one split per lane (nsplit <= 64)
+    const bool ok = tid < nsplit;
+    const float ms = ok ? wp[(size_t)tid * (D + 2) + D] : -INFINITY;
+    const float ls = ok ? wp[(size_t)tid * (D + 2) + D + 1] : 0.f;
+    const float M = wave_max(ms);
+    const float w = (ms > -INFINITY) ? __expf(ms - M) : 0.f;
+    const float den = wave_sum(w * ls);
+    wgt[tid] = w;
+    if (tid == 0) inv_s = den > 0.f ? 1.f / den : 0.f;
   }
-  const float inv = den > 0.f ? 1.f / den : 0.f;
-  for (int d = lane; d < D; d += 64) {
+  __syncthreads();
+  for (int d = tid; d < D; d += 128) {
     float num = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-      const float ms = wp[(size_t)s * (D + 2) + D];
-      if (ms > -INFINITY) num += __expf(ms - M) * wp[(size_t)s * (D + 2) + d];
+    int s = 0;
+    for (; s + 8 <= nsplit; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = wp[(size_t)(s + j) * (D + 2) + d];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) num = fmaf(wgt[s + j], v[j], num);
     }
-    out[((size_t)b * Hq + h) * D + d] = from_f<T>(num * inv);
+    for (; s < nsplit; ++s) num = fmaf(wgt[s], wp[(size_t)s * (D + 2) + d], num);
+    out[((size_t)b * Hq + h) * D + d] = from_f<T>(num * inv_s);
   }
 }
 
@@ -456,7 +506,7 @@ int launch_decode(const void* qkv, void* kc, void* vc, const int* pos, const voi
   }
   if (rc) return rc;
   SRGPT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(decode_combine_kernel<T>, dim3(Hq, B), dim3(64), 0, s, ws, (T*)out, Hq, D, nsplit);
+  hipLaunchKernelGGL(decode_combine_kernel<T>, dim3(Hq, B), dim3(128), 0, s, ws, (T*)out, Hq, D, nsplit);
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }

@@ -1,19 +1,22 @@
 // Decode-path weight-streaming GEMV (batch <= 4 rows): out[b, n] = W[n, :] . x[b, :]   (HBM-bound)
 //
-// Roofline: every weight byte is read exactly once per token (non-temporal 16-byte loads, one
-// 1 KiB wave-instruction per row chunk); x lives in LDS; fp32 accumulate on the VALU (24 lane-ops
-// per 16 B -- 12 % of VALU issue at HBM rate, so no MFMA reshaping).  Each wave owns pairs of weight
-// rows and keeps 8 (in flight) + 8 (being consumed) row chunks in registers, flattened across row
-// pairs so the load stream never drains; the first batch is issued BEFORE the x / RMSNorm prologue so
-// HBM is busy while every block stages x.  Grid = 2 blocks per CU, grid-strided over row pairs.
+// Roofline: every weight byte is read exactly once per token (non-temporal 16-byte loads, one 1 KiB
+// wave-instruction per row chunk); x lives in LDS; fp32 accumulate on the VALU (24 lane-ops per 16 B --
+// ~12 % of VALU issue at HBM rate, so no MFMA reshaping).
 //
-// Fusions (see include/srgpt.h): RMSNorm prologue (LlamaRMSNorm), SwiGLU epilogue, residual add,
-// fp32 logits.  Rounding points mirror PyTorch's bf16 materialisation of each intermediate.
+// Work decomposition: a unit = one output row (plain) or one (gate row, up row) pair (SwiGLU); each wave
+// owns units grid-strided, each unit's K range is cut into batches of 8 row chunks (8 KiB per wave).
+// The (unit, batch) sequence of a wave is flattened and software-pipelined THREE batches deep
+// (cur / n1 / n2 registers): 16 chunk loads stay in flight per wave while 8 are consumed, the stream
+// never drains at row boundaries, and the first two batches are issued BEFORE the activation / RMSNorm
+// prologue, so short matrices (o_proj: 2 batches per wave) pay a single memory latency.
+// Grid = 2 blocks per CU (8 waves/CU, ~128 KiB in flight per CU).
+//
+// Fusions (include/srgpt.h): RMSNorm prologue (LlamaRMSNorm), SwiGLU epilogue, residual add, fp32 logits.
+// Rounding points mirror PyTorch's bf16 materialisation of each intermediate.
 #include "common.h"
 
 namespace {
-
-constexpr int U = 4;  // K-chunks per row per batch (loads in flight = 2 rows * U)
 
 template <typename T>
 struct WChunk;  // 16 bytes of weights -> VEC floats
@@ -43,40 +46,50 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
                                                       const T* __restrict__ residual, void* __restrict__ out, int N,
                                                       int K, int out_f32) {
   constexpr int VEC = WChunk<T>::VEC;
+  constexpr int R = SWIGLU ? 2 : 1;  // weight rows per unit
+  constexpr int U = 8 / R;           // K-chunks per row per batch (8 loads per batch)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);  // [B][K]
   __shared__ float red[16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nchunks = K / VEC;                      // 16-byte chunks per row
-  const int nit = (nchunks + 63) >> 6;              // chunk iterations per row (64 lanes each)
-  const int NB = (nit + U - 1) / U;                 // load batches per row pair
-  const int units = SWIGLU ? N : (N + 1) >> 1;      // work units: (gate_n, up_n) or (row 2u, row 2u+1)
+  const int nchunks = K / VEC;          // 16-byte chunks per row
+  const int nit = (nchunks + 63) >> 6;  // chunk iterations per row (64 lanes each)
+  const int NB = (nit + U - 1) / U;     // batches per unit
+  const int units = N;
   const int wstride = gridDim.x * 4;
-  int unit = blockIdx.x * 4 + wave;
 
-  auto rowA = [&](int u) { return SWIGLU ? u : 2 * u; };
-  auto rowB = [&](int u) { return SWIGLU ? N + u : min(2 * u + 1, N - 1); };
-
-  u32x4 nxt[2][U], cur[2][U];
-  auto load = [&](int u, int b) {
-    const u32x4* pa = reinterpret_cast<const u32x4*>(W + (size_t)rowA(u) * K);
-    const u32x4* pb = reinterpret_cast<const u32x4*>(W + (size_t)rowB(u) * K);
+  struct Cursor {
+    int unit, b;
+  };
+  auto advance = [&](Cursor c) {
+    Cursor n{c.unit, c.b + 1};
+    if (n.b == NB) {
+      n.b = 0;
+      n.unit += wstride;
+    }
+    return n;
+  };
+  auto load = [&](Cursor c, u32x4 (&dst)[R][U]) {
+    if (c.unit < units) {
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const int c = (b * U + j) * 64 + lane;
-      if (c < nchunks) {
-        nxt[0][j] = __builtin_nontemporal_load(pa + c);
-        nxt[1][j] = __builtin_nontemporal_load(pb + c);
-      } else {
-        nxt[0][j] = u32x4{0, 0, 0, 0};
-        nxt[1][j] = u32x4{0, 0, 0, 0};
+      for (int r = 0; r < R; ++r) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(c.unit + r * N) * K);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const int ch = (c.b * U + j) * 64 + lane;
+          dst[r][j] = (ch < nchunks) ? __builtin_nontemporal_load(p + ch) : u32x4{0, 0, 0, 0};
+        }
       }
     }
   };
 
-  // first weight batch goes out before the activation prologue
-  if (unit < units) load(unit, 0);
+  u32x4 cur[R][U], n1[R][U], n2[R][U];
+  Cursor c0{(int)blockIdx.x * 4 + wave, 0};
+  Cursor c1 = advance(c0), c2 = advance(c1);
+  // two weight batches go out before the activation prologue
+  load(c0, n1);
+  load(c1, n2);
 
   // ---- prologue: stage x (and RMSNorm it) into LDS
   {
@@ -117,77 +130,71 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
     __syncthreads();
   }
 
-  float acc[2][B];
+  float acc[R][B];
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
 
-  int bidx = 0;
-  while (unit < units) {
+  while (c0.unit < units) {
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-      cur[0][j] = nxt[0][j];
-      cur[1][j] = nxt[1][j];
-    }
-    int nunit = unit, nb = bidx + 1;
-    if (nb == NB) {
-      nb = 0;
-      nunit += wstride;
-    }
-    if (nunit < units) load(nunit, nb);
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        cur[r][j] = n1[r][j];
+        n1[r][j] = n2[r][j];
+      }
+    const Cursor c3 = advance(c2);
+    load(c2, n2);  // third batch ahead of the one being consumed
 
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      const int c = (bidx * U + j) * 64 + lane;
-      if (c < nchunks) {
-        float wa[VEC], wb[VEC];
-        WChunk<T>::cvt(cur[0][j], wa);
-        WChunk<T>::cvt(cur[1][j], wb);
+      const int ch = (c0.b * U + j) * 64 + lane;
+      if (ch < nchunks) {
+        float wf[R][VEC];
+#pragma unroll
+        for (int r = 0; r < R; ++r) WChunk<T>::cvt(cur[r][j], wf[r]);
 #pragma unroll
         for (int b = 0; b < B; ++b) {
-          const Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(xs + (size_t)b * K + (size_t)c * VEC);
+          const Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(xs + (size_t)b * K + (size_t)ch * VEC);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
             const float xf = xv.get(i);
-            acc[0][b] = fmaf(wa[i], xf, acc[0][b]);
-            acc[1][b] = fmaf(wb[i], xf, acc[1][b]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][b] = fmaf(wf[r][i], xf, acc[r][b]);
           }
         }
       }
     }
 
-    if (bidx == NB - 1) {
+    if (c0.b == NB - 1) {
+      const int n = c0.unit;
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        const float a0 = wave_sum(acc[0][b]);
-        const float a1 = wave_sum(acc[1][b]);
-        acc[0][b] = 0.f;
-        acc[1][b] = 0.f;
+        float a[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          a[r] = wave_sum(acc[r][b]);
+          acc[r][b] = 0.f;
+        }
         if (lane == 0) {
           if (SWIGLU) {
-            const float g = rnd<T>(a0), u = rnd<T>(a1);
-            const float v = rnd<T>(rnd<T>(silu(g)) * u);
-            reinterpret_cast<T*>(out)[(size_t)b * N + unit] = from_f<T>(v);
+            const float g = rnd<T>(a[0]), u = rnd<T>(a[R - 1]);
+            reinterpret_cast<T*>(out)[(size_t)b * N + n] = from_f<T>(rnd<T>(silu(g)) * u);
           } else {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-              const int n = 2 * unit + r;
-              if (n < N) {
-                float v = rnd<T>(r == 0 ? a0 : a1);
-                if (residual) v = rnd<T>(to_f(residual[(size_t)b * N + n]) + v);
-                if (out_f32)
-                  reinterpret_cast<float*>(out)[(size_t)b * N + n] = v;
-                else
-                  reinterpret_cast<T*>(out)[(size_t)b * N + n] = from_f<T>(v);
-              }
-            }
+            float v = rnd<T>(a[0]);
+            if (residual) v = rnd<T>(to_f(residual[(size_t)b * N + n]) + v);
+            if (out_f32)
+              reinterpret_cast<float*>(out)[(size_t)b * N + n] = v;
+            else
+              reinterpret_cast<T*>(out)[(size_t)b * N + n] = from_f<T>(v);
           }
         }
       }
     }
-    unit = nunit;
-    bidx = nb;
+    c0 = c1;
+    c1 = c2;
+    c2 = c3;
   }
 }
 
@@ -196,20 +203,27 @@ int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, con
                 int K, int swiglu, int out_f32, hipStream_t s) {
   const size_t lds = (size_t)B * K * sizeof(T);
   SRGPT_CHECK(lds <= 150 * 1024, SRGPT_ERR_UNSUPPORTED, "srgpt_gemv: batch*K too large for LDS (%zu bytes)", lds);
-  const int units = swiglu ? N : (N + 1) / 2;
   const int cus = srgpt_device_cus();
   const int per_cu = lds > 70 * 1024 ? 1 : 2;
-  int grid = (units + 3) / 4;
+  int grid = (N + 3) / 4;
   if (grid > cus * per_cu) grid = cus * per_cu;
   if (grid < 1) grid = 1;
   if (swiglu) {
     auto kfn = gemv_kernel<T, B, true>;
-    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr_set = true;
+    }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, (const T*)x, (const T*)W, (const T*)norm_w, eps,
                        (const T*)residual, out, N, K, out_f32);
   } else {
     auto kfn = gemv_kernel<T, B, false>;
-    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr_set = true;
+    }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, (const T*)x, (const T*)W, (const T*)norm_w, eps,
                        (const T*)residual, out, N, K, out_f32);
   }
