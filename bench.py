@@ -240,9 +240,13 @@ def main():
         torch.cuda.synchronize()
         dec_ms = e0.elapsed_time(e1) / G
         wbytes = eng.w.llm_weight_bytes()
+        traffic = None  # HBM bytes per launch from the PMC pass (separate rocprofv3 --pmc run, 2x FETCH_SIZE correction)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")
+        if args.model == "vila15_8b" and os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
         roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16,1,swiglu> (decode gate/up projection, 54% of streamed bytes)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5),
+                "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5),
                 "how": "hip events around each launch on the launch stream, 3 sweeps over the 32 layers' matrices (cold in L3)",
                 "decode_ms_per_token": round(dec_ms, 4), "decode_weight_bytes_per_token": wbytes,
                 "decode_hbm_gbs_whole_step": round(wbytes / (dec_ms * 1e-3) / 1e9, 1),
