@@ -433,18 +433,27 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   }
 }
 
-// merge the per-split partials of one (head, batch row): every load is independent of the others
+// merge the per-split partials of one (head, batch row).  All loads (the first 16 splits' O rows and the
+// per-split statistics) are issued before anything depends on them: one memory latency for the whole kernel.
 template <typename T>
 __global__ __launch_bounds__(128) void decode_combine_kernel(const float* __restrict__ ws, T* __restrict__ out, int Hq,
                                                              int D, int nsplit) {
+  constexpr int PRE = 16;
   __shared__ float wgt[DEC_SPLIT_MAX];
   __shared__ float inv_s;
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const float* wp = ws + ((size_t)b * Hq + h) * (size_t)DEC_SPLIT_MAX * (D + 2);
+  const int d0 = min(tid, D - 1);
+  float v[PRE];
+#pragma unroll
+  for (int j = 0; j < PRE; ++j) v[j] = wp[(size_t)min(j, nsplit - 1) * (D + 2) + d0];
   if (tid < 64) {  // wave 0: one split per lane (nsplit <= 64)
+    const int sidx = min(tid, nsplit - 1);
+    const float ms_raw = wp[(size_t)sidx * (D + 2) + D];
+    const float ls_raw = wp[(size_t)sidx * (D + 2) + D + 1];
     const bool ok = tid < nsplit;
-    const float ms = ok ? wp[(size_t)tid * (D + 2) + D] : -INFINITY;
-    const float ls = ok ? wp[(size_t)tid * (D + 2) + D + 1] : 0.f;
+    const float ms = ok ? ms_raw : -INFINITY;
+    const float ls = ok ? ls_raw : 0.f;
     const float M = wave_max(ms);
     const float w = (ms > -INFINITY) ? __expf(ms - M) : 0.f;
     const float den = wave_sum(w * ls);
@@ -452,17 +461,17 @@ __global__ __launch_bounds__(128) void decode_combine_kernel(const float* __rest
     if (tid == 0) inv_s = den > 0.f ? 1.f / den : 0.f;
   }
   __syncthreads();
-  for (int d = tid; d < D; d += 128) {
+  if (tid < D) {
     float num = 0.f;
-    int s = 0;
-    for (; s + 8 <= nsplit; s += 8) {
-      float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = wp[(size_t)(s + j) * (D + 2) + d];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) num = fmaf(wgt[s + j], v[j], num);
-    }
-    for (; s < nsplit; ++s) num = fmaf(wgt[s], wp[(size_t)s * (D + 2) + d], num);
+    for (int j = 0; j < PRE; ++j)
+      if (j < nsplit) num = fmaf(wgt[j], v[j], num);
+    for (int s = PRE; s < nsplit; ++s) num = fmaf(wgt[s], wp[(size_t)s * (D + 2) + tid], num);
+    out[((size_t)b * Hq + h) * D + tid] = from_f<T>(num * inv_s);
+  }
+  for (int d = tid + 128; d < D; d += 128) {  // head_dim > 128
+    float num = 0.f;
+    for (int s = 0; s < nsplit; ++s) num = fmaf(wgt[s], wp[(size_t)s * (D + 2) + d], num);
     out[((size_t)b * Hq + h) * D + d] = from_f<T>(num * inv_s);
   }
 }

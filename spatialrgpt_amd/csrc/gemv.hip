@@ -14,6 +14,8 @@
 //
 // Fusions (include/srgpt.h): RMSNorm prologue (LlamaRMSNorm), SwiGLU epilogue, residual add, fp32 logits.
 // Rounding points mirror PyTorch's bf16 materialisation of each intermediate.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -40,7 +42,7 @@ struct WChunk<float> {
   }
 };
 
-template <typename T, int B, bool SWIGLU>
+template <typename T, int B, bool SWIGLU, int NX>
 __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, const T* __restrict__ W,
                                                       const T* __restrict__ norm_w, float norm_eps,
                                                       const T* __restrict__ residual, void* __restrict__ out, int N,
@@ -70,16 +72,17 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
     }
     return n;
   };
+  // loads are UNCONDITIONAL (indices clamped, surplus data discarded by the consumer): straight-line code lets
+  // the compiler emit counted s_waitcnt vmcnt(N) instead of draining the queue at every use
   auto load = [&](Cursor c, u32x4 (&dst)[R][U]) {
-    if (c.unit < units) {
+    const int u = min(c.unit, units - 1);
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(c.unit + r * N) * K);
+    for (int r = 0; r < R; ++r) {
+      const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(u + r * N) * K);
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-          const int ch = (c.b * U + j) * 64 + lane;
-          dst[r][j] = (ch < nchunks) ? __builtin_nontemporal_load(p + ch) : u32x4{0, 0, 0, 0};
-        }
+      for (int j = 0; j < U; ++j) {
+        const int ch = min((c.b * U + j) * 64 + lane, nchunks - 1);
+        dst[r][j] = __builtin_nontemporal_load(p + ch);
       }
     }
   };
@@ -87,43 +90,90 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
   u32x4 cur[R][U], n1[R][U], n2[R][U];
   Cursor c0{(int)blockIdx.x * 4 + wave, 0};
   Cursor c1 = advance(c0), c2 = advance(c1);
-  // two weight batches go out before the activation prologue
+  // ---- prologue: stage x (and RMSNorm it) into LDS.
+  // Program order matters: vmcnt retires in order, so the (L2-resident) activation and gain loads are issued
+  // FIRST and the two weight batches right after them -- the prologue then waits only for its own small loads
+  // while 16 KiB of weights per wave are already in flight.
+  // NX = activation chunks per thread held in registers (host picks 2 or 8; covers B*K <= NX*2048 elements)
+  const int total = B * nchunks;
+  Vec16<T> xr[NX], gr[NX];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    const int c = min(tid + 256 * j, total - 1);
+    xr[j] = *reinterpret_cast<const Vec16<T>*>(x + (size_t)c * VEC);
+  }
+  if (norm_w) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int c = min(tid + 256 * j, total - 1);
+      gr[j] = *reinterpret_cast<const Vec16<T>*>(norm_w + (size_t)(c % nchunks) * VEC);
+    }
+  }
   load(c0, n1);
   load(c1, n2);
-
-  // ---- prologue: stage x (and RMSNorm it) into LDS
   {
     float ss[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) ss[b] = 0.f;
-    for (int c = tid; c < B * nchunks; c += 256) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int c = tid + 256 * j;
+      if (c < total) {
+        if (norm_w) {
+          const int b = c / nchunks;
+          float sq = 0.f;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) sq += xr[j].get(i) * xr[j].get(i);
+#pragma unroll
+          for (int bb = 0; bb < B; ++bb)
+            if (bb == b) ss[bb] += sq;
+        } else {
+          *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC) = xr[j];
+        }
+      }
+    }
+    for (int c = tid + 256 * NX; c < total; c += 256) {  // rare: B*K > 16384
       Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(x + (size_t)c * VEC);
       *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC) = v;
       if (norm_w) {
         const int b = c / nchunks;
-        float s = 0.f;
+        float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) s += v.get(i) * v.get(i);
+        for (int i = 0; i < VEC; ++i) sq += v.get(i) * v.get(i);
 #pragma unroll
         for (int bb = 0; bb < B; ++bb)
-          if (bb == b) ss[bb] += s;
+          if (bb == b) ss[bb] += sq;
       }
     }
     if (norm_w) {
       float rs[B];
 #pragma unroll
       for (int b = 0; b < B; ++b) rs[b] = rsqrtf(block_sum(ss[b], red) / (float)K + norm_eps);
-      __syncthreads();
-      for (int c = tid; c < B * nchunks; c += 256) {
-        const int b = c / nchunks, kc = c - b * nchunks;
-        Vec16<T> v = *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC);
-        Vec16<T> g = *reinterpret_cast<const Vec16<T>*>(norm_w + (size_t)kc * VEC);
+      auto pick = [&](int b) {
         float r = rs[0];
 #pragma unroll
         for (int bb = 1; bb < B; ++bb)
           if (bb == b) r = rs[bb];
+        return r;
+      };
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) v.set(i, g.get(i) * rnd<T>(v.get(i) * r));  // weight * h.to(dtype)
+      for (int j = 0; j < NX; ++j) {
+        const int c = tid + 256 * j;
+        if (c < total) {
+          const float r = pick(c / nchunks);
+          Vec16<T> v;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v.set(i, gr[j].get(i) * rnd<T>(xr[j].get(i) * r));  // weight * h.to(dtype)
+          *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC) = v;
+        }
+      }
+      for (int c = tid + 256 * NX; c < total; c += 256) {
+        const int b = c / nchunks, kc = c - b * nchunks;
+        Vec16<T> v = *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC);  // written by this same thread above
+        const Vec16<T> g = *reinterpret_cast<const Vec16<T>*>(norm_w + (size_t)kc * VEC);
+        const float r = pick(b);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v.set(i, g.get(i) * rnd<T>(v.get(i) * r));
         *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC) = v;
       }
     }
@@ -204,29 +254,29 @@ int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, con
   const size_t lds = (size_t)B * K * sizeof(T);
   SRGPT_CHECK(lds <= 150 * 1024, SRGPT_ERR_UNSUPPORTED, "srgpt_gemv: batch*K too large for LDS (%zu bytes)", lds);
   const int cus = srgpt_device_cus();
-  const int per_cu = lds > 70 * 1024 ? 1 : 2;
+  static const int env_per_cu = getenv("SRGPT_GEMV_BLOCKS_PER_CU") ? atoi(getenv("SRGPT_GEMV_BLOCKS_PER_CU")) : 0;  // tuning knob
+  const int per_cu = lds > 70 * 1024 ? 1 : (env_per_cu > 0 ? env_per_cu : 2);
   int grid = (N + 3) / 4;
   if (grid > cus * per_cu) grid = cus * per_cu;
   if (grid < 1) grid = 1;
+  const int chunks = B * (K / WChunk<T>::VEC);
+#define SRGPT_GEMV_LAUNCH(SW, NXV)                                                                              \
+  do {                                                                                                          \
+    auto kfn = gemv_kernel<T, B, SW, NXV>;                                                                      \
+    static bool attr_set = false;                                                                               \
+    if (lds > 48 * 1024 && !attr_set) {                                                                         \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);      \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, (const T*)x, (const T*)W, (const T*)norm_w, eps,     \
+                       (const T*)residual, out, N, K, out_f32);                                                 \
+  } while (0)
   if (swiglu) {
-    auto kfn = gemv_kernel<T, B, true>;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, (const T*)x, (const T*)W, (const T*)norm_w, eps,
-                       (const T*)residual, out, N, K, out_f32);
+    if (chunks <= 512) SRGPT_GEMV_LAUNCH(true, 2); else SRGPT_GEMV_LAUNCH(true, 8);
   } else {
-    auto kfn = gemv_kernel<T, B, false>;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, (const T*)x, (const T*)W, (const T*)norm_w, eps,
-                       (const T*)residual, out, N, K, out_f32);
+    if (chunks <= 512) SRGPT_GEMV_LAUNCH(false, 2); else SRGPT_GEMV_LAUNCH(false, 8);
   }
+#undef SRGPT_GEMV_LAUNCH
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }

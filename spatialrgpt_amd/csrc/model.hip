@@ -44,8 +44,11 @@ struct LlmWs {
   void *x, *h, *qkv, *attn, *gu, *act, *last;  // prefill
   void *xd, *qkvd, *attnd, *actd;              // decode
   float* dws;
+  float* amax_v;  // [batch, ARGMAX_BLOCKS] partial maxima
+  int* amax_i;    // [batch, ARGMAX_BLOCKS] their indices
   size_t total;
 };
+constexpr int ARGMAX_BLOCKS = 128;
 LlmWs carve_llm(const srgpt_llm_weights* w, int batch, int max_tokens, void* ws) {
   const size_t es = dtype_size(w->dtype);
   const size_t rows = (size_t)batch * max_tokens;
@@ -64,6 +67,8 @@ LlmWs carve_llm(const srgpt_llm_weights* w, int batch, int max_tokens, void* ws)
   l.attnd = c.take((size_t)batch * w->heads * w->head_dim * es);
   l.actd = c.take((size_t)batch * w->inter * es);
   l.dws = reinterpret_cast<float*>(c.take((size_t)srgpt_decode_attn_ws_floats(batch, w->heads, w->head_dim) * 4));
+  l.amax_v = reinterpret_cast<float*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
+  l.amax_i = reinterpret_cast<int*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
   l.total = c.off;
   return l;
 }
@@ -73,16 +78,92 @@ __global__ void set_int_kernel(int* p, int n, int v) {
   if (i < n) p[i] = v;
 }
 
-// tok/out_ids/pos bookkeeping after argmax wrote tok[]
-__global__ void advance_kernel(const int64_t* tok, int64_t* out_ids, int* pos, int* step, int B, int max_new,
-                               int bump_pos) {
+// greedy pick, stage 1: each block scans a contiguous slice of one row (first max wins, like torch.argmax)
+__global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __restrict__ logits, float* __restrict__ pv,
+                                                             int* __restrict__ pi, int V) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int b = blockIdx.y, nb = gridDim.x;
+  const int per = (V + nb - 1) / nb;
+  const int lo = blockIdx.x * per, hi = min(lo + per, V);
+  const float* row = logits + (size_t)b * V;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const float v = row[i];
+    if (v > best) {  // ascending scan per thread: the first maximum is kept
+      best = v;
+      bi = i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = best;
+    si[threadIdx.x >> 6] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i)
+      if (sv[i] > best || (sv[i] == best && si[i] < bi)) {
+        best = sv[i];
+        bi = si[i];
+      }
+    pv[(size_t)b * nb + blockIdx.x] = best;
+    pi[(size_t)b * nb + blockIdx.x] = bi;
+  }
+}
+
+// stage 2 + bookkeeping: one wave per batch row merges the partials -> tok / out_ids[:, step] / pos / step
+__global__ void advance_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int nb, int64_t* tok,
+                               int64_t* out_ids, int* pos, int* step, int B, int max_new, int bump_pos) {
   const int s = *step;
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    if (s < max_new) out_ids[(size_t)b * max_new + s] = tok[b];
-    if (bump_pos) pos[b] += 1;
+  const int lane = threadIdx.x & 63;
+  for (int b = threadIdx.x >> 6; b < B; b += blockDim.x >> 6) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < nb; i += 64) {
+      const float v = pv[(size_t)b * nb + i];
+      const int ix = pi[(size_t)b * nb + i];
+      if (v > best || (v == best && ix < bi)) {
+        best = v;
+        bi = ix;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ov > best || (ov == best && oi < bi)) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      const int64_t t = bi == 0x7fffffff ? 0 : bi;
+      tok[b] = t;
+      if (s < max_new) out_ids[(size_t)b * max_new + s] = t;
+      if (bump_pos) pos[b] += 1;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) *step = s + 1;
+}
+
+static int greedy_pick(const srgpt_llm_weights* w, srgpt_llm_state* st, const LlmWs& d, int bump_pos, hipStream_t s) {
+  const int B = st->batch;
+  hipLaunchKernelGGL(argmax_partial_kernel, dim3(ARGMAX_BLOCKS, B), dim3(256), 0, s, st->logits, d.amax_v, d.amax_i, w->vocab);
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(256), 0, s, d.amax_v, d.amax_i, ARGMAX_BLOCKS, st->tok, st->out_ids,
+                     st->pos, st->step, B, st->max_new, bump_pos);
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
 }
 
 }  // namespace
@@ -215,11 +296,8 @@ extern "C" int srgpt_llm_sample_first(const srgpt_llm_weights* w, srgpt_llm_stat
   SRGPT_TRY(check_llm(w, st));
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, s, st->step, 1, 0);
-  SRGPT_TRY(srgpt_argmax(st->logits, st->tok, st->batch, w->vocab, stream));
-  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, st->tok, st->out_ids, st->pos, st->step, st->batch,
-                     st->max_new, 0);
-  SRGPT_LAUNCH_CHECK();
-  return SRGPT_OK;
+  const LlmWs d = carve_llm(w, st->batch, st->ws_tokens, st->ws);
+  return greedy_pick(w, st, d, 0, s);
 }
 
 extern "C" int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream) {
@@ -242,10 +320,7 @@ extern "C" int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state
     SRGPT_TRY(srgpt_gemv(d.actd, w->wdown[i], nullptr, 0.f, d.xd, d.xd, B, Hd, I, 0, 0, dt, stream));
   }
   SRGPT_TRY(srgpt_gemv(d.xd, w->lm_head, w->final_norm, w->rms_eps, nullptr, st->logits, B, w->vocab, Hd, 0, 1, dt, stream));
-  SRGPT_TRY(srgpt_argmax(st->logits, st->tok, B, w->vocab, stream));
-  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, st->tok, st->out_ids, st->pos, st->step, B, st->max_new, 1);
-  SRGPT_LAUNCH_CHECK();
-  return SRGPT_OK;
+  return greedy_pick(w, st, d, 1, s);
 }
 
 // ================================================================================================
