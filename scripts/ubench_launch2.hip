@@ -1,0 +1,44 @@
+// Does kernel resource footprint (VGPRs / LDS / launch bounds) change the dependent-kernel boundary cost?
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+template <int NV, int USE_LDS>
+__global__ __launch_bounds__(256, 2) void k_res(int* p, int n) {
+  extern __shared__ int sm[];
+  float v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = p[(threadIdx.x + i) & 1023] * 1.0001f;
+  if (USE_LDS) { sm[threadIdx.x] = (int)v[0]; __syncthreads(); v[1] += sm[(threadIdx.x + 1) & 255]; }
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += v[i] * v[(i * 7 + 3) % NV];
+  if (s == 1.2345f) p[0] = 1;
+  if (n == -1) p[threadIdx.x] = (int)s;
+}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+template <typename F>
+int run(const char* name, F launch, hipStream_t s) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipGraph_t g; hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < 200; ++i) launch();
+  CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  float ms = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < 10; ++i) CK(hipGraphLaunch(ge, s));
+    CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  printf("%-40s %.2f us/kernel\n", name, ms * 1e3 / 2000);
+  return 0;
+}
+int main() {
+  hipStream_t s; CK(hipStreamCreate(&s));
+  int* d; CK(hipMalloc(&d, 4096 * 4)); CK(hipMemset(d, 0, 4096 * 4));
+  run("8 vgpr-ish, no lds, grid 512", [&] { hipLaunchKernelGGL((k_res<4, 0>), dim3(512), dim3(256), 0, s, d, 0); }, s);
+  run("~140 vgpr, no lds, grid 512", [&] { hipLaunchKernelGGL((k_res<128, 0>), dim3(512), dim3(256), 0, s, d, 0); }, s);
+  run("8 vgpr-ish, 8 KB dyn lds, grid 512", [&] { hipLaunchKernelGGL((k_res<4, 1>), dim3(512), dim3(256), 8192, s, d, 0); }, s);
+  run("~140 vgpr, 28 KB dyn lds, grid 512", [&] { hipLaunchKernelGGL((k_res<128, 1>), dim3(512), dim3(256), 28672, s, d, 0); }, s);
+  run("~140 vgpr, 8 KB dyn lds, grid 512", [&] { hipLaunchKernelGGL((k_res<128, 1>), dim3(512), dim3(256), 8192, s, d, 0); }, s);
+  return 0;
+}

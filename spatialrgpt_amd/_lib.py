@@ -74,6 +74,7 @@ _SIGNATURES = {
     "srgpt_scatter_rows": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "srgpt_silu_mul": (i32, [vp, vp, i32, i32, i32, vp]),
     "srgpt_argmax": (i32, [vp, vp, i32, i32, vp]),
+    "srgpt_prefetch": (i32, [vp, i64, i32, vp]),
     "srgpt_vit_ws_bytes": (i64, [C.POINTER(VitWeights), i32]),
     "srgpt_vit_forward": (i32, [C.POINTER(VitWeights), vp, vp, vp, i32, vp]),
     "srgpt_llm_ws_bytes": (i64, [C.POINTER(LlmWeights), i32, i32]),

@@ -18,6 +18,22 @@
 
 #include "common.h"
 
+// Optional per-wave timestamping (scripts/ubench_gemv_ts.hip builds this file with -DSRGPT_GEMV_TS)
+#ifdef SRGPT_GEMV_TS
+__device__ long long srgpt_gemv_ts[8 * 8192];
+extern "C" void* srgpt_gemv_ts_ptr() {
+  void* p = nullptr;
+  (void)hipGetSymbolAddress(&p, HIP_SYMBOL(srgpt_gemv_ts));
+  return p;
+}
+#define SRGPT_TS(slot)                                                                             \
+  do {                                                                                             \
+    if (lane == 0) srgpt_gemv_ts[((int)blockIdx.x * 4 + wave) * 8 + (slot)] = wall_clock64();     \
+  } while (0)
+#else
+#define SRGPT_TS(slot)
+#endif
+
 namespace {
 
 template <typename T>
@@ -75,19 +91,24 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
   // loads are UNCONDITIONAL (indices clamped, surplus data discarded by the consumer): straight-line code lets
   // the compiler emit counted s_waitcnt vmcnt(N) instead of draining the queue at every use
   auto load = [&](Cursor c, u32x4 (&dst)[R][U]) {
-    const int u = min(c.unit, units - 1);
+    // dead cursors (past the wave's last unit) must issue NOTHING: redundant loads to a clamped address hot-spot
+    // one L2 channel and were measured to add microseconds to every launch.  The branch is scalar (readfirstlane).
+    const int u = __builtin_amdgcn_readfirstlane(c.unit);
+    if (u < units) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(u + r * N) * K);
+      for (int r = 0; r < R; ++r) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(u + r * N) * K);
 #pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const int ch = min((c.b * U + j) * 64 + lane, nchunks - 1);
-        dst[r][j] = __builtin_nontemporal_load(p + ch);
+        for (int j = 0; j < U; ++j) {
+          const int ch = min((c.b * U + j) * 64 + lane, nchunks - 1);
+          dst[r][j] = __builtin_nontemporal_load(p + ch);
+        }
       }
     }
   };
 
   u32x4 cur[R][U], n1[R][U], n2[R][U];
+  SRGPT_TS(0);
   Cursor c0{(int)blockIdx.x * 4 + wave, 0};
   Cursor c1 = advance(c0), c2 = advance(c1);
   // ---- prologue: stage x (and RMSNorm it) into LDS.
@@ -111,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
   }
   load(c0, n1);
   load(c1, n2);
+  SRGPT_TS(1);
   {
     float ss[B];
 #pragma unroll
@@ -185,6 +207,10 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
+  SRGPT_TS(2);
+#ifdef SRGPT_GEMV_TS
+  int ts_it = 0;
+#endif
 
   while (c0.unit < units) {
 #pragma unroll
@@ -242,10 +268,15 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
         }
       }
     }
+#ifdef SRGPT_GEMV_TS
+    if (ts_it == 0) SRGPT_TS(3);
+    ++ts_it;
+#endif
     c0 = c1;
     c1 = c2;
     c2 = c3;
   }
+  SRGPT_TS(4);
 }
 
 template <typename T, int B>
