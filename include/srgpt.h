@@ -63,11 +63,14 @@ int srgpt_device_cus(void);
  *   - out_mode SRGPT_OUT_DECONV2X: A rows are pixels (img, i, j) of a [n_img, gw, gw] grid, N = 4*Cout
  *     ordered n = (a*2+b)*Cout + co; C is the channels-last [n_img, 2gw, 2gw, Cout] map and
  *     element (m,n) lands at pixel (2i+a, 2j+b), channel co.  `gw` passes the grid width.
- *   - M <= 8 dispatches to the weight-streaming (HBM-bound) path used by decode.
+ *   - ws / ws_bytes: optional fp32 workspace for deterministic split-K (small-M shapes whose tile grid cannot fill
+ *     256 CUs: K is cut into <= 8 slabs written to ws and reduced in slab order); NULL disables split-K.
+ *     srgpt_gemm_ws_bytes(M, N) is always sufficient.
  * --------------------------------------------------------------------------------------------- */
+int64_t srgpt_gemm_ws_bytes(int M, int N);
 int srgpt_gemm(const void* A, const void* W, const void* bias, const void* residual, void* C,
                int M, int N, int K, int lda, int ldc, int act, int bias_mod, int res_mod,
-               int out_f32, int out_mode, int gw, int dtype, srgpt_stream_t stream);
+               int out_f32, int out_mode, int gw, void* ws, int64_t ws_bytes, int dtype, srgpt_stream_t stream);
 
 /* Decode-only fused GEMVs (M = batch <= 4 rows), weights streamed once from HBM:
  *   norm_w != NULL : x <- RMSNorm(x) * norm_w first (modeling_llama.py:61-75) (rounded to dtype like torch)

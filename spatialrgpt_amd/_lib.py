@@ -56,7 +56,8 @@ _SIGNATURES = {
     "srgpt_last_error": (C.c_char_p, []),
     "srgpt_abi_version": (i32, []),
     "srgpt_device_cus": (i32, []),
-    "srgpt_gemm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "srgpt_gemm_ws_bytes": (i64, [i32, i32]),
+    "srgpt_gemm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
     "srgpt_gemv": (i32, [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "srgpt_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, i32, i32, vp]),
     "srgpt_rmsnorm": (i32, [vp, vp, vp, i32, i32, f32, i32, vp]),

@@ -14,6 +14,8 @@ struct Epilogue {
   const void* residual;
   void* C;
   int M, N, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw;
+  float* partial;  // split-K: fp32 slabs [splits][M][N] (deterministic: reduced in slab order by splitk_reduce_kernel)
+  int splits, tiles_per_split;
 };
 
 template <typename T>
@@ -65,30 +67,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int sc = tid & 7, sr = tid >> 3;  // staging slot column / row
 
-  u32x4 ra[LA], rw[LW];
-  auto gload = [&](int kt) {
+  // two register sets: the global loads of K-tile t+2 are in flight while tile t is multiplied and tile t+1 sits
+  // in the other set waiting for its LDS slot (prefetch distance = 2 tiles; one tile cannot cover HBM/L2 latency)
+  u32x4 ra[2][LA], rw[2][LW];
+  auto gload = [&](int kt, u32x4 (&da)[LA], u32x4 (&dw)[LW]) {
     const int k = kt * BK + sc * 8;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int m = m0 + sr + 32 * i;
-      ra[i] = (m < e.M && k < K) ? *reinterpret_cast<const u32x4*>(A + (size_t)m * lda + k) : u32x4{0, 0, 0, 0};
+      da[i] = (m < e.M && k < K) ? *reinterpret_cast<const u32x4*>(A + (size_t)m * lda + k) : u32x4{0, 0, 0, 0};
     }
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
       const int n = n0 + sr + 32 * i;
-      rw[i] = (n < e.N && k < K) ? *reinterpret_cast<const u32x4*>(W + (size_t)n * K + k) : u32x4{0, 0, 0, 0};
+      dw[i] = (n < e.N && k < K) ? *reinterpret_cast<const u32x4*>(W + (size_t)n * K + k) : u32x4{0, 0, 0, 0};
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const u32x4 (&da)[LA], const u32x4 (&dw)[LW]) {
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int r = sr + 32 * i;
-      *reinterpret_cast<u32x4*>(As + (size_t)buf * BM * BK + r * BK + ((sc ^ (r & 7)) << 3)) = ra[i];
+      *reinterpret_cast<u32x4*>(As + (size_t)buf * BM * BK + r * BK + ((sc ^ (r & 7)) << 3)) = da[i];
     }
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
       const int r = sr + 32 * i;
-      *reinterpret_cast<u32x4*>(Ws + (size_t)buf * BN * BK + r * BK + ((sc ^ (r & 7)) << 3)) = rw[i];
+      *reinterpret_cast<u32x4*>(Ws + (size_t)buf * BN * BK + r * BK + ((sc ^ (r & 7)) << 3)) = dw[i];
     }
   };
 
@@ -99,13 +103,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = zero16;
 
-  const int nk = (K + BK - 1) / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload(kt + 1);
+  const int nk_all = (K + BK - 1) / BK;
+  const int kt0 = e.splits > 1 ? (int)blockIdx.z * e.tiles_per_split : 0;
+  const int nk = e.splits > 1 ? min(nk_all, kt0 + e.tiles_per_split) : nk_all;
+
+  auto compute = [&](int cur) {
     const bf16_t* as = As + (size_t)cur * BM * BK;
     const bf16_t* ws = Ws + (size_t)cur * BN * BK;
 #pragma unroll
@@ -128,10 +130,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) lstore(cur ^ 1);
+  };
+
+  // tile t lives in register set (t - kt0) & 1 until it is written to LDS buffer (t - kt0) & 1
+  gload(kt0, ra[0], rw[0]);
+  if (kt0 + 1 < nk) gload(kt0 + 1, ra[1], rw[1]);
+  lstore(0, ra[0], rw[0]);
+  __syncthreads();
+  int kt = kt0;
+  for (; kt + 1 < nk; kt += 2) {
+    // even step: multiply LDS[0] (tile kt); set 0 is free -> fetch tile kt+2; stage tile kt+1 (set 1) into LDS[1]
+    if (kt + 2 < nk) gload(kt + 2, ra[0], rw[0]);
+    compute(0);
+    lstore(1, ra[1], rw[1]);
     __syncthreads();
-    cur ^= 1;
+    // odd step: multiply LDS[1] (tile kt+1); set 1 is free -> fetch tile kt+3; stage tile kt+2 (set 0) into LDS[0]
+    if (kt + 3 < nk) gload(kt + 3, ra[1], rw[1]);
+    compute(1);
+    if (kt + 2 < nk) lstore(0, ra[0], rw[0]);
+    __syncthreads();
   }
+  if (kt < nk) compute(0);  // odd number of tiles: the last one is already staged in LDS[0]
 
   // D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma clang loop unroll(full)
@@ -141,9 +160,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__
       const f32x16 a = acc[i][j];
       const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
       const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+      if (e.splits > 1) {
+        float* slab = e.partial + (size_t)blockIdx.z * e.M * e.N;
 #pragma clang loop unroll(full)
-      for (int r = 0; r < 16; ++r) epilogue_store<bf16_t>(e, mb + (r & 3) + 8 * (r >> 2), n, a[r]);
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < e.M && n < e.N) slab[(size_t)m * e.N + n] = a[r];
+        }
+      } else {
+#pragma clang loop unroll(full)
+        for (int r = 0; r < 16; ++r) epilogue_store<bf16_t>(e, mb + (r & 3) + 8 * (r >> 2), n, a[r]);
+      }
     }
+}
+
+// split-K second pass: fixed-order sum of the fp32 slabs, then the fused epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(Epilogue e) {
+  const size_t total = (size_t)e.M * e.N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float acc = 0.f;
+    for (int z = 0; z < e.splits; ++z) acc += e.partial[(size_t)z * total + i];
+    const int m = (int)(i / e.N), n = (int)(i - (size_t)m * e.N);
+    epilogue_store<T>(e, m, n, acc);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -195,9 +235,11 @@ __global__ __launch_bounds__(256) void gemm_f32_simple(const float* __restrict__
 
 }  // namespace
 
+extern "C" int64_t srgpt_gemm_ws_bytes(int M, int N) { return (int64_t)8 * M * N * 4; }
+
 extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const void* residual, void* C, int M,
                           int N, int K, int lda, int ldc, int act, int bias_mod, int res_mod, int out_f32,
-                          int out_mode, int gw, int dtype, srgpt_stream_t stream) {
+                          int out_mode, int gw, void* ws, int64_t ws_bytes, int dtype, srgpt_stream_t stream) {
   SRGPT_CHECK(A && W && C, SRGPT_ERR_ARG, "srgpt_gemm: null pointer");
   SRGPT_CHECK(M > 0 && N > 0 && K > 0, SRGPT_ERR_ARG, "srgpt_gemm: bad shape M=%d N=%d K=%d", M, N, K);
   SRGPT_CHECK(dtype == SRGPT_F32 || dtype == SRGPT_BF16, SRGPT_ERR_ARG, "srgpt_gemm: bad dtype %d", dtype);
@@ -211,25 +253,52 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
     SRGPT_CHECK(out_mode == SRGPT_OUT_PLAIN, SRGPT_ERR_ARG, "srgpt_gemm: unknown out_mode %d", out_mode);
     SRGPT_CHECK(ldc >= N, SRGPT_ERR_ARG, "srgpt_gemm: ldc < N");
   }
-  Epilogue e{bias, residual, C, M, N, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw};
+  Epilogue e{bias, residual, C, M, N, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw, nullptr, 1, 0};
   hipStream_t s = as_stream(stream);
   if (dtype == SRGPT_F32) {
     dim3 grid(cdiv(N, 64), cdiv(M, 64));
     hipLaunchKernelGGL(gemm_f32_simple, grid, dim3(256), 0, s, (const float*)A, (const float*)W, K, lda, e);
-  } else {
-    // pick the tile so that the grid covers the 256 CUs when the problem allows it
-    const long b128 = (long)cdiv(M, 128) * cdiv(N, 128);
-    if (b128 >= 256 || (M > 64 && (long)cdiv(M, 64) * cdiv(N, 128) < 64)) {
-      dim3 grid(cdiv(N, 128), cdiv(M, 128));
-      hipLaunchKernelGGL((gemm_bf16_mfma<128, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
-    } else if ((long)cdiv(M, 64) * cdiv(N, 128) >= 192 || N >= 4 * M) {
-      dim3 grid(cdiv(N, 128), cdiv(M, 64));
-      hipLaunchKernelGGL((gemm_bf16_mfma<64, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
-    } else {
-      dim3 grid(cdiv(N, 64), cdiv(M, 64));
-      hipLaunchKernelGGL((gemm_bf16_mfma<64, 64>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+    SRGPT_LAUNCH_CHECK();
+    return SRGPT_OK;
+  }
+  // ---- tile / split-K selection: fill the 256 CUs with >= ~2 blocks each ----
+  const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
+  const long t64x128 = (long)cdiv(M, 64) * cdiv(N, 128);
+  const int nk = cdiv(K, BK);
+  int bm = 128, splits = 1;
+  long tiles = t128;
+  const bool pad_waste = (long)cdiv(M, 128) * 128 * 10 > (long)cdiv(M, 64) * 64 * 11;  // > 10 % fewer padded rows with BM = 64
+  if (t128 < 384 || pad_waste) {
+    bm = 64;
+    tiles = t64x128;
+    if (tiles < 384 && ws) {
+      splits = (int)((512 + tiles - 1) / tiles);
+      if (splits > nk / 8) splits = nk / 8;  // keep >= 8 K-tiles (512 columns of K) per split
+      if (splits > 8) splits = 8;
+      while (splits > 1 && (int64_t)splits * M * N * 4 > ws_bytes) --splits;
+      if (splits < 1) splits = 1;
     }
   }
+  if (splits > 1) {
+    e.partial = reinterpret_cast<float*>(ws);
+    e.tiles_per_split = cdiv(nk, splits);
+    splits = cdiv(nk, e.tiles_per_split);  // no empty split
+    e.splits = splits;
+  }
+  if (bm == 128) {
+    dim3 grid(cdiv(N, 128), cdiv(M, 128), 1);
+    hipLaunchKernelGGL((gemm_bf16_mfma<128, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+  } else {
+    dim3 grid(cdiv(N, 128), cdiv(M, 64), e.splits);
+    hipLaunchKernelGGL((gemm_bf16_mfma<64, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+  }
   SRGPT_LAUNCH_CHECK();
+  if (e.splits > 1) {
+    const size_t total = (size_t)M * N;
+    int rgrid = (int)((total + 255) / 256);
+    if (rgrid > 2048) rgrid = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(rgrid), dim3(256), 0, s, e);
+    SRGPT_LAUNCH_CHECK();
+  }
   return SRGPT_OK;
 }

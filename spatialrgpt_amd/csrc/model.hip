@@ -22,8 +22,8 @@ struct Carver {
 
 // ---- ViT workspace ----
 struct VitWs {
-  void *col, *h, *qkv, *mlp;
-  size_t total;
+  void *col, *h, *qkv, *mlp, *gws;
+  size_t gws_bytes, total;
 };
 VitWs carve_vit(const srgpt_vit_weights* w, int n_img, void* ws) {
   const size_t es = dtype_size(w->dtype);
@@ -35,6 +35,8 @@ VitWs carve_vit(const srgpt_vit_weights* w, int n_img, void* ws) {
   v.h = c.take(rows * w->hidden * es);
   v.qkv = c.take(rows * 3 * w->hidden * es);
   v.mlp = c.take(rows * w->inter * es);
+  v.gws_bytes = (size_t)srgpt_gemm_ws_bytes((int)rows, w->hidden);  // split-K only pays on the narrow (N = hidden) GEMMs
+  v.gws = c.take(v.gws_bytes);
   v.total = c.off;
   return v;
 }
@@ -44,6 +46,8 @@ struct LlmWs {
   void *x, *h, *qkv, *attn, *gu, *act, *last;  // prefill
   void *xd, *qkvd, *attnd, *actd;              // decode
   float* dws;
+  void* gws;  // split-K workspace of the prefill GEMMs
+  size_t gws_bytes;
   float* amax_v;  // [batch, ARGMAX_BLOCKS] partial maxima
   int* amax_i;    // [batch, ARGMAX_BLOCKS] their indices
   size_t total;
@@ -67,6 +71,8 @@ LlmWs carve_llm(const srgpt_llm_weights* w, int batch, int max_tokens, void* ws)
   l.attnd = c.take((size_t)batch * w->heads * w->head_dim * es);
   l.actd = c.take((size_t)batch * w->inter * es);
   l.dws = reinterpret_cast<float*>(c.take((size_t)srgpt_decode_attn_ws_floats(batch, w->heads, w->head_dim) * 4));
+  l.gws_bytes = (size_t)srgpt_gemm_ws_bytes((int)rows, (int)(qkvw > (size_t)w->hidden ? qkvw : (size_t)w->hidden));
+  l.gws = c.take(l.gws_bytes);
   l.amax_v = reinterpret_cast<float*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
   l.amax_i = reinterpret_cast<int*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
   l.total = c.off;
@@ -193,23 +199,23 @@ extern "C" int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images,
   SRGPT_TRY(srgpt_im2col(images, v.col, n_img, w->image_size, w->patch, w->kp, dt, stream));
   // conv-as-GEMM + bias, then + position embedding (row m uses pos_emb[m % L])
   SRGPT_TRY(srgpt_gemm(v.col, w->patch_w, w->patch_b, w->pos_emb, x, rows, C, w->kp, w->kp, C, SRGPT_ACT_NONE, 0, L, 0,
-                       SRGPT_OUT_PLAIN, 0, dt, stream));
+                       SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt, stream));
   const float scale = 1.0f / sqrtf((float)hd);
   const char* qkv = reinterpret_cast<const char*>(v.qkv);
   const size_t es = dtype_size(dt);
   for (int l = 0; l < w->n_layers_run; ++l) {
     SRGPT_TRY(srgpt_layernorm(x, w->ln1_w[l], w->ln1_b[l], v.h, rows, C, w->eps, SRGPT_ACT_NONE, dt, stream));
     SRGPT_TRY(srgpt_gemm(v.h, w->wqkv[l], w->bqkv[l], nullptr, v.qkv, rows, 3 * C, C, C, 3 * C, SRGPT_ACT_NONE, 0, 0, 0,
-                         SRGPT_OUT_PLAIN, 0, dt, stream));
+                         SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt, stream));
     SRGPT_TRY(srgpt_attention(qkv, qkv + (size_t)C * es, qkv + (size_t)2 * C * es, v.h, n_img, L, L, H, H, hd,
                               (int64_t)L * 3 * C, 3 * C, hd, (int64_t)L * 3 * C, 3 * C, hd, (int64_t)L * 3 * C, 3 * C, hd,
                               scale, 0, nullptr, dt, stream));
-    SRGPT_TRY(srgpt_gemm(v.h, w->wo[l], w->bo[l], x, x, rows, C, C, C, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, dt,
+    SRGPT_TRY(srgpt_gemm(v.h, w->wo[l], w->bo[l], x, x, rows, C, C, C, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt,
                          stream));
     SRGPT_TRY(srgpt_layernorm(x, w->ln2_w[l], w->ln2_b[l], v.h, rows, C, w->eps, SRGPT_ACT_NONE, dt, stream));
     SRGPT_TRY(srgpt_gemm(v.h, w->w1[l], w->b1[l], nullptr, v.mlp, rows, I, C, C, I, SRGPT_ACT_GELU_TANH, 0, 0, 0,
-                         SRGPT_OUT_PLAIN, 0, dt, stream));
-    SRGPT_TRY(srgpt_gemm(v.mlp, w->w2[l], w->b2[l], x, x, rows, C, I, I, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, dt,
+                         SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt, stream));
+    SRGPT_TRY(srgpt_gemm(v.mlp, w->w2[l], w->b2[l], x, x, rows, C, I, I, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt,
                          stream));
   }
   return SRGPT_OK;
@@ -256,20 +262,20 @@ extern "C" int srgpt_llm_prefill(const srgpt_llm_weights* w, srgpt_llm_state* st
     char* vc = reinterpret_cast<char*>(st->vcache) + (size_t)i * layer_kv;
     SRGPT_TRY(srgpt_rmsnorm(l.x, w->attn_norm[i], l.h, rows, Hd, w->rms_eps, dt, stream));
     SRGPT_TRY(srgpt_gemm(l.h, w->wqkv[i], nullptr, nullptr, l.qkv, rows, QW, Hd, Hd, QW, SRGPT_ACT_NONE, 0, 0, 0,
-                         SRGPT_OUT_PLAIN, 0, dt, stream));
+                         SRGPT_OUT_PLAIN, 0, l.gws, (int64_t)l.gws_bytes, dt, stream));
     SRGPT_TRY(srgpt_rope_kv_append(l.qkv, kc, vc, nullptr, w->rope_cos, w->rope_sin, B, T, Hq, Hkv, D, st->max_pos, dt,
                                    stream));
     SRGPT_TRY(srgpt_attention(l.qkv, kc, vc, l.attn, B, T, T, Hq, Hkv, D, (int64_t)T * QW, QW, D,
                               (int64_t)Hkv * st->max_pos * D, D, (int64_t)st->max_pos * D,
                               (int64_t)Hkv * st->max_pos * D, D, (int64_t)st->max_pos * D, scale, 1, nullptr, dt, stream));
     SRGPT_TRY(srgpt_gemm(l.attn, w->wo[i], nullptr, l.x, l.x, rows, Hd, Hq * D, Hq * D, Hd, SRGPT_ACT_NONE, 0, 0, 0,
-                         SRGPT_OUT_PLAIN, 0, dt, stream));
+                         SRGPT_OUT_PLAIN, 0, l.gws, (int64_t)l.gws_bytes, dt, stream));
     SRGPT_TRY(srgpt_rmsnorm(l.x, w->mlp_norm[i], l.h, rows, Hd, w->rms_eps, dt, stream));
     SRGPT_TRY(srgpt_gemm(l.h, w->wgu[i], nullptr, nullptr, l.gu, rows, 2 * I, Hd, Hd, 2 * I, SRGPT_ACT_NONE, 0, 0, 0,
-                         SRGPT_OUT_PLAIN, 0, dt, stream));
+                         SRGPT_OUT_PLAIN, 0, l.gws, (int64_t)l.gws_bytes, dt, stream));
     SRGPT_TRY(srgpt_silu_mul(l.gu, l.act, rows, I, dt, stream));
     SRGPT_TRY(srgpt_gemm(l.act, w->wdown[i], nullptr, l.x, l.x, rows, Hd, I, I, Hd, SRGPT_ACT_NONE, 0, 0, 0,
-                         SRGPT_OUT_PLAIN, 0, dt, stream));
+                         SRGPT_OUT_PLAIN, 0, l.gws, (int64_t)l.gws_bytes, dt, stream));
     if (hidden_out)
       hipMemcpyAsync(reinterpret_cast<char*>(hidden_out) + (size_t)(i + 1) * hid_bytes, l.x, hid_bytes,
                      hipMemcpyDeviceToDevice, s);
@@ -277,7 +283,7 @@ extern "C" int srgpt_llm_prefill(const srgpt_llm_weights* w, srgpt_llm_state* st
   if (all_logits) {
     SRGPT_TRY(srgpt_rmsnorm(l.x, w->final_norm, l.h, rows, Hd, w->rms_eps, dt, stream));
     SRGPT_TRY(srgpt_gemm(l.h, w->lm_head, nullptr, nullptr, all_logits, rows, w->vocab, Hd, Hd, w->vocab, SRGPT_ACT_NONE,
-                         0, 0, 1, SRGPT_OUT_PLAIN, 0, dt, stream));
+                         0, 0, 1, SRGPT_OUT_PLAIN, 0, nullptr, 0, dt, stream));
   }
   // last position of every sequence -> logits (final norm fused into the GEMV prologue)
   if (hipMemcpy2DAsync(l.last, (size_t)Hd * es, reinterpret_cast<char*>(l.x) + (size_t)(T - 1) * Hd * es,

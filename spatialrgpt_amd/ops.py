@@ -38,6 +38,19 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+_gemm_ws = {}
+
+
+def _splitk_ws(device, M, N):
+    """fp32 split-K workspace (grown on demand, one per device; same-stream reuse is ordered by the stream)."""
+    need = 8 * M * N * 4
+    t = _gemm_ws.get(device)
+    if t is None or t.numel() < need:
+        t = torch.empty((need,), device=device, dtype=torch.uint8)
+        _gemm_ws[device] = t
+    return t
+
+
 def gemm(a, w, bias=None, residual=None, act=L.ACT_NONE, out=None, out_f32=False, bias_mod=0, res_mod=0,
          out_mode=L.OUT_PLAIN, gw=0, out_shape=None):
     """act(a @ w.T + bias) + residual.  a [M,K] (row stride may exceed K), w [N,K]."""
@@ -49,8 +62,10 @@ def gemm(a, w, bias=None, residual=None, act=L.ACT_NONE, out=None, out_f32=False
         shape = out_shape if out_shape is not None else (M, N)
         out = torch.empty(shape, device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
     ldc = N if out_mode != L.OUT_PLAIN else out.stride(0) if out.dim() == 2 else N
+    ws = _splitk_ws(a.device, M, N) if (a.dtype == torch.bfloat16 and M * N <= (1 << 24)) else None
     L.check(L.load().srgpt_gemm(_p(a), _p(w), _p(bias), _p(residual), _p(out), M, N, K, a.stride(0), ldc, act,
-                                bias_mod, res_mod, int(out_f32), out_mode, gw, dt_code(a), _stream()))
+                                bias_mod, res_mod, int(out_f32), out_mode, gw, _p(ws), 0 if ws is None else ws.numel(),
+                                dt_code(a), _stream()))
     return out
 
 

@@ -64,11 +64,12 @@ def test_argument_validation_without_gpu():
     from spatialrgpt_amd import _lib
 
     lib = _lib.load()
-    rc = lib.srgpt_gemm(None, None, None, None, None, 1, 1, 8, 8, 1, 0, 0, 0, 0, 0, 0, _lib.BF16, None)
+    rc = lib.srgpt_gemm(None, None, None, None, None, 1, 1, 8, 8, 1, 0, 0, 0, 0, 0, 0, None, 0, _lib.BF16, None)
     assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
-    rc = lib.srgpt_gemm(16, 16, None, None, 16, 4, 4, 7, 7, 4, 0, 0, 0, 0, 0, 0, _lib.BF16, None)
+    rc = lib.srgpt_gemm(16, 16, None, None, 16, 4, 4, 7, 7, 4, 0, 0, 0, 0, 0, 0, None, 0, _lib.BF16, None)
     assert rc == _lib.ERR_ARG and b"multiples" in lib.srgpt_last_error()
     rc = lib.srgpt_gemv(16, 16, None, 0.0, None, 16, 9, 8, 8, 0, 0, _lib.BF16, None)
     assert rc == _lib.ERR_UNSUPPORTED
     assert lib.srgpt_decode_attn_ws_floats(1, 32, 128) == 32 * 64 * 130
     assert lib.srgpt_region_pool_ws_floats(8, 108, 1152) == 8 * 11664 + 92 * 8 * 1152
+    assert lib.srgpt_gemm_ws_bytes(259, 4096) == 8 * 259 * 4096 * 4
