@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--max-new-tokens", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--batch", type=int, default=1, help="equal-length requests per generate() call per GPU (<= 4)")
     return ap.parse_args()
 
 
@@ -176,7 +177,9 @@ def main():
     model.engine.use_graph = not args.no_graph
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
-    req = synth_request(cfg, args.regions, args.prompt_len, 1 + rank, device, dtype)
+    reqs = [synth_request(cfg, args.regions, args.prompt_len, 1 + rank * args.batch + i, device, dtype) for i in range(args.batch)]
+    req = (torch.cat([r[0] for r in reqs], 0), torch.cat([r[1] for r in reqs], 0), torch.cat([r[2] for r in reqs], 0),
+           [r[3][0] for r in reqs])
 
     def step():
         ids = model.generate(req[0], images=req[1], depths=req[2], masks=req[3], do_sample=False, max_new_tokens=G,
@@ -199,11 +202,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert out.shape[-1] == G
-    tokens = world * args.steps * G
+    tokens = world * args.steps * G * args.batch
     value = tokens / dt
 
     # ---------------- roofline of the dominant kernel: decode weight-streaming GEMV (gate/up + SwiGLU) --------
@@ -272,7 +275,7 @@ def main():
             "config": {"workload": ("BASELINE configs[1]: SpatialRGPT-VILA1.5-8B geometry (Llama-3-8B 32L/4096/GQA-8 + SigLIP-so400m "
                                     "384px x2 passes + regiongpt extractor + mlp_downsample), 8 region masks, bs=1 per GPU, "
                                     f"prompt {args.prompt_len} ids -> T=259, greedy {G} new tokens") if args.model == "vila15_8b" else args.model,
-                       "requests_per_step_per_gpu": 1, "new_tokens_per_request": G, "parallelism": f"dp{world}",
+                       "requests_per_step_per_gpu": args.batch, "new_tokens_per_request": G, "parallelism": f"dp{world}",
                        "decode": "hipGraph" if not args.no_graph else "eager", "build_s": round(t_build, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }

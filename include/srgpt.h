@@ -30,7 +30,7 @@ extern "C" {
 typedef void* srgpt_stream_t; /* hipStream_t */
 
 enum { SRGPT_F32 = 0, SRGPT_BF16 = 1 };
-enum { SRGPT_ACT_NONE = 0, SRGPT_ACT_GELU_ERF = 1, SRGPT_ACT_GELU_TANH = 2, SRGPT_ACT_SILU = 3 };
+enum { SRGPT_ACT_NONE = 0, SRGPT_ACT_GELU_ERF = 1, SRGPT_ACT_GELU_TANH = 2, SRGPT_ACT_SILU = 3, SRGPT_ACT_QUICK_GELU = 4 };
 enum {
   SRGPT_OK = 0,
   SRGPT_ERR_ARG = -1,      /* -> ValueError */
@@ -177,10 +177,14 @@ int srgpt_prefetch(const void* ptr, int64_t bytes, int blocks, srgpt_stream_t st
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
   int dtype, hidden, inter, heads, n_layers_run, image_size, patch, kp; /* kp: padded 3*p*p */
+  int act;              /* MLP activation: SRGPT_ACT_GELU_TANH (SigLIP) or SRGPT_ACT_QUICK_GELU (CLIP) */
   float eps;
   const void* patch_w;  /* [hidden, kp] (conv weight flattened (c,ky,kx), zero padded) */
-  const void* patch_b;  /* [hidden] */
-  const void* pos_emb;  /* [grid*grid, hidden] */
+  const void* patch_b;  /* [hidden] or NULL (CLIP's patch conv has no bias) */
+  const void* pos_emb;  /* [tokens, hidden], tokens = grid*grid (+1 with a class token) */
+  const void* cls_emb;  /* [hidden] class embedding prepended to every image (CLIP) or NULL (SigLIP) */
+  const void* pre_ln_w; /* CLIP pre_layrnorm (applied to the embeddings) or NULL */
+  const void* pre_ln_b;
   const void* const* ln1_w; const void* const* ln1_b;
   const void* const* wqkv;  const void* const* bqkv;   /* [3*hidden, hidden] rows q;k;v */
   const void* const* wo;    const void* const* bo;
@@ -191,7 +195,11 @@ typedef struct {
 
 /* workspace bytes for n_img images */
 int64_t srgpt_vit_ws_bytes(const srgpt_vit_weights* w, int n_img);
-/* images [n_img,3,S,S] -> out [n_img, grid^2, hidden] */
+/* rows [n_img*gg, C] patch embeddings -> x [n_img, 1+gg, C]: row 0 = cls + pos[0], row 1+p = patch p + pos[1+p]
+ * (HF CLIPVisionEmbeddings.forward: cat(class_embeds, patch_embeds) + position_embedding) */
+int srgpt_vit_assemble_cls(const void* patches, const void* cls_emb, const void* pos_emb, void* x, int n_img, int gg,
+                           int C, int dtype, srgpt_stream_t stream);
+/* images [n_img,3,S,S] -> out [n_img, tokens, hidden] */
 int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images, void* out, void* ws, int n_img,
                       srgpt_stream_t stream);
 

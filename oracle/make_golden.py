@@ -40,6 +40,10 @@ TINY_VIT = dict(hidden_size=64, intermediate_size=176, num_hidden_layers=3, num_
                 patch_size=14, layer_norm_eps=1e-6, hidden_act="gelu_pytorch_tanh")
 
 
+TINY_CLIP = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, image_size=336,
+                 patch_size=14, layer_norm_eps=1e-5, hidden_act="quick_gelu", projection_dim=32)
+
+
 def canonical_state_dict(model) -> dict:
     """reference in-memory keys -> checkpoint (transformers 4.37.2) key names."""
     out = {}
@@ -58,6 +62,8 @@ def cfg_from(model, tok) -> so.SrgptConfig:
         vit_hidden=vc.hidden_size, vit_inter=vc.intermediate_size, vit_layers=vc.num_hidden_layers,
         vit_heads=vc.num_attention_heads, image_size=vc.image_size, patch_size=vc.patch_size,
         vit_eps=vc.layer_norm_eps, select_layer=-2,
+        select_feature=model.get_vision_tower().select_feature,
+        tower="clip" if "clip" in type(model.get_vision_tower().vision_tower).__name__.lower() else "siglip",
         hidden=lc.hidden_size, inter=lc.intermediate_size, layers=lc.num_hidden_layers,
         heads=lc.num_attention_heads, kv_heads=lc.num_key_value_heads, vocab=model.llm.get_input_embeddings().weight.shape[0],
         rms_eps=lc.rms_norm_eps, rope_theta=float(lc.rope_parameters["rope_theta"]) if hasattr(lc, "rope_parameters") else float(lc.rope_theta),
@@ -127,10 +133,14 @@ def tensor_np(t):
     return t.numpy()
 
 
-def mint_model_case(dtype: torch.dtype, fname: str, max_new_tokens=12):
+def mint_model_case(dtype: torch.dtype, fname: str, max_new_tokens=12, tower="siglip"):
     print(f"== {fname}")
     with tempfile.TemporaryDirectory() as td:
-        model, tok = rh.build_tiny_reference_model(td, llm=TINY_LLM, vit=TINY_VIT, dtype="torch.float32", seed=0)
+        if tower == "clip":  # CLIP-L/336 style: 577 tokens, select_feature "patch" -> 576 = 24^2
+            model, tok = rh.build_tiny_reference_model(td, llm=TINY_LLM, vit=TINY_CLIP, dtype="torch.float32", seed=0,
+                                                       tower="clip", select_feature="patch")
+        else:
+            model, tok = rh.build_tiny_reference_model(td, llm=TINY_LLM, vit=TINY_VIT, dtype="torch.float32", seed=0)
     # make norm gains / biases non-trivial so that parity checks see them
     g = torch.Generator().manual_seed(123)
     with torch.no_grad():
@@ -305,4 +315,5 @@ if __name__ == "__main__":
     mint_tokenizer_kat()
     mint_model_case(torch.float32, "tiny_fp32.npz")
     mint_model_case(torch.bfloat16, "tiny_bf16.npz")
+    mint_model_case(torch.float32, "tiny_clip_fp32.npz", tower="clip")
     print("golden vectors written to", GOLD)

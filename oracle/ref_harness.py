@@ -143,17 +143,19 @@ def _write_tiny_tokenizer(path: str, vocab_size: int) -> None:
                    "model_max_length": 4096, "legacy": False}, f)
 
 
-def build_tiny_reference_model(workdir: str, *, llm: dict, vit: dict, dtype: str = "torch.float32", seed: int = 0):
+def build_tiny_reference_model(workdir: str, *, llm: dict, vit: dict, dtype: str = "torch.float32", seed: int = 0,
+                               tower: str = "siglip", select_feature: str = "cls_patch"):
     """Build the reference `LlavaLlamaModel` (llava/model/language_model/llava_llama.py:48) from tiny,
     seeded, randomly initialised sub-models written under `workdir`.  Mirrors what
     `load_pretrained_model` (llava/model/builder.py:141-204) does after construction."""
     install_shims()
     import torch
-    from transformers import LlamaConfig, LlamaForCausalLM, SiglipVisionConfig, SiglipVisionModel
+    from transformers import (CLIPVisionConfig, CLIPVisionModel, LlamaConfig, LlamaForCausalLM, SiglipVisionConfig,
+                              SiglipVisionModel)
 
     torch.manual_seed(seed)
     llm_dir = os.path.join(workdir, "llm")
-    vit_dir = os.path.join(workdir, "siglip_tower")
+    vit_dir = os.path.join(workdir, f"{tower}_tower")  # the reference dispatches on "clip" / "siglip" in the path
     os.makedirs(workdir, exist_ok=True)
 
     lcfg = LlamaConfig(**llm)
@@ -162,15 +164,26 @@ def build_tiny_reference_model(workdir: str, *, llm: dict, vit: dict, dtype: str
     lm.save_pretrained(llm_dir)
     _write_tiny_tokenizer(llm_dir, vocab_size=llm["vocab_size"] - 8)
 
-    vcfg = SiglipVisionConfig(**vit)
-    vcfg.architectures = ["SiglipVisionModel"]
-    vm = SiglipVisionModel(vcfg).to(torch.float32)
+    if tower == "clip":
+        vcfg = CLIPVisionConfig(**vit)
+        vcfg.architectures = ["CLIPVisionModel"]
+        vm = CLIPVisionModel(vcfg).to(torch.float32)
+        pp = {"image_processor_type": "CLIPImageProcessor", "do_resize": True, "size": {"shortest_edge": vit["image_size"]},
+              "do_center_crop": True, "crop_size": {"height": vit["image_size"], "width": vit["image_size"]},
+              "do_rescale": True, "rescale_factor": 1 / 255.0, "do_normalize": True,
+              "image_mean": [0.48145466, 0.4578275, 0.40821073], "image_std": [0.26862954, 0.26130258, 0.27577711],
+              "resample": 3, "do_convert_rgb": True}
+    else:
+        vcfg = SiglipVisionConfig(**vit)
+        vcfg.architectures = ["SiglipVisionModel"]
+        vm = SiglipVisionModel(vcfg).to(torch.float32)
+        pp = {"image_processor_type": "SiglipImageProcessor", "do_resize": True,
+              "size": {"height": vit["image_size"], "width": vit["image_size"]},
+              "do_rescale": True, "rescale_factor": 1 / 255.0, "do_normalize": True,
+              "image_mean": [0.5, 0.5, 0.5], "image_std": [0.5, 0.5, 0.5], "resample": 3}
     vm.save_pretrained(vit_dir)
     with open(os.path.join(vit_dir, "preprocessor_config.json"), "w") as f:
-        json.dump({"image_processor_type": "SiglipImageProcessor", "do_resize": True,
-                   "size": {"height": vit["image_size"], "width": vit["image_size"]},
-                   "do_rescale": True, "rescale_factor": 1 / 255.0, "do_normalize": True,
-                   "image_mean": [0.5, 0.5, 0.5], "image_std": [0.5, 0.5, 0.5], "resample": 3}, f)
+        json.dump(pp, f)
 
     from llava.model import LlavaLlamaConfig, LlavaLlamaModel
 
@@ -178,7 +191,7 @@ def build_tiny_reference_model(workdir: str, *, llm: dict, vit: dict, dtype: str
         llm_cfg=llm_dir, vision_tower_cfg=vit_dir, mm_projector_cfg="mlp_downsample",
         region_extractor_cfg="regiongpt", architectures=["LlavaLlamaModel"], enable_region=True, enable_depth=True,
         resume_path=None, hidden_size=None, mm_hidden_size=None, image_aspect_ratio="resize",
-        num_video_frames=None, fps=None, mm_vision_select_layer=-2, mm_vision_select_feature="cls_patch",
+        num_video_frames=None, fps=None, mm_vision_select_layer=-2, mm_vision_select_feature=select_feature,
         mm_use_im_start_end=False, mm_use_im_patch_token=False, mm_projector_lr=None, vision_resolution=None,
         interpolate_mode=None, s2=None, s2_scales=None, s2_max_split_size=None,
     )
@@ -187,7 +200,7 @@ def build_tiny_reference_model(workdir: str, *, llm: dict, vit: dict, dtype: str
         llm_cfg=llm_dir, vision_tower_cfg=vit_dir, mm_projector_cfg="mlp_downsample",
         region_extractor_cfg="regiongpt", enable_region=True, enable_depth=True, resume_path=None,
         hidden_size=None, mm_hidden_size=None, image_aspect_ratio="resize", num_video_frames=None, fps=None,
-        mm_vision_select_layer=-2, mm_vision_select_feature="cls_patch", mm_use_im_start_end=False,
+        mm_vision_select_layer=-2, mm_vision_select_feature=select_feature, mm_use_im_start_end=False,
         mm_use_im_patch_token=False, mm_projector_lr=None, vision_resolution=None, interpolate_mode=None,
         s2=None, s2_scales=None, s2_max_split_size=None, model_dtype=dtype,
     ).items():

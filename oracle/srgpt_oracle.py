@@ -44,6 +44,8 @@ class SrgptConfig:
     patch_size: int = 14
     vit_eps: float = 1e-6
     select_layer: int = -2  # scripts/srgpt/llama3_8b/3_sft.sh:30
+    select_feature: str = "cls_patch"  # "patch" drops token 0 (vision_encoder.py:26-34)
+    tower: str = "siglip"  # or "clip" (multimodal_encoder/clip_encoder.py: HF CLIPVisionModel)
     # language model (HF LlamaConfig fields)
     hidden: int = 4096
     inter: int = 14336
@@ -93,10 +95,16 @@ LM = "llm."
 def vit_forward(w: Dict[str, torch.Tensor], cfg: SrgptConfig, images: torch.Tensor) -> torch.Tensor:
     """images [N,3,S,S] -> hidden_states[select_layer] = [N, grid^2, C] cast back to images.dtype."""
     wd = w[VT + "embeddings.patch_embedding.weight"].dtype
-    x = F.conv2d(images.to(wd), w[VT + "embeddings.patch_embedding.weight"], w[VT + "embeddings.patch_embedding.bias"],
-                 stride=cfg.patch_size)
+    clip = cfg.tower == "clip"
+    x = F.conv2d(images.to(wd), w[VT + "embeddings.patch_embedding.weight"],
+                 None if clip else w[VT + "embeddings.patch_embedding.bias"], stride=cfg.patch_size)
     x = x.flatten(2).transpose(1, 2)  # [N, L, C]
+    if clip:  # HF CLIPVisionEmbeddings + pre_layrnorm (sic)
+        cls = w[VT + "embeddings.class_embedding"].expand(x.shape[0], 1, -1)
+        x = torch.cat([cls, x], dim=1)
     x = x + w[VT + "embeddings.position_embedding.weight"][None]
+    if clip:
+        x = F.layer_norm(x, (cfg.vit_hidden,), w[VT + "pre_layrnorm.weight"], w[VT + "pre_layrnorm.bias"], cfg.vit_eps)
     # hidden_states = (embeddings, out_0, ..., out_{L-1}); [-2] is the output of layer L-2 (SURVEY 9.7)
     n_run = cfg.vit_layers + 1 + cfg.select_layer if cfg.select_layer < 0 else cfg.select_layer
     H, hd = cfg.vit_heads, cfg.vit_head_dim
@@ -116,10 +124,17 @@ def vit_forward(w: Dict[str, torch.Tensor], cfg: SrgptConfig, images: torch.Tens
         r = x
         h = F.layer_norm(x, (cfg.vit_hidden,), w[p + "layer_norm2.weight"], w[p + "layer_norm2.bias"], cfg.vit_eps)
         h = F.linear(h, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"])
-        h = F.gelu(h, approximate="tanh")  # SigLIP hidden_act = gelu_pytorch_tanh
+        if clip:
+            h = h * torch.sigmoid(1.702 * h)  # CLIP hidden_act = quick_gelu
+        else:
+            h = F.gelu(h, approximate="tanh")  # SigLIP hidden_act = gelu_pytorch_tanh
         h = F.linear(h, w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"])
         x = r + h
-    return x.to(images.dtype)  # vision_encoder.py:130; select_feature == "cls_patch" keeps all tokens
+    if cfg.select_feature == "patch":
+        x = x[:, 1:]
+    elif cfg.select_feature != "cls_patch":
+        raise ValueError(f"Unexpected select feature: {cfg.select_feature}")
+    return x.to(images.dtype)  # vision_encoder.py:130
 
 
 # ------------------------------------------------------------------------------------------------
@@ -495,8 +510,13 @@ def weight_shapes(cfg: SrgptConfig) -> Dict[str, tuple]:
     d = cfg.head_dim
     s: Dict[str, tuple] = {}
     s[VT + "embeddings.patch_embedding.weight"] = (C, 3, cfg.patch_size, cfg.patch_size)
-    s[VT + "embeddings.patch_embedding.bias"] = (C,)
-    s[VT + "embeddings.position_embedding.weight"] = (cfg.grid ** 2, C)
+    if cfg.tower == "clip":
+        s[VT + "embeddings.class_embedding"] = (C,)
+        s[VT + "pre_layrnorm.weight"] = (C,)
+        s[VT + "pre_layrnorm.bias"] = (C,)
+    else:
+        s[VT + "embeddings.patch_embedding.bias"] = (C,)
+    s[VT + "embeddings.position_embedding.weight"] = (cfg.grid ** 2 + (1 if cfg.tower == "clip" else 0), C)
     for i in range(cfg.vit_layers):
         p = f"{VT}encoder.layers.{i}."
         for n in ("layer_norm1", "layer_norm2"):
@@ -548,13 +568,13 @@ def synth_weights(cfg: SrgptConfig, seed: int = 0, dtype=torch.float32, device="
     g = torch.Generator(device="cpu").manual_seed(seed)
     w = {}
     for name, shape in weight_shapes(cfg).items():
-        is_gain = name.endswith("norm.weight") or name.endswith("layernorm.weight") or \
+        is_gain = name.endswith("norm.weight") or name.endswith("layernorm.weight") or name.endswith("layrnorm.weight") or \
             name.endswith("layer_norm1.weight") or name.endswith("layer_norm2.weight") or \
             name in (RE + "feature_refinement_module.1.weight", MP + "1.weight")
         t = torch.randn(shape, generator=g, dtype=torch.float32) * std
         if is_gain:
             t = t + 1.0
-        if "position_embedding" in name or "embed_tokens" in name:
+        if "position_embedding" in name or "embed_tokens" in name or "class_embedding" in name:
             t = t * (1.0 / std) * 0.5  # O(1)-ish embeddings keep activations away from denormal land
         w[name] = t.to(dtype).to(device)
     return w

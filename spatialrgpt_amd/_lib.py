@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrgpt_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU = 0, 1, 2, 3
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU, ACT_QUICK_GELU = 0, 1, 2, 3, 4
 OUT_PLAIN, OUT_DECONV2X = 0, 1
 ERR_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_STATE = -1, -2, -3, -4
 
@@ -24,8 +24,8 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 class VitWeights(C.Structure):
     _fields_ = [
         ("dtype", i32), ("hidden", i32), ("inter", i32), ("heads", i32), ("n_layers_run", i32),
-        ("image_size", i32), ("patch", i32), ("kp", i32), ("eps", f32),
-        ("patch_w", vp), ("patch_b", vp), ("pos_emb", vp),
+        ("image_size", i32), ("patch", i32), ("kp", i32), ("act", i32), ("eps", f32),
+        ("patch_w", vp), ("patch_b", vp), ("pos_emb", vp), ("cls_emb", vp), ("pre_ln_w", vp), ("pre_ln_b", vp),
         ("ln1_w", C.POINTER(vp)), ("ln1_b", C.POINTER(vp)),
         ("wqkv", C.POINTER(vp)), ("bqkv", C.POINTER(vp)),
         ("wo", C.POINTER(vp)), ("bo", C.POINTER(vp)),
@@ -76,6 +76,7 @@ _SIGNATURES = {
     "srgpt_silu_mul": (i32, [vp, vp, i32, i32, i32, vp]),
     "srgpt_argmax": (i32, [vp, vp, i32, i32, vp]),
     "srgpt_prefetch": (i32, [vp, i64, i32, vp]),
+    "srgpt_vit_assemble_cls": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "srgpt_vit_ws_bytes": (i64, [C.POINTER(VitWeights), i32]),
     "srgpt_vit_forward": (i32, [C.POINTER(VitWeights), vp, vp, vp, i32, vp]),
     "srgpt_llm_ws_bytes": (i64, [C.POINTER(LlmWeights), i32, i32]),

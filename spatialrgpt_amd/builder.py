@@ -52,7 +52,12 @@ def config_from_checkpoint(model_path: str) -> SrgptConfig:
     vc = _read_json(os.path.join(model_path, "vision_tower", "config.json"))
     vc = vc.get("vision_config", vc)
     arch = (vc.get("architectures") or [vc.get("model_type", "")])[0].lower() if (vc.get("architectures") or vc.get("model_type")) else ""
-    if "siglip" not in arch and "siglip" not in str(top.get("vision_tower_cfg", "")).lower() and "siglip" not in vc.get("model_type", ""):
+    tname = (arch + " " + str(vc.get("model_type", ""))).lower()
+    if "siglip" in tname:
+        tower = "siglip"
+    elif "clip" in tname:
+        tower = "clip"
+    else:
         raise ValueError(f"Unknown vision tower: {arch or vc.get('model_type')}")  # multimodal_encoder/builder.py:46
     if top.get("mm_projector_cfg", {}).get("mm_projector_type", "mlp_downsample") != "mlp_downsample" \
             if isinstance(top.get("mm_projector_cfg"), dict) else False:
@@ -63,8 +68,8 @@ def config_from_checkpoint(model_path: str) -> SrgptConfig:
     return SrgptConfig(
         vit_hidden=vc["hidden_size"], vit_inter=vc["intermediate_size"], vit_layers=vc["num_hidden_layers"],
         vit_heads=vc["num_attention_heads"], image_size=vc["image_size"], patch_size=vc["patch_size"],
-        vit_eps=vc.get("layer_norm_eps", 1e-6), select_layer=top.get("mm_vision_select_layer", -2) or -2,
-        select_feature=top.get("mm_vision_select_feature", "cls_patch") or "cls_patch",
+        vit_eps=vc.get("layer_norm_eps", 1e-6 if tower == "siglip" else 1e-5), select_layer=top.get("mm_vision_select_layer", -2) or -2,
+        select_feature=top.get("mm_vision_select_feature", "cls_patch") or "cls_patch", tower=tower,
         hidden=lc["hidden_size"], inter=lc["intermediate_size"], layers=lc["num_hidden_layers"],
         heads=lc["num_attention_heads"], kv_heads=lc.get("num_key_value_heads", lc["num_attention_heads"]),
         vocab=lc["vocab_size"], rms_eps=lc.get("rms_norm_eps", 1e-5), rope_theta=float(lc.get("rope_theta", 10000.0)),

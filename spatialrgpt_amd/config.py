@@ -18,6 +18,7 @@ class SrgptConfig:
     vit_eps: float = 1e-6
     select_layer: int = -2            # mm_vision_select_layer (scripts/srgpt/llama3_8b/3_sft.sh)
     select_feature: str = "cls_patch"  # mm_vision_select_feature
+    tower: str = "siglip"              # "siglip" (SiglipVisionTower) or "clip" (CLIPVisionTower)
     # language model (Llama)
     hidden: int = 4096
     inter: int = 14336
@@ -53,6 +54,11 @@ class SrgptConfig:
         return self.image_size // self.patch_size
 
     @property
+    def tower_tokens(self) -> int:
+        """tokens per image inside the tower (CLIP prepends a class token)"""
+        return self.grid ** 2 + (1 if self.tower == "clip" else 0)
+
+    @property
     def vit_layers_run(self) -> int:
         """hidden_states[select_layer] = output of this many encoder layers."""
         return self.vit_layers + 1 + self.select_layer if self.select_layer < 0 else self.select_layer
@@ -74,6 +80,12 @@ class SrgptConfig:
     def llama2_7b(cls):
         return cls(hidden=4096, inter=11008, layers=32, heads=32, kv_heads=32, vocab=32002, rope_theta=10000.0,
                    mask_token_id=32000, depth_token_id=32001, max_position_embeddings=4096)
+
+    @classmethod
+    def clip_l14_336(cls, **llm):
+        """CLIP-L/14-336 tower (576 patch tokens with select_feature="patch") in front of any LLM."""
+        return cls(vit_hidden=1024, vit_inter=4096, vit_layers=24, vit_heads=16, image_size=336, patch_size=14, vit_eps=1e-5,
+                   tower="clip", select_feature="patch", **llm)
 
     @classmethod
     def sheared_3b(cls):

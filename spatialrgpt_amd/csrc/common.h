@@ -123,6 +123,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     case SRGPT_ACT_GELU_ERF: return gelu_erf(x);
     case SRGPT_ACT_GELU_TANH: return gelu_tanh(x);
     case SRGPT_ACT_SILU: return silu(x);
+    case SRGPT_ACT_QUICK_GELU: return x / (1.f + __expf(-1.702f * x));  // x * sigmoid(1.702 x)
     default: return x;
   }
 }

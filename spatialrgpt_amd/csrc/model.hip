@@ -28,7 +28,7 @@ struct VitWs {
 VitWs carve_vit(const srgpt_vit_weights* w, int n_img, void* ws) {
   const size_t es = dtype_size(w->dtype);
   const int g = w->image_size / w->patch;
-  const size_t rows = (size_t)n_img * g * g;
+  const size_t rows = (size_t)n_img * (g * g + (w->cls_emb ? 1 : 0));
   Carver c(ws);
   VitWs v;
   v.col = c.take(rows * w->kp * es);
@@ -193,13 +193,21 @@ extern "C" int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images,
   // image_size need not be a multiple of patch: a 'valid' conv drops the remainder (384 px / 14 -> 27 patches)
   SRGPT_CHECK(w->hidden % w->heads == 0 && w->image_size >= w->patch, SRGPT_ERR_ARG, "srgpt_vit_forward: bad config");
   const int dt = w->dtype, C = w->hidden, I = w->inter, H = w->heads, hd = C / H;
-  const int g = w->image_size / w->patch, L = g * g, rows = n_img * L;
+  const int g = w->image_size / w->patch, gg = g * g, L = gg + (w->cls_emb ? 1 : 0), rows = n_img * L;
   const VitWs v = carve_vit(w, n_img, ws);
   void* x = out;  // residual stream lives in the output buffer
   SRGPT_TRY(srgpt_im2col(images, v.col, n_img, w->image_size, w->patch, w->kp, dt, stream));
-  // conv-as-GEMM + bias, then + position embedding (row m uses pos_emb[m % L])
-  SRGPT_TRY(srgpt_gemm(v.col, w->patch_w, w->patch_b, w->pos_emb, x, rows, C, w->kp, w->kp, C, SRGPT_ACT_NONE, 0, L, 0,
-                       SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt, stream));
+  if (!w->cls_emb) {
+    // SigLIP: conv-as-GEMM + bias, then + position embedding (row m uses pos_emb[m % L])
+    SRGPT_TRY(srgpt_gemm(v.col, w->patch_w, w->patch_b, w->pos_emb, x, rows, C, w->kp, w->kp, C, SRGPT_ACT_NONE, 0, L, 0,
+                         SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt, stream));
+  } else {
+    // CLIP: patch GEMM (no bias) -> [cls | patches] + position embedding -> pre_layrnorm
+    SRGPT_TRY(srgpt_gemm(v.col, w->patch_w, w->patch_b, nullptr, v.h, n_img * gg, C, w->kp, w->kp, C, SRGPT_ACT_NONE, 0, 0, 0,
+                         SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt, stream));
+    SRGPT_TRY(srgpt_vit_assemble_cls(v.h, w->cls_emb, w->pos_emb, x, n_img, gg, C, dt, stream));
+    if (w->pre_ln_w) SRGPT_TRY(srgpt_layernorm(x, w->pre_ln_w, w->pre_ln_b, x, rows, C, w->eps, SRGPT_ACT_NONE, dt, stream));
+  }
   const float scale = 1.0f / sqrtf((float)hd);
   const char* qkv = reinterpret_cast<const char*>(v.qkv);
   const size_t es = dtype_size(dt);
@@ -213,7 +221,7 @@ extern "C" int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images,
     SRGPT_TRY(srgpt_gemm(v.h, w->wo[l], w->bo[l], x, x, rows, C, C, C, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt,
                          stream));
     SRGPT_TRY(srgpt_layernorm(x, w->ln2_w[l], w->ln2_b[l], v.h, rows, C, w->eps, SRGPT_ACT_NONE, dt, stream));
-    SRGPT_TRY(srgpt_gemm(v.h, w->w1[l], w->b1[l], nullptr, v.mlp, rows, I, C, C, I, SRGPT_ACT_GELU_TANH, 0, 0, 0,
+    SRGPT_TRY(srgpt_gemm(v.h, w->w1[l], w->b1[l], nullptr, v.mlp, rows, I, C, C, I, w->act, 0, 0, 0,
                          SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt, stream));
     SRGPT_TRY(srgpt_gemm(v.mlp, w->w2[l], w->b2[l], x, x, rows, C, I, I, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt,
                          stream));

@@ -182,6 +182,25 @@ __global__ void im2col_kernel(const T* __restrict__ img, T* __restrict__ out, in
   }
 }
 
+// CLIP embeddings: [cls | patches] + position embedding, one block per output token
+template <typename T>
+__global__ void vit_assemble_cls_kernel(const T* __restrict__ patches, const T* __restrict__ cls, const T* __restrict__ pos,
+                                        T* __restrict__ x, int gg, int C) {
+  constexpr int VEC = Vec16<T>::N;
+  const int t = blockIdx.x, img = blockIdx.y;
+  const T* src = (t == 0) ? cls : patches + ((size_t)img * gg + (t - 1)) * C;
+  const T* pe = pos + (size_t)t * C;
+  T* dst = x + ((size_t)img * (gg + 1) + t) * C;
+  for (int c = threadIdx.x; c < C / VEC; c += blockDim.x) {
+    const Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(src + c * VEC);
+    const Vec16<T> b = *reinterpret_cast<const Vec16<T>*>(pe + c * VEC);
+    Vec16<T> o;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o.set(i, a.get(i) + b.get(i));
+    *reinterpret_cast<Vec16<T>*>(dst + c * VEC) = o;
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t srgpt_region_pool_ws_floats(int M, int fw, int C) {
@@ -273,6 +292,16 @@ extern "C" int srgpt_im2col(const void* images, void* out, int n_img, int S, int
   const int gw = S / patch;
   RDISPATCH(dtype, hipLaunchKernelGGL(im2col_kernel<T>, dim3(gw * gw, n_img), dim3(256), 0, as_stream(stream),
                                       (const T*)images, (T*)out, S, patch, kp));
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
+
+extern "C" int srgpt_vit_assemble_cls(const void* patches, const void* cls_emb, const void* pos_emb, void* x, int n_img,
+                                      int gg, int C, int dtype, srgpt_stream_t stream) {
+  SRGPT_CHECK(patches && cls_emb && pos_emb && x && n_img > 0 && gg > 0 && C > 0, SRGPT_ERR_ARG, "srgpt_vit_assemble_cls: bad args");
+  SRGPT_CHECK(C % (dtype == SRGPT_BF16 ? 8 : 4) == 0, SRGPT_ERR_ARG, "srgpt_vit_assemble_cls: C not a 16-byte multiple");
+  RDISPATCH(dtype, hipLaunchKernelGGL(vit_assemble_cls_kernel<T>, dim3(gg + 1, n_img), dim3(128), 0, as_stream(stream),
+                                      (const T*)patches, (const T*)cls_emb, (const T*)pos_emb, (T*)x, gg, C));
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }

@@ -22,7 +22,7 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SRGPT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
@@ -49,6 +49,9 @@ def gather_ids(local_ids: torch.Tensor, pad_id: int = 0, group=None) -> torch.Te
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local_ids
     world = dist.get_world_size(group)
+    out_dev = local_ids.device
+    if dist.get_backend(group) == "gloo" and local_ids.is_cuda:
+        local_ids = local_ids.cpu()  # gloo moves host buffers; RCCL ("nccl") takes the device tensor directly
     dev = local_ids.device
     shape = torch.tensor(list(local_ids.shape) if local_ids.dim() == 2 else [0, 0], dtype=torch.int64, device=dev)
     shapes = [torch.zeros_like(shape) for _ in range(world)]
@@ -61,7 +64,7 @@ def gather_ids(local_ids: torch.Tensor, pad_id: int = 0, group=None) -> torch.Te
     bufs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(bufs, buf, group=group)
     rows = [b[:int(s[0])] for b, s in zip(bufs, shapes)]
-    return torch.cat(rows, dim=0) if rows else buf[:0]
+    return (torch.cat(rows, dim=0) if rows else buf[:0]).to(out_dev)
 
 
 def generate_data_parallel(model, requests: Sequence[dict], group=None, pad_id: int = 0, **gen_kwargs) -> torch.Tensor:

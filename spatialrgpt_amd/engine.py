@@ -99,8 +99,10 @@ class SrgptEngine:
         need = lib.srgpt_vit_ws_bytes(C.byref(self.w.vit), n)
         if self._vit_ws is None or self._vit_ws.numel() < need:
             self._vit_ws = torch.empty((need,), device=self.device, dtype=torch.uint8)
-        out = torch.empty((n, self.cfg.grid ** 2, self.cfg.vit_hidden), device=self.device, dtype=self.dtype)
+        out = torch.empty((n, self.cfg.tower_tokens, self.cfg.vit_hidden), device=self.device, dtype=self.dtype)
         L.check(lib.srgpt_vit_forward(C.byref(self.w.vit), x.data_ptr(), out.data_ptr(), self._vit_ws.data_ptr(), n, ops._stream()))
+        if self.cfg.select_feature == "patch":
+            out = out[:, 1:]  # feature_select drops token 0 whatever the tower (vision_encoder.py:28-29)
         return out.to(in_dtype)  # vision_encoder.py:130
 
     # ------------------------------------------------------------------ A2

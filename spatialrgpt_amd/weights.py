@@ -64,8 +64,14 @@ class PreparedWeights:
         patch_w = torch.zeros((C_, self.kp), device=self.device, dtype=dtype)
         patch_w[:, :kk] = pw
         self.patch_w = patch_w
-        self.patch_b = get(VT + "embeddings.patch_embedding.bias")
+        clip = cfg.tower == "clip"
+        self.patch_b = None if clip else get(VT + "embeddings.patch_embedding.bias")
         self.pos_emb = get(VT + "embeddings.position_embedding.weight")
+        if self.pos_emb.shape[0] != cfg.tower_tokens:
+            raise ValueError(f"position embedding has {self.pos_emb.shape[0]} rows, tower expects {cfg.tower_tokens}")
+        self.cls_emb = get(VT + "embeddings.class_embedding").reshape(-1) if clip else None
+        self.pre_ln_w = get(VT + "pre_layrnorm.weight") if clip else None
+        self.pre_ln_b = get(VT + "pre_layrnorm.bias") if clip else None
         n_run = cfg.vit_layers_run
         v = {k: [] for k in ("ln1_w", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")}
         for i in range(n_run):
@@ -86,7 +92,12 @@ class PreparedWeights:
         vw = L.VitWeights()
         vw.dtype, vw.hidden, vw.inter, vw.heads = code, C_, cfg.vit_inter, cfg.vit_heads
         vw.n_layers_run, vw.image_size, vw.patch, vw.kp, vw.eps = n_run, cfg.image_size, p, self.kp, cfg.vit_eps
-        vw.patch_w, vw.patch_b, vw.pos_emb = self.patch_w.data_ptr(), self.patch_b.data_ptr(), self.pos_emb.data_ptr()
+        vw.act = L.ACT_QUICK_GELU if clip else L.ACT_GELU_TANH
+        vw.patch_w, vw.pos_emb = self.patch_w.data_ptr(), self.pos_emb.data_ptr()
+        vw.patch_b = None if self.patch_b is None else self.patch_b.data_ptr()
+        vw.cls_emb = None if self.cls_emb is None else self.cls_emb.data_ptr()
+        vw.pre_ln_w = None if self.pre_ln_w is None else self.pre_ln_w.data_ptr()
+        vw.pre_ln_b = None if self.pre_ln_b is None else self.pre_ln_b.data_ptr()
         for k, ts in v.items():
             arr = _ptr_array(ts)
             self._keep.append(arr)
@@ -154,8 +165,13 @@ def weight_shapes(cfg: SrgptConfig) -> Dict[str, tuple]:
     C_, I, H, F_, V, d = cfg.vit_hidden, cfg.vit_inter, cfg.hidden, cfg.inter, cfg.vocab, cfg.head_dim
     s: Dict[str, tuple] = {}
     s[VT + "embeddings.patch_embedding.weight"] = (C_, 3, cfg.patch_size, cfg.patch_size)
-    s[VT + "embeddings.patch_embedding.bias"] = (C_,)
-    s[VT + "embeddings.position_embedding.weight"] = (cfg.grid ** 2, C_)
+    if cfg.tower == "clip":
+        s[VT + "embeddings.class_embedding"] = (C_,)
+        s[VT + "pre_layrnorm.weight"] = (C_,)
+        s[VT + "pre_layrnorm.bias"] = (C_,)
+    else:
+        s[VT + "embeddings.patch_embedding.bias"] = (C_,)
+    s[VT + "embeddings.position_embedding.weight"] = (cfg.tower_tokens, C_)
     for i in range(cfg.vit_layers_run):  # layers past select_layer never influence the output
         p = f"{VT}encoder.layers.{i}."
         for n in ("layer_norm1", "layer_norm2"):
@@ -208,9 +224,9 @@ def synth_state_dict(cfg: SrgptConfig, seed: int, dtype, device, std: float = 0.
     sd = {}
     for name, shape in weight_shapes(cfg).items():
         t = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
-        is_gain = name.endswith(("norm.weight", "layernorm.weight", "layer_norm1.weight", "layer_norm2.weight")) or \
+        is_gain = name.endswith(("norm.weight", "layernorm.weight", "layrnorm.weight", "layer_norm1.weight", "layer_norm2.weight")) or \
             name in (RE + "feature_refinement_module.1.weight", MP + "1.weight")
-        if "position_embedding" in name or "embed_tokens" in name:
+        if "position_embedding" in name or "embed_tokens" in name or "class_embedding" in name:
             t = t * 0.5
         elif is_gain:
             t = 1.0 + t * std

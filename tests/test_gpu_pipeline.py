@@ -26,7 +26,7 @@ def _to_dev(inp):
                 masks=[m.to(DEV) for m in inp["masks"]])
 
 
-@pytest.mark.parametrize("name,rel", [("tiny_fp32.npz", 2e-4), ("tiny_bf16.npz", 3e-2)])
+@pytest.mark.parametrize("name,rel", [("tiny_fp32.npz", 2e-4), ("tiny_bf16.npz", 3e-2), ("tiny_clip_fp32.npz", 2e-4)])
 def test_stages_match_reference_golden(name, rel):
     model, cfg, dtype, w, inp, ref = _engine(name)
     d = _to_dev(inp)
@@ -57,9 +57,11 @@ def test_stages_match_reference_golden(name, rel):
     chk(stt.logits, ref["prefill_logits"][:, -1], "last-position logits (GEMV path)", 2)
 
 
-def test_greedy_ids_bit_exact_fp32():
-    """BASELINE config 1: tiny model, greedy decode -- token ids identical to the reference's generate()."""
-    model, cfg, dtype, w, inp, ref = _engine("tiny_fp32.npz")
+@pytest.mark.parametrize("name", ["tiny_fp32.npz", "tiny_clip_fp32.npz"])
+def test_greedy_ids_bit_exact_fp32(name):
+    """BASELINE config 1: tiny model, greedy decode -- token ids identical to the reference's generate()
+    (SigLIP tower and CLIP-336-style tower with select_feature="patch")."""
+    model, cfg, dtype, w, inp, ref = _engine(name)
     d = _to_dev(inp)
     n = ref["new_ids"].shape[1]
     out = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], do_sample=False,

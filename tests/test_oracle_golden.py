@@ -13,7 +13,8 @@ def _cfg(d):
     return so.SrgptConfig(**{k: v for k, v in d.items() if k in names})
 
 
-@pytest.mark.parametrize("name,atol,rtol", [("tiny_fp32.npz", 1e-5, 1e-5), ("tiny_bf16.npz", 0.0, 2e-2)])
+@pytest.mark.parametrize("name,atol,rtol", [("tiny_fp32.npz", 1e-5, 1e-5), ("tiny_bf16.npz", 0.0, 2e-2),
+                                            ("tiny_clip_fp32.npz", 1e-5, 1e-5)])
 def test_oracle_reproduces_reference_stages(name, atol, rtol):
     cfgd, dtype, w, inp, ref = load_tiny(name)
     cfg = _cfg(cfgd)
