@@ -7,7 +7,7 @@ from spatialrgpt_amd import ops
 
 dev = "cuda"
 torch.manual_seed(0)
-shapes = [("qkv+norm", 6144, 4096, dict(norm=True)), ("o", 4096, 4096, {}), ("gateup+norm", 14336, 4096, dict(norm=True, swiglu=True)), ("n2048", 2048, 4096, {})]
+shapes = [("qkv+norm", 6144, 4096, dict(norm=True)), ("o+res", 4096, 4096, dict(res=True)), ("gateup+norm", 14336, 4096, dict(norm=True, swiglu=True)), ("down+res", 4096, 14336, dict(res=True)), ("n2048", 2048, 4096, {})]
 L = 32
 side = torch.cuda.Stream()
 for name, N, K, opt in shapes:

@@ -1,0 +1,108 @@
+// Which ingredient of the decode GEMV costs the ~2.5 us of extra fixed time over a plain streaming read?
+// Variants morph a streaming kernel toward the GEMV: row-per-wave mapping, in-flight depth, LDS prologue, FMA, reduce+store.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+// V: 0 grid-stride 4 in flight | 1 row-per-wave, DEPTH loads in flight, no compute | 2 +LDS prologue | 3 +FMA | 4 +reduce/store
+template <int V, int DEPTH>
+__global__ __launch_bounds__(256, 2) void k(const u4* __restrict__ W, const u4* __restrict__ x, float* __restrict__ out, int N, int K16) {
+  __shared__ u4 xs[2048];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (V == 0) {
+    unsigned acc = 0;
+    const size_t n16 = (size_t)N * K16, stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + tid;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+      u4 a = __builtin_nontemporal_load(W + i), b = __builtin_nontemporal_load(W + i + stride), c = __builtin_nontemporal_load(W + i + 2 * stride), d = __builtin_nontemporal_load(W + i + 3 * stride);
+      acc ^= a[0] ^ b[1] ^ c[2] ^ d[3];
+    }
+    if (acc == 0x12345u) out[0] = 1.f;
+    return;
+  }
+  if (V >= 2) {
+    for (int c = tid; c < K16; c += 256) xs[c] = x[c];
+    __syncthreads();
+  }
+  const int nit = K16 / 64;  // chunk iterations per row
+  float facc = 0.f;
+  unsigned uacc = 0;
+  for (int row = blockIdx.x * 4 + wave; row < N; row += gridDim.x * 4) {
+    const u4* p = W + (size_t)row * K16;
+    for (int it0 = 0; it0 < nit; it0 += DEPTH) {
+      u4 r[DEPTH];
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) r[j] = __builtin_nontemporal_load(p + (it0 + j) * 64 + lane);
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        if (V >= 3) {
+          const u4 xv = xs[(it0 + j) * 64 + lane];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            facc = fmaf(__uint_as_float(r[j][q] << 16), __uint_as_float(xv[q] << 16), facc);
+            facc = fmaf(__uint_as_float(r[j][q] & 0xffff0000u), __uint_as_float(xv[q] & 0xffff0000u), facc);
+          }
+        } else {
+          uacc ^= r[j][0] ^ r[j][3];
+        }
+      }
+    }
+    if (V >= 4) {
+      float s = facc;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (lane == 0) out[row] = s;
+      facc = 0.f;
+    }
+  }
+  if (V < 4 && (uacc == 0x12345u || facc == 1.2345f)) out[0] = 1.f;
+}
+
+__global__ void fill_random(unsigned* p, size_t n, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    // two bf16 values ~ N(0, small): random sign/mantissa, exponent around 2^-6
+    p[i] = (h & 0x807f807fu) | 0x3c003c00u;
+  }
+}
+
+template <int V, int DEPTH>
+int run(const char* name, hipStream_t s, std::vector<u4*>& Ws, u4* x, float* out, int N, int K) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipGraph_t g; hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  for (auto W : Ws) hipLaunchKernelGGL((k<V, DEPTH>), dim3(512), dim3(256), 0, s, W, x, out, N, K / 8);
+  CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  float ms = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  const double us = ms * 1e3 / Ws.size(), mb = (double)N * K * 2 / 1e6;
+  printf("  %-44s %7.2f us  (%.2f TB/s; fixed vs 7.05 TB/s %5.2f us)\n", name, us, mb / us, us - mb / 7.05);
+  return 0;
+}
+
+int main() {
+  hipStream_t s; CK(hipStreamCreate(&s));
+  for (int cfg = 0; cfg < 2; ++cfg) {
+    const int N = cfg == 0 ? 4096 : 14336, K = 4096, L = 24;
+    std::vector<u4*> Ws(L);
+    for (auto& W : Ws) { CK(hipMalloc(&W, (size_t)N * K * 2)); hipLaunchKernelGGL(fill_random, dim3(2048), dim3(256), 0, s, (unsigned*)W, (size_t)N * K / 2, (unsigned)(size_t)W); }
+    CK(hipStreamSynchronize(s));
+    u4* x; CK(hipMalloc(&x, K * 2)); CK(hipMemset(x, 0x3c, K * 2));
+    float* out; CK(hipMalloc(&out, N * 4));
+    printf("N=%d K=%d (%.1f MB per launch)\n", N, K, (double)N * K * 2 / 1e6);
+    run<0, 4>("V0 grid-stride, 4 in flight", s, Ws, x, out, N, K);
+    run<1, 4>("V1 row/wave, 4 in flight, no compute", s, Ws, x, out, N, K);
+    run<1, 8>("V1 row/wave, 8 in flight", s, Ws, x, out, N, K);
+    run<2, 8>("V2 + LDS x prologue (barrier)", s, Ws, x, out, N, K);
+    run<3, 8>("V3 + bf16 FMA on the data", s, Ws, x, out, N, K);
+    run<4, 8>("V4 + wave reduce + store", s, Ws, x, out, N, K);
+    run<4, 4>("V4 depth 4", s, Ws, x, out, N, K);
+    for (auto W : Ws) CK(hipFree(W));
+  }
+  return 0;
+}

@@ -4,13 +4,12 @@
 // wave-instruction per row chunk); x lives in LDS; fp32 accumulate on the VALU (24 lane-ops per 16 B --
 // ~12 % of VALU issue at HBM rate, so no MFMA reshaping).
 //
-// Work decomposition: a unit = one output row (plain) or one (gate row, up row) pair (SwiGLU); each wave
-// owns units grid-strided, each unit's K range is cut into batches of 8 row chunks (8 KiB per wave).
-// The (unit, batch) sequence of a wave is flattened and software-pipelined THREE batches deep
-// (cur / n1 / n2 registers): 16 chunk loads stay in flight per wave while 8 are consumed, the stream
-// never drains at row boundaries, and the first two batches are issued BEFORE the activation / RMSNorm
-// prologue, so short matrices (o_proj: 2 batches per wave) pay a single memory latency.
-// Grid = 2 blocks per CU (8 waves/CU, ~128 KiB in flight per CU).
+// Work decomposition: a unit = one output row (plain) or one (gate row, up row) pair (SwiGLU); each wave owns
+// units grid-strided; per unit the K range is walked in batches of 8 row chunks: 8 independent 1-KiB loads are
+// issued back to back, then consumed in order with counted waits.  No cross-batch software pipeline: measured
+// (scripts/ubench_stream.hip, ubench_gemv_ts.hip) a 3-deep register pipeline with 16+ loads in flight per wave
+// was 2-3 us SLOWER per launch -- 8 waves/CU x 8 KiB already saturate HBM, and the independent waves of a CU
+// drift apart so that some stream while others multiply.  Grid = 2 blocks per CU.
 //
 // Fusions (include/srgpt.h): RMSNorm prologue (LlamaRMSNorm), SwiGLU epilogue, residual add, fp32 logits.
 // Rounding points mirror PyTorch's bf16 materialisation of each intermediate.
@@ -58,142 +57,106 @@ struct WChunk<float> {
   }
 };
 
-template <typename T, int B, bool SWIGLU, int NX>
+template <typename T, int B, bool SWIGLU, int NXMAX>
 __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, const T* __restrict__ W,
                                                       const T* __restrict__ norm_w, float norm_eps,
                                                       const T* __restrict__ residual, void* __restrict__ out, int N,
                                                       int K, int out_f32) {
   constexpr int VEC = WChunk<T>::VEC;
   constexpr int R = SWIGLU ? 2 : 1;  // weight rows per unit
-  constexpr int U = 8 / R;           // K-chunks per row per batch (8 loads per batch)
+  constexpr int U = 8 / R;           // K-chunks per row per batch: 8 loads (8 KiB per wave) in flight, then consumed
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);  // [B][K]
   __shared__ float red[16];
+  constexpr int RES_MAXU = 4;  // residual elements of a wave's first 4 units are staged through LDS by the prologue
+  __shared__ float res_s[B][4][RES_MAXU];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunks = K / VEC;          // 16-byte chunks per row
   const int nit = (nchunks + 63) >> 6;  // chunk iterations per row (64 lanes each)
-  const int NB = (nit + U - 1) / U;     // batches per unit
-  const int units = N;
-  const int wstride = gridDim.x * 4;
-
-  struct Cursor {
-    int unit, b;
-  };
-  auto advance = [&](Cursor c) {
-    Cursor n{c.unit, c.b + 1};
-    if (n.b == NB) {
-      n.b = 0;
-      n.unit += wstride;
-    }
-    return n;
-  };
-  // loads are UNCONDITIONAL (indices clamped, surplus data discarded by the consumer): straight-line code lets
-  // the compiler emit counted s_waitcnt vmcnt(N) instead of draining the queue at every use
-  auto load = [&](Cursor c, u32x4 (&dst)[R][U]) {
-    // dead cursors (past the wave's last unit) must issue NOTHING: redundant loads to a clamped address hot-spot
-    // one L2 channel and were measured to add microseconds to every launch.  The branch is scalar (readfirstlane).
-    const int u = __builtin_amdgcn_readfirstlane(c.unit);
-    if (u < units) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(u + r * N) * K);
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          const int ch = min((c.b * U + j) * 64 + lane, nchunks - 1);
-          dst[r][j] = __builtin_nontemporal_load(p + ch);
-        }
-      }
-    }
-  };
-
-  u32x4 cur[R][U], n1[R][U], n2[R][U];
   SRGPT_TS(0);
-  Cursor c0{(int)blockIdx.x * 4 + wave, 0};
-  Cursor c1 = advance(c0), c2 = advance(c1);
-  // ---- prologue: stage x (and RMSNorm it) into LDS.
-  // Program order matters: vmcnt retires in order, so the (L2-resident) activation and gain loads are issued
-  // FIRST and the two weight batches right after them -- the prologue then waits only for its own small loads
-  // while 16 KiB of weights per wave are already in flight.
-  // NX = activation chunks per thread held in registers (host picks 2 or 8; covers B*K <= NX*2048 elements)
-  const int total = B * nchunks;
-  Vec16<T> xr[NX], gr[NX];
-#pragma unroll
-  for (int j = 0; j < NX; ++j) {
-    const int c = min(tid + 256 * j, total - 1);
-    xr[j] = *reinterpret_cast<const Vec16<T>*>(x + (size_t)c * VEC);
-  }
-  if (norm_w) {
-#pragma unroll
-    for (int j = 0; j < NX; ++j) {
-      const int c = min(tid + 256 * j, total - 1);
-      gr[j] = *reinterpret_cast<const Vec16<T>*>(norm_w + (size_t)(c % nchunks) * VEC);
-    }
-  }
-  load(c0, n1);
-  load(c1, n2);
-  SRGPT_TS(1);
+
+  // ---- prologue: stage x (and RMSNorm it) into LDS ----
+  // All global loads of the prologue (activation chunks AND norm gains) are issued up front, branch-free, so the
+  // block pays one L2 latency.  NXMAX (2 or 8, picked by the host) = chunks per thread held in registers; unused
+  // slots wrap around to valid chunks (a clamped address would hot-spot one cache line from every thread of the
+  // grid); chunks beyond NXMAX*256 (B*K > 16384 elements) take the generic loop.
   {
+    const int total = B * nchunks;
+    const bool do_norm = norm_w != nullptr;
+    Vec16<T> xr[NXMAX], gr[NXMAX];
+    // residual elements this block will need: fetched with the prologue's loads (a load placed next to its use at
+    // the end of a row gets sunk behind the weight stream by the compiler and exposes a full memory latency per row)
+    float res_pre = 0.f;
+    const int rb = tid / (4 * RES_MAXU), rw = (tid / RES_MAXU) & 3, rk = tid % RES_MAXU;
+    const int runit = (int)blockIdx.x * 4 + rw + rk * (int)gridDim.x * 4;
+    const bool rok = !SWIGLU && residual != nullptr && tid < B * 4 * RES_MAXU && runit < N;
+    if (!SWIGLU && residual != nullptr) res_pre = to_f(residual[rok ? (size_t)rb * N + runit : 0]);
+#pragma unroll
+    for (int j = 0; j < NXMAX; ++j) {
+      const int c = (tid + 256 * j) % total;
+      xr[j] = *reinterpret_cast<const Vec16<T>*>(x + (size_t)c * VEC);
+      gr[j] = *reinterpret_cast<const Vec16<T>*>((do_norm ? norm_w : x) + (size_t)(c % nchunks) * VEC);
+    }
     float ss[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) ss[b] = 0.f;
 #pragma unroll
-    for (int j = 0; j < NX; ++j) {
+    for (int j = 0; j < NXMAX; ++j) {
       const int c = tid + 256 * j;
-      if (c < total) {
-        if (norm_w) {
-          const int b = c / nchunks;
-          float sq = 0.f;
+      const bool ok = c < total;
+      float sq = 0.f;
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) sq += xr[j].get(i) * xr[j].get(i);
+      for (int i = 0; i < VEC; ++i) sq += xr[j].get(i) * xr[j].get(i);
+      const int b = (B == 1) ? 0 : (c % total) / nchunks;
 #pragma unroll
-          for (int bb = 0; bb < B; ++bb)
-            if (bb == b) ss[bb] += sq;
-        } else {
-          *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC) = xr[j];
-        }
-      }
+      for (int bb = 0; bb < B; ++bb) ss[bb] += (ok && bb == b) ? sq : 0.f;
     }
-    for (int c = tid + 256 * NX; c < total; c += 256) {  // rare: B*K > 16384
-      Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(x + (size_t)c * VEC);
+    for (int c = tid + 256 * NXMAX; c < total; c += 256) {  // rare
+      const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(x + (size_t)c * VEC);
       *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC) = v;
-      if (norm_w) {
-        const int b = c / nchunks;
-        float sq = 0.f;
+      const int b = c / nchunks;
+      float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) sq += v.get(i) * v.get(i);
+      for (int i = 0; i < VEC; ++i) sq += v.get(i) * v.get(i);
 #pragma unroll
-        for (int bb = 0; bb < B; ++bb)
-          if (bb == b) ss[bb] += sq;
-      }
+      for (int bb = 0; bb < B; ++bb)
+        if (bb == b) ss[bb] += sq;
     }
-    if (norm_w) {
-      float rs[B];
+    if (rok) res_s[rb][rw][rk] = res_pre;
+    float rs[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) rs[b] = 1.f;
+    if (do_norm) {
 #pragma unroll
       for (int b = 0; b < B; ++b) rs[b] = rsqrtf(block_sum(ss[b], red) / (float)K + norm_eps);
-      auto pick = [&](int b) {
+    }
+#pragma unroll
+    for (int j = 0; j < NXMAX; ++j) {
+      const int c = tid + 256 * j;
+      if (c < total) {
+        Vec16<T> v = xr[j];
+        if (do_norm) {
+          const int b = (B == 1) ? 0 : c / nchunks;
+          float r = rs[0];
+#pragma unroll
+          for (int bb = 1; bb < B; ++bb)
+            if (bb == b) r = rs[bb];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) v.set(i, gr[j].get(i) * rnd<T>(xr[j].get(i) * r));  // weight * h.to(dtype)
+        }
+        *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC) = v;
+      }
+    }
+    if (do_norm) {
+      for (int c = tid + 256 * NXMAX; c < total; c += 256) {  // rare; each thread re-reads the chunks it wrote itself
+        const int b = c / nchunks, kc = c - b * nchunks;
+        Vec16<T> v = *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC);
+        const Vec16<T> g = *reinterpret_cast<const Vec16<T>*>(norm_w + (size_t)kc * VEC);
         float r = rs[0];
 #pragma unroll
         for (int bb = 1; bb < B; ++bb)
           if (bb == b) r = rs[bb];
-        return r;
-      };
-#pragma unroll
-      for (int j = 0; j < NX; ++j) {
-        const int c = tid + 256 * j;
-        if (c < total) {
-          const float r = pick(c / nchunks);
-          Vec16<T> v;
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) v.set(i, gr[j].get(i) * rnd<T>(xr[j].get(i) * r));  // weight * h.to(dtype)
-          *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC) = v;
-        }
-      }
-      for (int c = tid + 256 * NX; c < total; c += 256) {
-        const int b = c / nchunks, kc = c - b * nchunks;
-        Vec16<T> v = *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC);  // written by this same thread above
-        const Vec16<T> g = *reinterpret_cast<const Vec16<T>*>(norm_w + (size_t)kc * VEC);
-        const float r = pick(b);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) v.set(i, g.get(i) * rnd<T>(v.get(i) * r));
         *reinterpret_cast<Vec16<T>*>(xs + (size_t)c * VEC) = v;
@@ -201,38 +164,51 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
     }
     __syncthreads();
   }
-
-  float acc[R][B];
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
   SRGPT_TS(2);
-#ifdef SRGPT_GEMV_TS
-  int ts_it = 0;
-#endif
 
-  while (c0.unit < units) {
+  int uk = 0;
+  for (int unit = blockIdx.x * 4 + wave; unit < N; unit += gridDim.x * 4, ++uk) {
+    float acc[R][B];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int j = 0; j < U; ++j) {
-        cur[r][j] = n1[r][j];
-        n1[r][j] = n2[r][j];
-      }
-    const Cursor c3 = advance(c2);
-    load(c2, n2);  // third batch ahead of the one being consumed
+      for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
 
+    for (int it0 = 0; it0 < nit; it0 += U) {
+      // one batch: 8 independent 1-KiB wave loads go out back to back (indices clamped, never branched, so the
+      // compiler can place counted s_waitcnt vmcnt(N) in front of each consumer), then they are consumed in order.
+      // Waves drift apart naturally, so some stream while others multiply; 8 waves/CU keep 64 KiB in flight.
+      u32x4 w[R][U];
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-      const int ch = (c0.b * U + j) * 64 + lane;
-      if (ch < nchunks) {
+      for (int r = 0; r < R; ++r) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(unit + r * N) * K);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          w[r][j] = __builtin_nontemporal_load(p + min((it0 + j) * 64 + lane, nchunks - 1));
+          // pin ISSUE order == CONSUMPTION order: left alone, the scheduler issued the first-consumed chunk last,
+          // which turns the counted waits below into a full vmcnt(0) drain before the first FMA
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        // branch-free: a chunk index past the row end is clamped for the loads and its weights are zeroed here.
+        // (A per-chunk `if` made the compiler sink the chunk's global load INTO the branch, behind all the others,
+        //  followed by s_waitcnt vmcnt(0): every batch was fully drained before its first FMA.)
+        const int ch = (it0 + j) * 64 + lane;
+        const bool valid = ch < nchunks;
+        const int chc = valid ? ch : nchunks - 1;
         float wf[R][VEC];
 #pragma unroll
-        for (int r = 0; r < R; ++r) WChunk<T>::cvt(cur[r][j], wf[r]);
+        for (int r = 0; r < R; ++r) {
+          u32x4 wv = w[r][j];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) wv[q] = valid ? wv[q] : 0u;
+          WChunk<T>::cvt(wv, wf[r]);
+        }
 #pragma unroll
         for (int b = 0; b < B; ++b) {
-          const Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(xs + (size_t)b * K + (size_t)ch * VEC);
+          const Vec16<T> xv = *reinterpret_cast<const Vec16<T>*>(xs + (size_t)b * K + (size_t)chc * VEC);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
             const float xf = xv.get(i);
@@ -243,38 +219,25 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
       }
     }
 
-    if (c0.b == NB - 1) {
-      const int n = c0.unit;
 #pragma unroll
-      for (int b = 0; b < B; ++b) {
-        float a[R];
+    for (int b = 0; b < B; ++b) {
+      float a[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          a[r] = wave_sum(acc[r][b]);
-          acc[r][b] = 0.f;
-        }
-        if (lane == 0) {
-          if (SWIGLU) {
-            const float g = rnd<T>(a[0]), u = rnd<T>(a[R - 1]);
-            reinterpret_cast<T*>(out)[(size_t)b * N + n] = from_f<T>(rnd<T>(silu(g)) * u);
-          } else {
-            float v = rnd<T>(a[0]);
-            if (residual) v = rnd<T>(to_f(residual[(size_t)b * N + n]) + v);
-            if (out_f32)
-              reinterpret_cast<float*>(out)[(size_t)b * N + n] = v;
-            else
-              reinterpret_cast<T*>(out)[(size_t)b * N + n] = from_f<T>(v);
-          }
+      for (int r = 0; r < R; ++r) a[r] = wave_sum(acc[r][b]);
+      if (lane == 0) {
+        if (SWIGLU) {
+          const float g = rnd<T>(a[0]), u = rnd<T>(a[R - 1]);
+          reinterpret_cast<T*>(out)[(size_t)b * N + unit] = from_f<T>(rnd<T>(silu(g)) * u);
+        } else {
+          float v = rnd<T>(a[0]);
+          if (residual) v = rnd<T>((uk < RES_MAXU ? res_s[b][wave][uk] : to_f(residual[(size_t)b * N + unit])) + v);
+          if (out_f32)
+            reinterpret_cast<float*>(out)[(size_t)b * N + unit] = v;
+          else
+            reinterpret_cast<T*>(out)[(size_t)b * N + unit] = from_f<T>(v);
         }
       }
     }
-#ifdef SRGPT_GEMV_TS
-    if (ts_it == 0) SRGPT_TS(3);
-    ++ts_it;
-#endif
-    c0 = c1;
-    c1 = c2;
-    c2 = c3;
   }
   SRGPT_TS(4);
 }
