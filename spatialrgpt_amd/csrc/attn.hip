@@ -288,23 +288,41 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
     }
   }
 
-  // ---- rotate q (G heads) and the new k; stage v ----
-  for (int w = tid; w < (G + 1) * HALF; w += 256) {
-    const int hh = w / HALF, i = w - hh * HALF;
-    const float c = to_f(cos_tab[(size_t)P * HALF + i]), s = to_f(sin_tab[(size_t)P * HALF + i]);
-    const T* p = (hh < G) ? row + (size_t)(hk * G + hh) * D : row + (size_t)(Hq + hk) * D;
-    const float x1 = to_f(p[i]), x2 = to_f(p[i + HALF]);
-    const float o1 = rnd<T>(rnd<T>(x1 * c) + rnd<T>(-x2 * s));
-    const float o2 = rnd<T>(rnd<T>(x2 * c) + rnd<T>(x1 * s));
-    if (hh < G) {
-      qs[hh][i] = o1;
-      qs[hh][i + HALF] = o2;
-    } else {
-      knew[i] = o1;
-      knew[i + HALF] = o2;
+  // ---- rotate q (G heads) and the new k; stage v.  Every global load of this stage is issued before any of
+  //      them is consumed (unrolled, index wrapped instead of branched): one L2 latency instead of three. ----
+  {
+    constexpr int NITEM = (G + 1) * HALF;
+    constexpr int ITEMS = (NITEM + 255) / 256;
+    float x1v[ITEMS], x2v[ITEMS], cv[ITEMS], sv[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int w = (tid + 256 * it) % NITEM;
+      const int hh = w / HALF, i = w - hh * HALF;
+      const T* p = (hh < G) ? row + (size_t)(hk * G + hh) * D : row + (size_t)(Hq + hk) * D;
+      x1v[it] = to_f(p[i]);
+      x2v[it] = to_f(p[i + HALF]);
+      cv[it] = to_f(cos_tab[(size_t)P * HALF + i]);
+      sv[it] = to_f(sin_tab[(size_t)P * HALF + i]);
     }
+    const float vraw = to_f(row[(size_t)(Hq + Hkv + hk) * D + (tid % D)]);
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int w0 = tid + 256 * it;
+      if (w0 < NITEM) {
+        const int hh = w0 / HALF, i = w0 - hh * HALF;
+        const float o1 = rnd<T>(rnd<T>(x1v[it] * cv[it]) + rnd<T>(-x2v[it] * sv[it]));
+        const float o2 = rnd<T>(rnd<T>(x2v[it] * cv[it]) + rnd<T>(x1v[it] * sv[it]));
+        if (hh < G) {
+          qs[hh][i] = o1;
+          qs[hh][i + HALF] = o2;
+        } else {
+          knew[i] = o1;
+          knew[i + HALF] = o2;
+        }
+      }
+    }
+    if (tid < D) vnew[tid] = vraw;
   }
-  for (int d = tid; d < D; d += 256) vnew[d] = to_f(row[(size_t)(Hq + Hkv + hk) * D + d]);
   __syncthreads();
   if (split == 0) {  // exactly one block per (b, hk) appends; nobody reads position P from the cache
     for (int d = tid; d < D; d += 256) {
