@@ -1,0 +1,174 @@
+"""GPU: input-contract edge cases of generate()/prepare_inputs (llava_arch.py:333-650) against the oracle on the CPU,
+and a true-width parity check (VILA1.5-8B layer geometry, truncated depth) in bf16."""
+import pytest
+import torch
+
+from tests.util import assert_close, load_tiny
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _both(name="tiny_fp32.npz"):
+    from oracle import srgpt_oracle as so
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.model import LlavaLlamaModel
+
+    cfgd, dtype, w, inp, ref = load_tiny(name)
+    cfg = SrgptConfig.from_dict(cfgd)
+    ocfg = so.SrgptConfig(**{k: v for k, v in cfgd.items() if k in so.SrgptConfig.__dataclass_fields__})
+    model = LlavaLlamaModel(cfg, dict(w), device=DEV, dtype=dtype, rope_positions=1024)
+    return so, ocfg, model, w, inp
+
+
+def _embeds(model, ids, images, depths, masks, am=None):
+    e, a, lens = model.engine.prepare_inputs(ids.to(DEV), images if isinstance(images, list) else images.to(DEV),
+                                             None if depths is None else (depths if isinstance(depths, list) else depths.to(DEV)),
+                                             None if masks is None else [None if m is None else m.to(DEV) for m in masks],
+                                             None if am is None else am.to(DEV))
+    return e, a, lens
+
+
+def test_depths_none_and_masks_none():
+    so, ocfg, model, w, inp = _both()
+    ids, im, dp, mk = inp["input_ids"], inp["images"], inp["depths"], inp["masks"]
+    # no depth maps: only <mask> rows are replaced, <depth> ids keep their token embedding (llava_arch.py:406-407)
+    ref, _, _, _ = so.prepare_inputs(w, ocfg, ids, im, None, mk)
+    got, _, _ = _embeds(model, ids, im, None, mk)
+    assert_close(got, ref, 2e-4 * float(ref.abs().max()), 0, "depths=None")
+    # masks=[None]: nothing replaced, a diagnostic is printed (llava_arch.py:476-477)
+    ref, _, _, _ = so.prepare_inputs(w, ocfg, ids, im, dp, [None])
+    got, _, _ = _embeds(model, ids, im, dp, [None])
+    assert_close(got, ref, 2e-4 * float(ref.abs().max()), 0, "masks=[None]")
+    ref, _, _, _ = so.prepare_inputs(w, ocfg, ids, im, dp, None)
+    got, _, _ = _embeds(model, ids, im, dp, None)
+    assert_close(got, ref, 2e-4 * float(ref.abs().max()), 0, "masks=None")
+
+
+def test_image_containers_and_attention_mask():
+    so, ocfg, model, w, inp = _both()
+    ids, im, dp, mk = inp["input_ids"], inp["images"], inp["depths"], inp["masks"]
+    ref, _, _, _ = so.prepare_inputs(w, ocfg, ids, im, dp, mk)
+    got, _, _ = _embeds(model, ids, [im.to(DEV)], [dp.to(DEV)], mk)  # list of [1,3,S,S]
+    assert_close(got, ref, 2e-4 * float(ref.abs().max()), 0, "list images")
+    got, _, _ = _embeds(model, ids, im[None], dp[None], mk)  # 5-D [B, n, 3, S, S]
+    assert_close(got, ref, 2e-4 * float(ref.abs().max()), 0, "5-D images")
+    am = torch.ones_like(ids)
+    got, a, _ = _embeds(model, ids, im, dp, mk, am)
+    assert a is not None and a.dtype == am.dtype and a.shape == got.shape[:2] and bool(a.bool().all())
+    assert_close(got, ref, 2e-4 * float(ref.abs().max()), 0, "explicit attention mask")
+
+
+def test_two_images_one_prompt_and_masks_follow_image_index():
+    """two <image> sentinels in one sample: T = P - 2 + 2*196; region embeds come from the sample's first image."""
+    so, ocfg, model, w, inp = _both()
+    ids, im, dp, mk = inp["input_ids"], inp["images"], inp["depths"], inp["masks"]
+    ids2 = torch.cat([ids[:, :8], torch.tensor([[-200]]), ids[:, 8:]], dim=1)
+    im2, dp2 = torch.cat([im, dp], 0), torch.cat([dp, im], 0)
+    mk2 = [mk[0], mk[0].flip(0)]
+    ref, _, _, _ = so.prepare_inputs(w, ocfg, ids2, im2, dp2, mk2)
+    got, _, lens = _embeds(model, ids2, im2, dp2, mk2)
+    assert got.shape[1] == ids2.shape[1] - 2 + 2 * 196 == lens[0]
+    assert_close(got, ref, 2e-4 * float(ref.abs().max()), 0, "two images")
+
+
+def test_ragged_batch_right_and_left_padding():
+    so, ocfg, model, w, inp = _both()
+    ids, im, dp, mk = inp["input_ids"], inp["images"], inp["depths"], inp["masks"]
+    P = ids.shape[1]
+    short = ids[:, :P - 3]
+    pad = torch.zeros((1, 3), dtype=ids.dtype)
+    ids_b = torch.cat([ids, torch.cat([short, pad], 1)], 0)
+    am = torch.ones_like(ids_b)
+    am[1, P - 3:] = 0
+    im2, dp2, mk2 = torch.cat([im, im], 0), torch.cat([dp, dp], 0), [mk[0], mk[0]]
+    ref, ram, _, _ = so.prepare_inputs(w, ocfg, ids_b, im2, dp2, mk2, am)
+    got, gam, lens = _embeds(model, ids_b, im2, dp2, mk2, am)
+    assert lens == [P - 1 + 196, P - 4 + 196]
+    assert torch.equal(gam.cpu(), ram)
+    assert_close(got, ref, 2e-4 * float(ref.abs().max()), 0, "ragged, right padded")
+    assert float(got[1, lens[1]:].abs().max()) == 0.0  # padding rows are zeros
+    # generate() on the ragged batch == each row on its own
+    out = model.generate(ids_b.to(DEV), images=im2.to(DEV), depths=dp2.to(DEV), masks=[m.to(DEV) for m in mk2],
+                         attention_mask=am.to(DEV), do_sample=False, max_new_tokens=5, eos_token_id=None)
+    one = model.generate(ids.to(DEV), images=im.to(DEV), depths=dp.to(DEV), masks=[mk[0].to(DEV)], do_sample=False,
+                         max_new_tokens=5, eos_token_id=None)
+    two = model.generate(short.to(DEV), images=im.to(DEV), depths=dp.to(DEV), masks=[mk[0].to(DEV)], do_sample=False,
+                         max_new_tokens=5, eos_token_id=None)
+    assert torch.equal(out[0:1], one) and torch.equal(out[1:2], two)
+    # left padding (llm.config.tokenizer_padding_side == "left", llava_arch.py:570-590)
+    model.engine.cfg.padding_side = ocfg.padding_side = "left"
+    ref, ram, _, _ = so.prepare_inputs(w, ocfg, ids_b, im2, dp2, mk2, am)
+    got, gam, _ = _embeds(model, ids_b, im2, dp2, mk2, am)
+    assert torch.equal(gam.cpu(), ram)
+    assert_close(got, ref, 2e-4 * float(ref.abs().max()), 0, "ragged, left padded")
+
+
+def test_truncation_warns_like_reference():
+    so, ocfg, model, w, inp = _both()
+    ids, im, dp, mk = inp["input_ids"], inp["images"], inp["depths"], inp["masks"]
+    model.engine.cfg.tokenizer_model_max_length = ocfg.tokenizer_model_max_length = 100
+    with pytest.warns(UserWarning, match="Inputs truncated!"):
+        got, _, lens = _embeds(model, ids, im, dp, mk)
+    with pytest.warns(UserWarning):
+        ref, _, _, _ = so.prepare_inputs(w, ocfg, ids, im, dp, mk)
+    assert got.shape[1] == 100 and lens == [100]
+    assert_close(got, ref, 2e-4 * float(ref.abs().max()), 0, "truncated")
+
+
+def test_sampling_path_runs_and_respects_eos():
+    so, ocfg, model, w, inp = _both()
+    d = {k: (v.to(DEV) if torch.is_tensor(v) else [m.to(DEV) for m in v]) for k, v in inp.items()}
+    torch.manual_seed(0)
+    out = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], do_sample=True, temperature=0.2,
+                         top_p=0.9, max_new_tokens=6, eos_token_id=None)
+    assert out.shape == (1, 6) and int(out.min()) >= 0 and int(out.max()) < model.config.vocab
+    # temperature -> 0 limit: top_k = 1 must reproduce greedy
+    g = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], do_sample=False, max_new_tokens=6,
+                       eos_token_id=None)
+    s = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], do_sample=True, temperature=1.0,
+                       top_k=1, max_new_tokens=6, eos_token_id=None)
+    assert torch.equal(g, s)
+    with pytest.raises(NotImplementedError):
+        model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], num_beams=2, max_new_tokens=2)
+
+
+def test_true_width_truncated_depth_bf16_vs_oracle():
+    """VILA1.5-8B layer geometry (hidden 4096, GQA 32/8, inter 14336, SigLIP-so400m width) with 2 LLM / 2 ViT layers and a
+    16k vocab, bf16, one full request: stage tensors within bf16 tolerance of the oracle, ids margin-aware."""
+    from oracle import srgpt_oracle as so
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.model import LlavaLlamaModel
+
+    kw = dict(vit_layers=3, layers=2, vocab=16386, mask_token_id=16384, depth_token_id=16385)
+    ocfg = so.SrgptConfig(**kw)
+    w = so.synth_weights(ocfg, seed=11, dtype=torch.bfloat16)
+    ids, images, depths, masks = so.synth_inputs(ocfg, batch=1, regions=8, prompt_len=64, seed=2, dtype=torch.bfloat16)
+    model = LlavaLlamaModel(SrgptConfig(**kw), dict(w), device=DEV, dtype=torch.bfloat16, rope_positions=1024)
+    torch.set_num_threads(16)
+    G = 6
+    ref_ids, st = so.generate(w, ocfg, ids, images, depths, masks, max_new_tokens=G, return_stages=True, model_dtype=torch.bfloat16)
+    got = {}
+    emb, _, _ = model.engine.prepare_inputs(ids.to(DEV), images.to(DEV), depths.to(DEV), [m.to(DEV) for m in masks], None, stages=got)
+    assert emb.shape == (1, 259, 4096)
+
+    def chk(a, b, what, rel=4e-2):
+        assert_close(a, b, rel * (float(b.float().abs().max()) + 1e-6), 0, what)
+
+    chk(got["tower_features"], st["tower_features"], "tower (2 SigLIP-so400m layers)")
+    chk(got["hres"], st["hres"], "hres 11664 x 1152")
+    chk(torch.stack(got["mask_embeds"]), torch.stack(st["mask_embeds"]), "mask embeds")
+    chk(torch.stack(got["depth_embeds"]), torch.stack(st["depth_embeds"]), "depth embeds")
+    chk(got["image_features"], st["image_features"], "projector")
+    chk(emb, st["inputs_embeds"], "inputs_embeds")
+    stt, logits, _ = model.engine.prefill(st["inputs_embeds"].to(DEV), max_new=G, all_logits=True)
+    chk(logits, st["prefill_logits"], "prefill logits (T = 259)")
+    out = model.engine.greedy_decode(stt, G).cpu()
+    sl = st["step_logits"].float()[0]
+    top2 = sl.topk(2, dim=-1).values
+    margin = top2[:, 0] - top2[:, 1]
+    tol = 4e-2 * float(sl.abs().max())
+    for s_ in range(G):
+        if int(out[0, s_]) != int(ref_ids[0, s_]):
+            assert float(margin[s_]) <= tol, f"step {s_}: {int(out[0, s_])} vs {int(ref_ids[0, s_])}, margin {float(margin[s_]):.4f} > {tol:.4f}"
+            break
