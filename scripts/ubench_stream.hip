@@ -7,6 +7,37 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u4;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 // V: 0 grid-stride 4 in flight | 1 row-per-wave, DEPTH loads in flight, no compute | 2 +LDS prologue | 3 +FMA | 4 +reduce/store
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f4v;
+// fragment-shaped weight loads: lane l reads W[row0 + (l & 15)][k0 + 8 * (l >> 4) .. +8]  (16 rows x 64 B per instruction)
+template <int DEPTH>
+__global__ __launch_bounds__(256, 2) void kfrag(const u4* __restrict__ W, const u4* __restrict__ x, float* __restrict__ out, int N, int K16) {
+  __shared__ u4 xs[512];  // one activation row (bandwidth experiment: every batch column reads the same x)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < K16; c += 256) xs[c] = x[c];
+  __syncthreads();
+  const int r = lane & 15, g = lane >> 4;
+  const int nsteps = K16 / 4;  // 32-wide k steps
+  for (int unit = blockIdx.x * 4 + wave; unit * 16 < N; unit += gridDim.x * 4) {
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
+    const u4* p = W + (size_t)(unit * 16 + r) * K16 + g;
+    for (int s0 = 0; s0 < nsteps; s0 += DEPTH) {
+      u4 w[DEPTH];
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) w[j] = __builtin_nontemporal_load(p + (s0 + j) * 4);
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        const u4 xv = xs[(s0 + j) * 4 + g];
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]), __builtin_bit_cast(bf16x8, xv), acc, 0, 0, 0);
+      }
+    }
+    if (r == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[unit * 16 + g * 4 + q] = acc[q];
+    }
+  }
+}
+
 template <int V, int DEPTH>
 __global__ __launch_bounds__(256, 2) void k(const u4* __restrict__ W, const u4* __restrict__ x, float* __restrict__ out, int N, int K16) {
   __shared__ u4 xs[2048];
@@ -68,6 +99,23 @@ __global__ void fill_random(unsigned* p, size_t n, unsigned seed) {
   }
 }
 
+template <int DEPTH>
+int runfrag(const char* name, hipStream_t s, std::vector<u4*>& Ws, u4* x, float* out, int N, int K) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipGraph_t g; hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  for (auto W : Ws) hipLaunchKernelGGL((kfrag<DEPTH>), dim3(512), dim3(256), 0, s, W, x, out, N, K / 8);
+  CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  float ms = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  const double us = ms * 1e3 / Ws.size(), mb = (double)N * K * 2 / 1e6;
+  printf("  %-44s %7.2f us  (%.2f TB/s; fixed vs 7.05 TB/s %5.2f us)\n", name, us, mb / us, us - mb / 7.05);
+  return 0;
+}
+
 template <int V, int DEPTH>
 int run(const char* name, hipStream_t s, std::vector<u4*>& Ws, u4* x, float* out, int N, int K) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -102,6 +150,8 @@ int main() {
     run<3, 8>("V3 + bf16 FMA on the data", s, Ws, x, out, N, K);
     run<4, 8>("V4 + wave reduce + store", s, Ws, x, out, N, K);
     run<4, 4>("V4 depth 4", s, Ws, x, out, N, K);
+    runfrag<8>("MFMA 16x16x32, fragment-shaped loads, depth 8", s, Ws, x, out, N, K);
+    runfrag<16>("MFMA 16x16x32, fragment-shaped loads, depth 16", s, Ws, x, out, N, K);
     for (auto W : Ws) CK(hipFree(W));
   }
   return 0;
