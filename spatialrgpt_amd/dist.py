@@ -43,28 +43,39 @@ def get_chunk(lst: Sequence, n: int, k: int) -> Sequence:
     return chunks[k] if k < len(chunks) else lst[0:0]
 
 
-def gather_ids(local_ids: torch.Tensor, pad_id: int = 0, group=None) -> torch.Tensor:
-    """All-gather generated ids [B_local, G_local] (int64) from every rank -> [sum B_local, max G] in rank order.
-    Shapes may differ per rank (ragged shards, early EOS): sizes are exchanged first, payloads padded."""
+def _gather_rows(local: torch.Tensor, pad, group=None) -> torch.Tensor:
+    """All-gather 2-D per-rank blocks [rows_r, cols_r] -> [sum rows, max cols] in rank order.  Shapes may differ per rank
+    (ragged shards, early EOS): sizes are exchanged first, payloads padded to the common shape -> one collective each."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return local_ids
+        return local
     world = dist.get_world_size(group)
-    out_dev = local_ids.device
-    if dist.get_backend(group) == "gloo" and local_ids.is_cuda:
-        local_ids = local_ids.cpu()  # gloo moves host buffers; RCCL ("nccl") takes the device tensor directly
-    dev = local_ids.device
-    shape = torch.tensor(list(local_ids.shape) if local_ids.dim() == 2 else [0, 0], dtype=torch.int64, device=dev)
+    out_dev = local.device
+    if dist.get_backend(group) == "gloo" and local.is_cuda:
+        local = local.cpu()  # gloo moves host buffers; RCCL ("nccl") takes the device tensor directly
+    dev = local.device
+    shape = torch.tensor(list(local.shape) if local.dim() == 2 else [0, 0], dtype=torch.int64, device=dev)
     shapes = [torch.zeros_like(shape) for _ in range(world)]
     dist.all_gather(shapes, shape, group=group)
     mb = max(int(s[0]) for s in shapes)
     mg = max(int(s[1]) for s in shapes)
-    buf = torch.full((mb, mg), pad_id, dtype=torch.int64, device=dev)
-    if local_ids.numel():
-        buf[:local_ids.shape[0], :local_ids.shape[1]] = local_ids
+    buf = torch.full((mb, mg), pad, dtype=local.dtype, device=dev)
+    if local.numel():
+        buf[:local.shape[0], :local.shape[1]] = local
     bufs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(bufs, buf, group=group)
     rows = [b[:int(s[0])] for b, s in zip(bufs, shapes)]
     return (torch.cat(rows, dim=0) if rows else buf[:0]).to(out_dev)
+
+
+def gather_ids(local_ids: torch.Tensor, pad_id: int = 0, group=None) -> torch.Tensor:
+    """All-gather generated ids [B_local, G_local] (int64) from every rank -> [sum B_local, max G] in rank order."""
+    return _gather_rows(local_ids, pad_id, group)
+
+
+def gather_logits(local_logits: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather last-position logits [B_local, V] (fp32) from every rank -> [sum B_local, V] in rank order: the exchange
+    the north-star names.  V * 4 B per row (0.5 MB at V = 128258): one all-gather after the shard is done, never per token."""
+    return _gather_rows(local_logits.float(), 0.0, group)
 
 
 def generate_data_parallel(model, requests: Sequence[dict], group=None, pad_id: int = 0, **gen_kwargs) -> torch.Tensor:
@@ -85,3 +96,22 @@ def generate_data_parallel(model, requests: Sequence[dict], group=None, pad_id: 
     else:
         local = torch.zeros((0, 0), dtype=torch.int64, device=dev)
     return gather_ids(local, pad_id, group)
+
+
+def forward_data_parallel(model, requests: Sequence[dict], group=None) -> torch.Tensor:
+    """Run `model.forward` (llava_llama.py:100-192 surface) on this rank's shard and all-gather the LAST-position logits
+    of every request: [len(requests), V] fp32 on every rank, request order."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = get_chunk(list(requests), world, rank)
+    rows = []
+    for req in mine:
+        out = model.forward(**req)
+        logits = out.logits if hasattr(out, "logits") else out
+        rows.append(logits[:, -1, :].float())
+    if rows:
+        local = torch.cat(rows, dim=0)
+    else:
+        dev = model.device if hasattr(model, "device") else "cpu"
+        local = torch.zeros((0, 0), dtype=torch.float32, device=dev)
+    return gather_logits(local, group)

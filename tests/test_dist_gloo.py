@@ -24,10 +24,14 @@ class _FakeModel:
         base = int(input_ids[0, 0])
         return torch.arange(base, base + n_new, dtype=torch.int64)[None]
 
+    def forward(self, input_ids=None, **kw):
+        base = float(input_ids[0, 0])
+        return (torch.arange(3 * 7, dtype=torch.float32).reshape(1, 3, 7) + base)  # [B=1, T=3, V=7]
+
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
-    from spatialrgpt_amd.dist import gather_ids, generate_data_parallel, init_distributed
+    from spatialrgpt_amd.dist import forward_data_parallel, gather_ids, generate_data_parallel, init_distributed
 
     r, w, _ = init_distributed("gloo")
     assert (r, w) == (rank, world)
@@ -43,6 +47,11 @@ def _worker(rank, world, port, q):
         n = 2 + (i % 2)
         exp[i, :n] = torch.arange(100 * i, 100 * i + n)
     assert torch.equal(out, exp), (out, exp)
+    # last-position logits of every request on every rank, request order (5 requests over 2 ranks: 3 + 2)
+    lg = forward_data_parallel(_FakeModel(), [dict(input_ids=r["input_ids"]) for r in reqs])
+    assert lg.shape == (5, 7) and lg.dtype == torch.float32
+    for i in range(5):
+        assert torch.equal(lg[i], torch.arange(14, 21, dtype=torch.float32) + 100 * i)
     dist.barrier()
     dist.destroy_process_group()
     q.put(rank)
