@@ -1,4 +1,4 @@
-// Decode-path weight-streaming GEMV (batch <= 4 rows): out[b, n] = W[n, :] . x[b, :]   (HBM-bound)
+// Decode-path weight-streaming GEMV (batch <= 4 rows; more rows -> skinny.hip): out[b, n] = W[n, :] . x[b, :]   (HBM-bound)
 //
 // Roofline: every weight byte is read exactly once per token (non-temporal 16-byte loads, one 1 KiB
 // wave-instruction per row chunk); x lives in LDS; fp32 accumulate on the VALU (24 lane-ops per 16 B --
@@ -32,6 +32,9 @@ extern "C" void* srgpt_gemv_ts_ptr() {
 #else
 #define SRGPT_TS(slot)
 #endif
+
+int srgpt_skinny_launch(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
+                        int batch, int N, int K, int swiglu, int out_f32, hipStream_t s);  // skinny.hip
 
 namespace {
 
@@ -278,13 +281,34 @@ int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, con
 template <typename T>
 int dispatch_b(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
                int batch, int N, int K, int swiglu, int out_f32, hipStream_t s) {
+  static const int skinny_min = getenv("SRGPT_SKINNY_MIN_BATCH") ? atoi(getenv("SRGPT_SKINNY_MIN_BATCH")) : 3;  // measured: VALU wins at 1-2 rows, MFMA from 3
+  if (batch > 4 || (sizeof(T) == 2 && batch >= skinny_min)) {
+    // bf16: rows go through the MFMA skinny kernel 16 at a time (skinny.hip); fp32 (parity dtype of the tiny models):
+    // 4 rows at a time through the VALU kernel.  Each chunk streams the weights once.
+    const bool mfma = sizeof(T) == 2;
+    int step = mfma ? 16 : 4;
+    if (!mfma)
+      while (step > 1 && (size_t)step * K * sizeof(T) > 150 * 1024) --step;
+    const size_t on = out_f32 ? sizeof(float) : sizeof(T);
+    for (int b0 = 0; b0 < batch; b0 += step) {
+      const int nb = batch - b0 < step ? batch - b0 : step;
+      const void* xb = (const char*)x + (size_t)b0 * K * sizeof(T);
+      const void* rb = residual ? (const char*)residual + (size_t)b0 * N * sizeof(T) : nullptr;
+      void* ob = (char*)out + (size_t)b0 * N * on;
+      if (mfma && (nb > 4 || nb >= skinny_min))
+        SRGPT_TRY(srgpt_skinny_launch(xb, W, norm_w, eps, rb, ob, nb, N, K, swiglu, out_f32, s));
+      else
+        SRGPT_TRY((dispatch_b<T>(xb, W, norm_w, eps, rb, ob, nb, N, K, swiglu, out_f32, s)));
+    }
+    return SRGPT_OK;
+  }
   switch (batch) {
     case 1: return launch_gemv<T, 1>(x, W, norm_w, eps, residual, out, N, K, swiglu, out_f32, s);
     case 2: return launch_gemv<T, 2>(x, W, norm_w, eps, residual, out, N, K, swiglu, out_f32, s);
     case 3: return launch_gemv<T, 3>(x, W, norm_w, eps, residual, out, N, K, swiglu, out_f32, s);
     case 4: return launch_gemv<T, 4>(x, W, norm_w, eps, residual, out, N, K, swiglu, out_f32, s);
     default:
-      srgpt_set_error("srgpt_gemv: batch %d not supported (1..4)", batch);
+      srgpt_set_error("srgpt_gemv: batch %d not supported", batch);
       return SRGPT_ERR_UNSUPPORTED;
   }
 }

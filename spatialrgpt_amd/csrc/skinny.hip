@@ -1,0 +1,267 @@
+// Batched decode-path weight-streaming product for 5..16 rows: out[b, n] = W[n, :] . x[b, :]   (bf16, HBM-bound)
+//
+// Same contract and fusions as the GEMV (gemv.hip: RMSNorm prologue, SwiGLU epilogue, residual add, fp32 logits), but
+// above 4 rows the VALU formulation runs out of issue slots and LDS bandwidth (B LDS reads + 8 B FMAs per 16 weight
+// bytes), so the 16-row batch becomes the M side of v_mfma_f32_16x16x32_bf16 and 16 weight rows the N side.
+//
+// Roofline: weight bytes read exactly once (non-temporal, each wave-instruction = 2 rows x 512 contiguous bytes).
+// MFMA operand fragments need lane (r = l & 15, g = l >> 4) to hold 16 bytes of ROW r -- loading them straight from
+// HBM puts 16 different rows in one instruction (64-byte pieces; measured slow, scripts/ubench_stream.hip), so each
+// wave stages its 16 x 256 weight tile through a PRIVATE 8 KiB LDS region: 8 coalesced global loads -> 8 ds_write_b128
+// -> 8 conflict-free ds_read_b128 fragments (row stride padded to 528 B).  The matching [rows][256] slice of the
+// (normalised) activations goes through a second private region the same way (it comes from L2).  Nothing in the K loop
+// is shared between waves, so there is NO block barrier in it (LDS ops of one wave execute in order) and the 8-12 waves
+// of a CU drift apart like the GEMV's do: some stream while others multiply.
+//
+// Work decomposition: a unit = 16 output columns (SwiGLU: 16 gate rows + the 16 matching up rows = 2 sub-units);
+// block b owns units b, b + grid, ...; up to 4 sub-units per pass keep their 16x16 fp32 accumulators in registers
+// (4 VGPRs each).  The 4 waves of a block split K in interleaved 256-wide slices, so every block uses all its waves
+// even when N/16 is only one tile per CU (o_proj / down_proj); their partial sums are added in a fixed order through
+// LDS at the end of the pass (deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int WSK = 256;               // k per wave slice
+constexpr int WROWB = WSK * 2 + 16;    // bytes per staged row (padded: fragment reads hit 64 distinct banks)
+constexpr int WSTAGEB = 16 * WROWB;    // weight stage per wave
+constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumulated per pass
+
+// NI = x rows staged per wave / 2: 4 (batch <= 8) or 8 (batch <= 16)
+template <bool SWIGLU, int NI>
+__global__ __launch_bounds__(256, 2) void skinny_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
+                                                                      const bf16_t* __restrict__ norm_w, float norm_eps,
+                                                                      const bf16_t* __restrict__ residual, void* __restrict__ out,
+                                                                      int B, int N, int K, int out_f32) {
+  constexpr int R = SWIGLU ? 2 : 1;
+  constexpr int MAXU = MAXSU / R;
+  constexpr int XSTAGEB = 2 * NI * WROWB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // per wave: [x stage | w stage]; reused for the reduction
+  __shared__ float rs_s[16];
+  __shared__ float ss_s[16][2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* xst = smem + wave * (XSTAGEB + WSTAGEB);
+  unsigned char* wst = xst + XSTAGEB;
+  const int nsl = (K + WSK - 1) / WSK;  // K slices; wave w takes w, w + 4, ...
+  const int NU = (N + 15) >> 4;
+  const int grid = gridDim.x;
+  const int npass = (NU + grid * MAXU - 1) / (grid * MAXU);
+  const bool do_norm = norm_w != nullptr;
+  const int lrow = lane >> 5, lchunk = lane & 31;  // staging loads: lane -> (row parity, 16-byte chunk of the 512-byte row piece)
+
+  // ---- RMSNorm statistics of every batch row (LlamaRMSNorm: fp32 mean of squares over K) ----
+  float rsr[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) rsr[j] = 1.f;
+  if (do_norm) {
+    const int half = tid >> 7, kc = tid & 127;  // thread -> rows {2i + half}, chunks kc, kc + 128, ...
+    float ss[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ss[i] = 0.f;
+    const int nch = K >> 3;
+    for (int c0 = 0; c0 < nch; c0 += 512) {
+      u32x4 v[4][NI];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int b = min(2 * i + half, B - 1);
+          const int c = min(c0 + u * 128 + kc, nch - 1);
+          v[u][i] = *reinterpret_cast<const u32x4*>(x + (size_t)b * K + (size_t)c * 8);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = c0 + u * 128 + kc < nch;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          float s = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float lo = bf16lo(v[u][i][q]), hi = bf16hi(v[u][i][q]);
+            s += lo * lo + hi * hi;
+          }
+          ss[i] += ok ? s : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float t = wave_sum(ss[i]);
+      if (lane == 0) ss_s[2 * i + half][wave & 1] = t;
+    }
+    __syncthreads();
+    if (tid < 2 * NI) rs_s[tid] = rsqrtf((ss_s[tid][0] + ss_s[tid][1]) / (float)K + norm_eps);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) rsr[j] = rs_s[2 * j + lrow];
+  }
+
+  // activation slice: NI loads, each 2 rows x 512 contiguous bytes (rows past the batch re-read row B-1: their outputs
+  // are never stored), plus the 512 bytes of RMSNorm gains of the slice
+  u32x4 xr[NI];
+  u32x4 gr = {0u, 0u, 0u, 0u};
+  auto load_x = [&](int sl) {
+    const int kg = min(sl * WSK + lchunk * 8, K - 8);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int b = min(2 * j + lrow, B - 1);
+      xr[j] = *reinterpret_cast<const u32x4*>(x + (size_t)b * K + kg);
+    }
+    if (do_norm) gr = *reinterpret_cast<const u32x4*>(norm_w + kg);
+  };
+  auto stage_x = [&](int sl) {
+    const bool kvalid = sl * WSK + lchunk * 8 < K;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      u32x4 v = xr[j];
+      if (do_norm) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // weight * hidden.to(dtype): two roundings, like the GEMV prologue
+          const float lo = bf16lo(gr[q]) * rnd<bf16_t>(bf16lo(v[q]) * rsr[j]);
+          const float hi = bf16hi(gr[q]) * rnd<bf16_t>(bf16hi(v[q]) * rsr[j]);
+          bf16x2 p;
+          p[0] = (bf16_t)lo;
+          p[1] = (bf16_t)hi;
+          v[q] = __builtin_bit_cast(unsigned int, p);
+        }
+      }
+      if (!kvalid) v = u32x4{0u, 0u, 0u, 0u};  // k past K contributes zeros (the weight loads there are clamped)
+      *reinterpret_cast<u32x4*>(xst + (2 * j + lrow) * WROWB + lchunk * 16) = v;
+    }
+  };
+
+  u32x4 w[8];
+  // weight stage of sub-unit su of (pass, slice): 8 loads, each 2 rows x 512 contiguous bytes
+  auto issue_w = [&](int pass, int sl, int su) {
+    const int unit = (pass * MAXU + su / R) * grid + (int)blockIdx.x;
+    const int kg = min(sl * WSK + lchunk * 8, K - 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int n = min(unit * 16 + 2 * j + lrow, N - 1);
+      const size_t row = (size_t)n + (size_t)(su % R) * N;
+      w[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + row * K + kg));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  if (wave < nsl) load_x(wave);
+  for (int pass = 0; pass < npass; ++pass) {
+    int nu = 0;
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) nu += ((pass * MAXU + u) * grid + (int)blockIdx.x < NU) ? 1 : 0;
+    if (nu == 0) break;  // uniform per block; later passes are empty too
+    const int nsu = nu * R;
+    f32x4 acc[MAXSU];
+#pragma unroll
+    for (int su = 0; su < MAXSU; ++su) acc[su] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int sl = wave; sl < nsl; sl += 4) {
+      issue_w(pass, sl, 0);  // HBM latency overlaps the activation staging below
+      stage_x(sl);
+      if (sl + 4 < nsl) load_x(sl + 4);
+      else if (pass + 1 < npass) load_x(wave);
+      __builtin_amdgcn_wave_barrier();
+      bf16x8 xf[8];
+      const int xrow = (NI == 8) ? (lane & 15) : (lane & 7);
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        xf[s] = *reinterpret_cast<const bf16x8*>(xst + xrow * WROWB + (4 * s + (lane >> 4)) * 16);
+#pragma unroll
+      for (int su = 0; su < MAXSU; ++su) {
+        if (su < nsu) {
+          if (su > 0) issue_w(pass, sl, su);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(wst + (2 * j + lrow) * WROWB + lchunk * 16) = w[j];
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wst + (lane & 15) * WROWB + (4 * s + (lane >> 4)) * 16);
+            // D[batch row][weight row] += x[batch row][k] * W[weight row][k]
+            acc[su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[s], wf, acc[su], 0, 0, 0);
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+
+    // ---- cross-wave reduction (fixed order) + epilogue ----
+    __syncthreads();
+    float* redf = reinterpret_cast<float*>(smem);  // [4 waves][MAXSU][64 lanes][4] = 16 KiB
+#pragma unroll
+    for (int su = 0; su < MAXSU; ++su)
+      if (su < nsu) *reinterpret_cast<f32x4*>(redf + ((wave * MAXSU + su) * 64 + lane) * 4) = acc[su];
+    __syncthreads();
+    {
+      const int l2 = tid & 63, q = tid >> 6;
+      const int b = 4 * (l2 >> 4) + q;
+#pragma unroll
+      for (int u = 0; u < MAXU; ++u) {
+        if (u < nu) {
+          const int unit = (pass * MAXU + u) * grid + (int)blockIdx.x;
+          const int n = unit * 16 + (l2 & 15);
+          float a[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            float t = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) t += redf[((wv * MAXSU + u * R + r) * 64 + l2) * 4 + q];
+            a[r] = t;
+          }
+          if (b < B && n < N) {
+            if (SWIGLU) {
+              const float g = rnd<bf16_t>(a[0]), up = rnd<bf16_t>(a[R - 1]);
+              reinterpret_cast<bf16_t*>(out)[(size_t)b * N + n] = (bf16_t)(rnd<bf16_t>(silu(g)) * up);
+            } else {
+              float v = rnd<bf16_t>(a[0]);
+              if (residual) v = rnd<bf16_t>((float)residual[(size_t)b * N + n] + v);
+              if (out_f32)
+                reinterpret_cast<float*>(out)[(size_t)b * N + n] = v;
+              else
+                reinterpret_cast<bf16_t*>(out)[(size_t)b * N + n] = (bf16_t)v;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // the reduction buffer aliases the wave-private stages of the next pass
+  }
+}
+
+template <bool SWIGLU, int NI>
+int launch_skinny(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out, int batch,
+                  int N, int K, int out_f32, int grid, hipStream_t s) {
+  constexpr int lds = 4 * (2 * NI * WROWB + WSTAGEB);
+  static_assert(lds >= 4 * MAXSU * 64 * 4 * 4, "reduction buffer must fit");
+  auto kfn = skinny_kernel<SWIGLU, NI>;
+  static bool attr_set = false;
+  if (lds > 48 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)W, (const bf16_t*)norm_w, eps,
+                     (const bf16_t*)residual, out, batch, N, K, out_f32);
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
+
+}  // namespace
+
+// host entry used by srgpt_gemv (gemv.hip) for batches of up to 16 rows, bf16
+int srgpt_skinny_launch(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
+                        int batch, int N, int K, int swiglu, int out_f32, hipStream_t s) {
+  SRGPT_CHECK(batch >= 1 && batch <= 16, SRGPT_ERR_ARG, "skinny: batch %d outside 1..16", batch);
+  SRGPT_CHECK(K % 8 == 0 && K >= 8, SRGPT_ERR_ARG, "skinny: K=%d must be a multiple of 8", K);
+  const int cus = srgpt_device_cus();
+  const int NU = (N + 15) / 16;
+  // balanced grid: every block gets the same number of units whenever N allows (e.g. 896 SwiGLU units -> 448 blocks x 2)
+  const int maxgrid = cus * 2;
+  const int per = (NU + maxgrid - 1) / maxgrid;  // units per block (more than MAXSU/R -> several passes in the kernel)
+  const int grid = (NU + per - 1) / per;
+  if (batch <= 8)
+    return swiglu ? launch_skinny<true, 4>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, grid, s)
+                  : launch_skinny<false, 4>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, grid, s);
+  return swiglu ? launch_skinny<true, 8>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, grid, s)
+                : launch_skinny<false, 8>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, grid, s);
+}

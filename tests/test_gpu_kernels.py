@@ -82,7 +82,11 @@ def test_gemm_deconv2x(dtype, n_img, g, C):
 # ------------------------------------------------------------------------------------------------ GEMV
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("B,N,K", [(1, 1000, 4096), (1, 1001, 4096), (2, 512, 11008), (4, 300, 1024), (1, 128, 64),
-                                   (3, 77, 2560)])
+                                   (3, 77, 2560),
+                                   # > 4 rows: MFMA skinny kernel (bf16, 16 rows per launch) / chunked VALU kernel (fp32);
+                                   # ragged N (not a multiple of 16), K tails (not a multiple of 1024 / 256), multi-pass N
+                                   (5, 1000, 4096), (8, 4096, 4096), (16, 1001, 2560), (13, 512, 11008), (7, 40, 72),
+                                   (20, 300, 1024), (33, 130, 512), (6, 33000, 256)])
 def test_gemv_variants(dtype, B, N, K):
     ops, L = _ops()
     x, w = _rand((B, K), dtype, 11), _rand((N, K), dtype, 12, 0.03)
@@ -102,7 +106,7 @@ def test_gemv_variants(dtype, B, N, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("B,N,K", [(1, 1024, 4096), (2, 333, 512)])
+@pytest.mark.parametrize("B,N,K", [(1, 1024, 4096), (2, 333, 512), (8, 1024, 4096), (16, 333, 512), (5, 14336, 1024), (19, 100, 264)])
 def test_gemv_swiglu(dtype, B, N, K):
     ops, L = _ops()
     x, w = _rand((B, K), dtype, 15), _rand((2 * N, K), dtype, 16, 0.03)
