@@ -18,6 +18,8 @@
 // (4 VGPRs each).  The 4 waves of a block split K in interleaved 256-wide slices, so every block uses all its waves
 // even when N/16 is only one tile per CU (o_proj / down_proj); their partial sums are added in a fixed order through
 // LDS at the end of the pass (deterministic).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -27,52 +29,110 @@ constexpr int WROWB = WSK * 2 + 16;    // bytes per staged row (padded: fragment
 constexpr int WSTAGEB = 16 * WROWB;    // weight stage per wave
 constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumulated per pass
 
-// NI = x rows staged per wave / 2: 4 (batch <= 8) or 8 (batch <= 16)
-template <bool SWIGLU, int NI>
-__global__ __launch_bounds__(256, 2) void skinny_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
-                                                                      const bf16_t* __restrict__ norm_w, float norm_eps,
-                                                                      const bf16_t* __restrict__ residual, void* __restrict__ out,
-                                                                      int B, int N, int K, int out_f32) {
+// NI = x rows staged per wave / 2: 4 (batch <= 8) or 8 (batch <= 16).  NW = waves per block (the K split): 4, or 8 when
+// there are no more units than CUs so that one block per CU still keeps 8 waves streaming.
+template <bool SWIGLU, int NI, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
+                                                                          const bf16_t* __restrict__ norm_w, float norm_eps,
+                                                                          const bf16_t* __restrict__ residual, void* __restrict__ out,
+                                                                          int B, int N, int K, int out_f32) {
   constexpr int R = SWIGLU ? 2 : 1;
   constexpr int MAXU = MAXSU / R;
   constexpr int XSTAGEB = 2 * NI * WROWB;
+  constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // per wave: [x stage | w stage]; reused for the reduction
   __shared__ float rs_s[16];
-  __shared__ float ss_s[16][2];
+  __shared__ float ss_s[16][NW / 2];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned char* xst = smem + wave * (XSTAGEB + WSTAGEB);
   unsigned char* wst = xst + XSTAGEB;
-  const int nsl = (K + WSK - 1) / WSK;  // K slices; wave w takes w, w + 4, ...
+  const int nsl = (K + WSK - 1) / WSK;  // K slices; wave w takes w, w + NW, ...
   const int NU = (N + 15) >> 4;
   const int grid = gridDim.x;
   const int npass = (NU + grid * MAXU - 1) / (grid * MAXU);
   const bool do_norm = norm_w != nullptr;
   const int lrow = lane >> 5, lchunk = lane & 31;  // staging loads: lane -> (row parity, 16-byte chunk of the 512-byte row piece)
 
-  // ---- RMSNorm statistics of every batch row (LlamaRMSNorm: fp32 mean of squares over K) ----
-  float rsr[NI];
+  // activation slice: NI loads, each 2 rows x 512 contiguous bytes (rows past the batch re-read row B-1: their outputs
+  // are never stored), plus the 512 bytes of RMSNorm gains of the slice
+  u32x4 xr[NI];
+  u32x4 gr = {0u, 0u, 0u, 0u};
+  auto load_x = [&](int sl) {
+    int kg = min(sl * WSK + lchunk * 8, K - 8);
+    asm volatile("" : "+v"(kg));  // keep the row products out of loop-invariant registers (see issue_w)
 #pragma unroll
-  for (int j = 0; j < NI; ++j) rsr[j] = 1.f;
-  if (do_norm) {
-    const int half = tid >> 7, kc = tid & 127;  // thread -> rows {2i + half}, chunks kc, kc + 128, ...
+    for (int j = 0; j < NI; ++j) {
+      const unsigned off = (unsigned)min(2 * j + lrow, B - 1) * (unsigned)K + (unsigned)kg;
+      xr[j] = *reinterpret_cast<const u32x4*>(x + off);
+    }
+    if (do_norm) gr = *reinterpret_cast<const u32x4*>(norm_w + kg);
+  };
+  auto stage_x = [&](int sl) {
+    const bool kvalid = sl * WSK + lchunk * 8 < K;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      u32x4 v = xr[j];
+      if (do_norm) {
+        const float rsj = rs_s[2 * j + lrow];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // weight * hidden.to(dtype): two roundings, like the GEMV prologue
+          const float lo = bf16lo(gr[q]) * rnd<bf16_t>(bf16lo(v[q]) * rsj);
+          const float hi = bf16hi(gr[q]) * rnd<bf16_t>(bf16hi(v[q]) * rsj);
+          bf16x2 p;
+          p[0] = (bf16_t)lo;
+          p[1] = (bf16_t)hi;
+          v[q] = __builtin_bit_cast(unsigned int, p);
+        }
+      }
+      if (!kvalid) v = u32x4{0u, 0u, 0u, 0u};  // k past K contributes zeros (the weight loads there are clamped)
+      *reinterpret_cast<u32x4*>(xst + (2 * j + lrow) * WROWB + lchunk * 16) = v;
+    }
+  };
+
+  // weight stage of sub-unit su of (pass, slice): 8 loads, each 2 rows x 512 contiguous bytes
+  auto issue_w = [&](u32x4* w, int pass, int sl, int su) {
+    const int unit = (pass * MAXU + su / R) * grid + (int)blockIdx.x;
+    // uniform 64-bit base of the unit's first row + a 32-bit per-lane offset.  The per-lane part is made opaque per call:
+    // left visible, LICM hoists the 8 x MAXSU row products out of the K loop and holds them in ~64 VGPRs.
+    const bf16_t* base = W + ((size_t)unit * 16 + (size_t)(su % R) * N) * K;
+    const int rmax = N - 1 - unit * 16;  // last valid row of the unit (>= 15 except in the last unit)
+    int kg = min(sl * WSK + lchunk * 8, K - 8);
+    asm volatile("" : "+v"(kg));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned off = (unsigned)min(2 * j + lrow, rmax) * (unsigned)K + (unsigned)kg;
+      w[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + off));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const int cnt = wave < nsl ? (nsl - wave + NW - 1) / NW : 0;  // slices of this wave
+  if (cnt > 0) load_x(wave);
+
+  // ---- RMSNorm statistics of every batch row (LlamaRMSNorm: fp32 mean of squares over K) ----
+  auto rms_stats = [&]() {
+    constexpr int HT = NT / 2;                      // threads per row parity
+    constexpr int UF = 16 / NI;                     // 16 loads in flight per thread
+    const int half = tid / HT, kc = tid % HT;       // thread -> rows {2i + half}, chunks kc, kc + HT, ...
     float ss[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) ss[i] = 0.f;
     const int nch = K >> 3;
-    for (int c0 = 0; c0 < nch; c0 += 512) {
-      u32x4 v[4][NI];
+    for (int c0 = 0; c0 < nch; c0 += UF * HT) {
+      u32x4 v[UF][NI];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < UF; ++u)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           const int b = min(2 * i + half, B - 1);
-          const int c = min(c0 + u * 128 + kc, nch - 1);
+          const int c = min(c0 + u * HT + kc, nch - 1);
           v[u][i] = *reinterpret_cast<const u32x4*>(x + (size_t)b * K + (size_t)c * 8);
         }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool ok = c0 + u * 128 + kc < nch;
+      for (int u = 0; u < UF; ++u) {
+        const bool ok = c0 + u * HT + kc < nch;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           float s = 0.f;
@@ -88,162 +148,140 @@ __global__ __launch_bounds__(256, 2) void skinny_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const float t = wave_sum(ss[i]);
-      if (lane == 0) ss_s[2 * i + half][wave & 1] = t;
+      if (lane == 0) ss_s[2 * i + half][wave % (NW / 2)] = t;
     }
     __syncthreads();
-    if (tid < 2 * NI) rs_s[tid] = rsqrtf((ss_s[tid][0] + ss_s[tid][1]) / (float)K + norm_eps);
+    if (tid < 2 * NI) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW / 2; ++k) t += ss_s[tid][k];
+      rs_s[tid] = rsqrtf(t / (float)K + norm_eps);
+    }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NI; ++j) rsr[j] = rs_s[2 * j + lrow];
-  }
-
-  // activation slice: NI loads, each 2 rows x 512 contiguous bytes (rows past the batch re-read row B-1: their outputs
-  // are never stored), plus the 512 bytes of RMSNorm gains of the slice
-  u32x4 xr[NI];
-  u32x4 gr = {0u, 0u, 0u, 0u};
-  auto load_x = [&](int sl) {
-    const int kg = min(sl * WSK + lchunk * 8, K - 8);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int b = min(2 * j + lrow, B - 1);
-      xr[j] = *reinterpret_cast<const u32x4*>(x + (size_t)b * K + kg);
-    }
-    if (do_norm) gr = *reinterpret_cast<const u32x4*>(norm_w + kg);
-  };
-  auto stage_x = [&](int sl) {
-    const bool kvalid = sl * WSK + lchunk * 8 < K;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      u32x4 v = xr[j];
-      if (do_norm) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          // weight * hidden.to(dtype): two roundings, like the GEMV prologue
-          const float lo = bf16lo(gr[q]) * rnd<bf16_t>(bf16lo(v[q]) * rsr[j]);
-          const float hi = bf16hi(gr[q]) * rnd<bf16_t>(bf16hi(v[q]) * rsr[j]);
-          bf16x2 p;
-          p[0] = (bf16_t)lo;
-          p[1] = (bf16_t)hi;
-          v[q] = __builtin_bit_cast(unsigned int, p);
-        }
-      }
-      if (!kvalid) v = u32x4{0u, 0u, 0u, 0u};  // k past K contributes zeros (the weight loads there are clamped)
-      *reinterpret_cast<u32x4*>(xst + (2 * j + lrow) * WROWB + lchunk * 16) = v;
-    }
   };
 
-  u32x4 w[8];
-  // weight stage of sub-unit su of (pass, slice): 8 loads, each 2 rows x 512 contiguous bytes
-  auto issue_w = [&](int pass, int sl, int su) {
-    const int unit = (pass * MAXU + su / R) * grid + (int)blockIdx.x;
-    const int kg = min(sl * WSK + lchunk * 8, K - 8);
+  // one pass over K for NSU sub-units.  Two register stages alternate (static parity: 2 slices x NSU stages per trip), the
+  // loads of stage t+1 are issued before stage t is multiplied, so a wave keeps 8-16 KiB of weights in flight.
+  auto run_pass = [&](auto nsu_c, int pass, int nu) {
+    constexpr int NSU = decltype(nsu_c)::value;
+    f32x4 acc[NSU];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int n = min(unit * 16 + 2 * j + lrow, N - 1);
-      const size_t row = (size_t)n + (size_t)(su % R) * N;
-      w[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + row * K + kg));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  if (wave < nsl) load_x(wave);
-  for (int pass = 0; pass < npass; ++pass) {
-    int nu = 0;
+    for (int su = 0; su < NSU; ++su) acc[su] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 wb[2][8];
+    if (cnt > 0) issue_w(wb[0], pass, wave, 0);
+    for (int i = 0; i < cnt; i += 2) {
 #pragma unroll
-    for (int u = 0; u < MAXU; ++u) nu += ((pass * MAXU + u) * grid + (int)blockIdx.x < NU) ? 1 : 0;
-    if (nu == 0) break;  // uniform per block; later passes are empty too
-    const int nsu = nu * R;
-    f32x4 acc[MAXSU];
+      for (int h = 0; h < 2; ++h) {
+        const int sl = wave + NW * (i + h);
+        if (i + h < cnt) {
 #pragma unroll
-    for (int su = 0; su < MAXSU; ++su) acc[su] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int sl = wave; sl < nsl; sl += 4) {
-      issue_w(pass, sl, 0);  // HBM latency overlaps the activation staging below
-      stage_x(sl);
-      if (sl + 4 < nsl) load_x(sl + 4);
-      else if (pass + 1 < npass) load_x(wave);
-      __builtin_amdgcn_wave_barrier();
-      bf16x8 xf[8];
-      const int xrow = (NI == 8) ? (lane & 15) : (lane & 7);
+          for (int su = 0; su < NSU; ++su) {
+            const int cur = (h * NSU + su) & 1;
+            if (su + 1 < NSU) issue_w(wb[cur ^ 1], pass, sl, su + 1);
+            else if (i + h + 1 < cnt) issue_w(wb[cur ^ 1], pass, sl + NW, 0);
+            if (su == 0) {
+              stage_x(sl);
+              if (i + h + 1 < cnt) load_x(sl + NW);
+              else if (pass + 1 < npass) load_x(wave);
+            }
 #pragma unroll
-      for (int s = 0; s < 8; ++s)
-        xf[s] = *reinterpret_cast<const bf16x8*>(xst + xrow * WROWB + (4 * s + (lane >> 4)) * 16);
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(wst + (2 * j + lrow) * WROWB + lchunk * 16) = wb[cur][j];
+            __builtin_amdgcn_wave_barrier();
+            // x fragments are re-read per sub-unit rather than held: 32 VGPRs buy nothing, LDS has the headroom
+            const int xrow = (NI == 8) ? (lane & 15) : (lane & 7);
 #pragma unroll
-      for (int su = 0; su < MAXSU; ++su) {
-        if (su < nsu) {
-          if (su > 0) issue_w(pass, sl, su);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(wst + (2 * j + lrow) * WROWB + lchunk * 16) = w[j];
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wst + (lane & 15) * WROWB + (4 * s + (lane >> 4)) * 16);
-            // D[batch row][weight row] += x[batch row][k] * W[weight row][k]
-            acc[su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[s], wf, acc[su], 0, 0, 0);
+            for (int s = 0; s < 8; ++s) {
+              const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xst + xrow * WROWB + (4 * s + (lane >> 4)) * 16);
+              const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wst + (lane & 15) * WROWB + (4 * s + (lane >> 4)) * 16);
+              // D[batch row][weight row] += x[batch row][k] * W[weight row][k]
+              acc[su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, wf, acc[su], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
           }
-          __builtin_amdgcn_wave_barrier();
         }
       }
     }
 
     // ---- cross-wave reduction (fixed order) + epilogue ----
     __syncthreads();
-    float* redf = reinterpret_cast<float*>(smem);  // [4 waves][MAXSU][64 lanes][4] = 16 KiB
+    float* redf = reinterpret_cast<float*>(smem);  // [NW waves][MAXSU][64 lanes][4]
 #pragma unroll
-    for (int su = 0; su < MAXSU; ++su)
-      if (su < nsu) *reinterpret_cast<f32x4*>(redf + ((wave * MAXSU + su) * 64 + lane) * 4) = acc[su];
+    for (int su = 0; su < NSU; ++su) *reinterpret_cast<f32x4*>(redf + ((wave * MAXSU + su) * 64 + lane) * 4) = acc[su];
     __syncthreads();
-    {
-      const int l2 = tid & 63, q = tid >> 6;
+    for (int e = tid; e < (NSU / R) * 256; e += NT) {
+      const int u = e >> 8, l2 = e & 63, q = (e >> 6) & 3;
       const int b = 4 * (l2 >> 4) + q;
+      const int unit = (pass * MAXU + u) * grid + (int)blockIdx.x;
+      const int n = unit * 16 + (l2 & 15);
+      float a[R];
 #pragma unroll
-      for (int u = 0; u < MAXU; ++u) {
-        if (u < nu) {
-          const int unit = (pass * MAXU + u) * grid + (int)blockIdx.x;
-          const int n = unit * 16 + (l2 & 15);
-          float a[R];
+      for (int r = 0; r < R; ++r) {
+        float t = 0.f;
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            float t = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < 4; ++wv) t += redf[((wv * MAXSU + u * R + r) * 64 + l2) * 4 + q];
-            a[r] = t;
-          }
-          if (b < B && n < N) {
-            if (SWIGLU) {
-              const float g = rnd<bf16_t>(a[0]), up = rnd<bf16_t>(a[R - 1]);
-              reinterpret_cast<bf16_t*>(out)[(size_t)b * N + n] = (bf16_t)(rnd<bf16_t>(silu(g)) * up);
-            } else {
-              float v = rnd<bf16_t>(a[0]);
-              if (residual) v = rnd<bf16_t>((float)residual[(size_t)b * N + n] + v);
-              if (out_f32)
-                reinterpret_cast<float*>(out)[(size_t)b * N + n] = v;
-              else
-                reinterpret_cast<bf16_t*>(out)[(size_t)b * N + n] = (bf16_t)v;
-            }
-          }
+        for (int wv = 0; wv < NW; ++wv) t += redf[((wv * MAXSU + u * R + r) * 64 + l2) * 4 + q];
+        a[r] = t;
+      }
+      if (b < B && n < N) {
+        if (SWIGLU) {
+          const float g = rnd<bf16_t>(a[0]), up = rnd<bf16_t>(a[R - 1]);
+          reinterpret_cast<bf16_t*>(out)[(size_t)b * N + n] = (bf16_t)(rnd<bf16_t>(silu(g)) * up);
+        } else {
+          float v = rnd<bf16_t>(a[0]);
+          if (residual) v = rnd<bf16_t>((float)residual[(size_t)b * N + n] + v);
+          if (out_f32)
+            reinterpret_cast<float*>(out)[(size_t)b * N + n] = v;
+          else
+            reinterpret_cast<bf16_t*>(out)[(size_t)b * N + n] = (bf16_t)v;
         }
       }
     }
     __syncthreads();  // the reduction buffer aliases the wave-private stages of the next pass
+  };
+
+  if (do_norm) rms_stats();
+  for (int pass = 0; pass < npass; ++pass) {
+    int nu = 0;
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) nu += ((pass * MAXU + u) * grid + (int)blockIdx.x < NU) ? 1 : 0;
+    if (nu == 0) break;  // uniform per block; later passes are empty too
+    switch (nu * R) {
+      case 1: run_pass(std::integral_constant<int, 1>{}, pass, nu); break;
+      case 2: run_pass(std::integral_constant<int, 2>{}, pass, nu); break;
+      case 3: run_pass(std::integral_constant<int, 3>{}, pass, nu); break;
+      default: run_pass(std::integral_constant<int, 4>{}, pass, nu); break;
+    }
   }
 }
 
-template <bool SWIGLU, int NI>
+template <bool SWIGLU, int NI, int NW>
 int launch_skinny(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out, int batch,
                   int N, int K, int out_f32, int grid, hipStream_t s) {
-  constexpr int lds = 4 * (2 * NI * WROWB + WSTAGEB);
-  static_assert(lds >= 4 * MAXSU * 64 * 4 * 4, "reduction buffer must fit");
-  auto kfn = skinny_kernel<SWIGLU, NI>;
+  constexpr int lds = NW * (2 * NI * WROWB + WSTAGEB);
+  static_assert(lds >= NW * MAXSU * 64 * 4 * 4, "reduction buffer must fit");
+  static_assert(lds <= 160 * 1024, "LDS");
+  auto kfn = skinny_kernel<SWIGLU, NI, NW>;
   static bool attr_set = false;
   if (lds > 48 * 1024 && !attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)W, (const bf16_t*)norm_w, eps,
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * NW), lds, s, (const bf16_t*)x, (const bf16_t*)W, (const bf16_t*)norm_w, eps,
                      (const bf16_t*)residual, out, batch, N, K, out_f32);
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
+}
+
+template <bool SWIGLU, int NI>
+int launch_skinny_nw(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out, int batch,
+                     int N, int K, int out_f32, hipStream_t s) {
+  const int cus = srgpt_device_cus();
+  const int NU = (N + 15) / 16;
+  if (NU <= cus) return launch_skinny<SWIGLU, NI, 8>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, NU, s);
+  // balanced grid: every block gets the same number of units whenever N allows (e.g. 896 SwiGLU units -> 448 blocks x 2)
+  const int maxgrid = cus * 2;
+  const int per = (NU + maxgrid - 1) / maxgrid;  // units per block (more than MAXSU/R -> several passes in the kernel)
+  const int grid = (NU + per - 1) / per;
+  return launch_skinny<SWIGLU, NI, 4>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, grid, s);
 }
 
 }  // namespace
@@ -253,15 +291,9 @@ int srgpt_skinny_launch(const void* x, const void* W, const void* norm_w, float 
                         int batch, int N, int K, int swiglu, int out_f32, hipStream_t s) {
   SRGPT_CHECK(batch >= 1 && batch <= 16, SRGPT_ERR_ARG, "skinny: batch %d outside 1..16", batch);
   SRGPT_CHECK(K % 8 == 0 && K >= 8, SRGPT_ERR_ARG, "skinny: K=%d must be a multiple of 8", K);
-  const int cus = srgpt_device_cus();
-  const int NU = (N + 15) / 16;
-  // balanced grid: every block gets the same number of units whenever N allows (e.g. 896 SwiGLU units -> 448 blocks x 2)
-  const int maxgrid = cus * 2;
-  const int per = (NU + maxgrid - 1) / maxgrid;  // units per block (more than MAXSU/R -> several passes in the kernel)
-  const int grid = (NU + per - 1) / per;
   if (batch <= 8)
-    return swiglu ? launch_skinny<true, 4>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, grid, s)
-                  : launch_skinny<false, 4>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, grid, s);
-  return swiglu ? launch_skinny<true, 8>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, grid, s)
-                : launch_skinny<false, 8>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, grid, s);
+    return swiglu ? launch_skinny_nw<true, 4>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, s)
+                  : launch_skinny_nw<false, 4>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, s);
+  return swiglu ? launch_skinny_nw<true, 8>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, s)
+                : launch_skinny_nw<false, 8>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, s);
 }
