@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--max-new-tokens", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--batch", type=int, default=1, help="equal-length requests per generate() call per GPU (<= 4)")
+    ap.add_argument("--batch", type=int, default=1, help="equal-length requests per generate() call per GPU")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8 = BASELINE configs[4]: weight-only OCP e4m3fn for the streamed LLM matrices (W8A16); NOT the headline")
     return ap.parse_args()
 
 
@@ -172,7 +174,8 @@ def main():
                     continue
             keep.append(k)
         sd_cpu = {k: sd[k].cpu() for k in keep}
-    model = LlavaLlamaModel(cfg, sd, device=device, dtype=dtype, rope_positions=1024, consume_state_dict=True)
+    model = LlavaLlamaModel(cfg, sd, device=device, dtype=dtype, rope_positions=1024, consume_state_dict=True,
+                            llm_weight_format="fp8" if args.weights == "fp8" else "native")
     del sd
     model.engine.use_graph = not args.no_graph
     torch.cuda.synchronize()
@@ -216,16 +219,25 @@ def main():
     if rank == 0:
         x = torch.randn((1, cfg.hidden), device=device).to(dtype)
         outb = torch.empty((1, cfg.inter), device=device, dtype=dtype)
-        wgu = eng.w.llm_t["wgu"]
-        for wmat in wgu:  # warm (JIT-free, but first-touch TLB)
-            ops.gemv(x, wmat, norm_w=eng.w.llm_t["mlp_norm"][0], eps=cfg.rms_eps, swiglu=True, out=outb)
+        fp8 = args.weights == "fp8"
+        wgu = eng.w.llm_q["wgu"][0] if fp8 else eng.w.llm_t["wgu"]
+        wsc = eng.w.llm_q["wgu"][1] if fp8 else [None] * len(wgu)
+
+        def gateup(i):
+            if fp8:
+                ops.gemv_w8(x, wgu[i], wsc[i], norm_w=eng.w.llm_t["mlp_norm"][i], eps=cfg.rms_eps, swiglu=True, out=outb)
+            else:
+                ops.gemv(x, wgu[i], norm_w=eng.w.llm_t["mlp_norm"][i], eps=cfg.rms_eps, swiglu=True, out=outb)
+
+        for i in range(len(wgu)):  # warm (JIT-free, but first-touch TLB)
+            gateup(i)
         reps = 3
         evs = []
         for _ in range(reps):
-            for i, wmat in enumerate(wgu):
+            for i in range(len(wgu)):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ops.gemv(x, wmat, norm_w=eng.w.llm_t["mlp_norm"][i], eps=cfg.rms_eps, swiglu=True, out=outb)
+                gateup(i)
                 e1.record()
                 evs.append((e0, e1))
         torch.cuda.synchronize()
@@ -245,9 +257,10 @@ def main():
         wbytes = eng.w.llm_weight_bytes()
         traffic = None  # HBM bytes per launch from the PMC pass (separate rocprofv3 --pmc run, 2x FETCH_SIZE correction)
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")
-        if args.model == "vila15_8b" and os.path.exists(pmc):
+        if args.model == "vila15_8b" and os.path.exists(pmc) and not fp8:
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-        roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16,1,swiglu> (decode gate/up projection, 54% of streamed bytes)",
+        roof = {"bound": "hbm", "kernel": ("skinny_kernel<swiglu, W8> (decode gate/up projection, fp8 weights)" if fp8 else
+                                           "gemv_kernel<bf16,1,swiglu> (decode gate/up projection, 54% of streamed bytes)"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5),
                 "how": "hip events around each launch on the launch stream, 3 sweeps over the 32 layers' matrices (cold in L3)",
@@ -271,12 +284,13 @@ def main():
             "metric": "region-grounded output tokens/sec @ VILA1.5-8B, 8 regions, greedy",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (seeded random weights of the named architecture; random images/depth/box masks/ids)",
+            "dtype": "bf16" if args.weights == "bf16" else "bf16 activations / fp8-e4m3fn LLM weights (W8A16)", "data": "synthetic (seeded random weights of the named architecture; random images/depth/box masks/ids)",
             "config": {"workload": ("BASELINE configs[1]: SpatialRGPT-VILA1.5-8B geometry (Llama-3-8B 32L/4096/GQA-8 + SigLIP-so400m "
                                     "384px x2 passes + regiongpt extractor + mlp_downsample), 8 region masks, bs=1 per GPU, "
                                     f"prompt {args.prompt_len} ids -> T=259, greedy {G} new tokens") if args.model == "vila15_8b" else args.model,
                        "requests_per_step_per_gpu": args.batch, "new_tokens_per_request": G, "parallelism": f"dp{world}",
-                       "decode": "hipGraph" if not args.no_graph else "eager", "build_s": round(t_build, 1)},
+                       "decode": "hipGraph" if not args.no_graph else "eager", "build_s": round(t_build, 1),
+                       "llm_weights": args.weights},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

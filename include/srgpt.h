@@ -72,13 +72,21 @@ int srgpt_gemm(const void* A, const void* W, const void* bias, const void* resid
                int M, int N, int K, int lda, int ldc, int act, int bias_mod, int res_mod,
                int out_f32, int out_mode, int gw, void* ws, int64_t ws_bytes, int dtype, srgpt_stream_t stream);
 
-/* Decode-only fused GEMVs (M = batch <= 4 rows), weights streamed once from HBM:
+/* Decode-only fused GEMVs (any batch; 1-2 rows: VALU kernel, 3+ rows: MFMA kernel, 16 rows per weight pass), weights
+ * streamed once from HBM:
  *   norm_w != NULL : x <- RMSNorm(x) * norm_w first (modeling_llama.py:61-75) (rounded to dtype like torch)
  *   swiglu != 0    : W = [gate rows(N); up rows(N)], out[n] = silu(gate.x) * (up.x) (modeling_llama.py:221)
  *   residual       : out = residual + (W x)   (decoder layer residual adds, modeling_llama.py:650-684)
  */
 int srgpt_gemv(const void* x, const void* W, const void* norm_w, float norm_eps, const void* residual,
                void* out, int batch, int N, int K, int swiglu, int out_f32, int dtype, srgpt_stream_t stream);
+/* Same product with weight-only fp8 quantisation (W8A16, BASELINE config 5): W8 = OCP e4m3fn bytes [N (2N if swiglu), K],
+ * wscale = one fp32 scale per weight row, x / norm_w / residual / out bf16 (out fp32 if out_f32):
+ *   out[b, n] = round_bf16( (sum_k x[b,k] * fp8(W8[n,k])) * wscale[n] ), fp32 accumulation; same fusions as srgpt_gemv.
+ * The reference has no fp8 path (it offers bitsandbytes 8/4-bit loading, builder.py:51-60); this replaces that option. */
+int srgpt_gemv_w8(const void* x, const void* W8, const float* wscale, const void* norm_w, float norm_eps,
+                  const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32,
+                  srgpt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Normalisations.
@@ -221,6 +229,19 @@ typedef struct {
   const void* const* mlp_norm;  /* per layer [hidden] */
   const void* const* wgu;       /* per layer [2*inter, hidden]  rows gate;up */
   const void* const* wdown;     /* per layer [hidden, inter] */
+  /* Optional fp8 (OCP e4m3fn) copies + per-row fp32 scales of the five streamed matrices.  When wqkv8 != NULL the DECODE
+   * step streams these through srgpt_gemv_w8 (half the bytes per token); prefill keeps using the dtype matrices above,
+   * which the loader fills with the dequantised values so both phases see the same weights. */
+  const void* lm_head8;
+  const float* lm_head_scale;
+  const void* const* wqkv8;
+  const float* const* wqkv_scale;
+  const void* const* wo8;
+  const float* const* wo_scale;
+  const void* const* wgu8;
+  const float* const* wgu_scale;
+  const void* const* wdown8;
+  const float* const* wdown_scale;
 } srgpt_llm_weights;
 
 typedef struct {

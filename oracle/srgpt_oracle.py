@@ -617,3 +617,25 @@ def synth_inputs(cfg: SrgptConfig, *, batch=1, regions=8, prompt_len=64, seed=1,
         assert len(seq) == prompt_len, (len(seq), prompt_len)
         ids[b] = torch.tensor(seq)
     return ids, images, depths, masks
+
+
+def fp8_dequantised_weights(w: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Weight-only fp8 option (BASELINE config 5; no counterpart in the reference, which offers bitsandbytes int8 at
+    builder.py:51-52): every LLM Linear weight (q/k/v/o/gate/up/down projections and lm_head) is replaced by
+    dequant(quant(W)) with one power-of-two fp32 scale per output row -- the smallest 2^k with max|row| / 2^k <= 448 --
+    and codes = round-to-nearest-even OCP e4m3fn (torch.float8_e4m3fn).  The oracle then runs unchanged on these weights."""
+    out = dict(w)
+    for k, t in w.items():
+        if not k.startswith("llm."):
+            continue
+        if k.endswith("_proj.weight") or k == "llm.lm_head.weight":
+            tf = t.float()
+            amax = tf.abs().amax(dim=1).clamp_min(2.0 ** -100)
+            kk = torch.ceil(torch.log2(amax.double() / 448.0)).to(torch.int32)  # double: exact enough to place the power
+            sc = torch.ldexp(torch.ones_like(amax), kk)
+            # guard the log2 boundary: the scale must satisfy amax/sc <= 448 < 2*amax/sc... (exact check, exact fix)
+            sc = torch.where(amax / sc > 448.0, sc * 2, sc)
+            sc = torch.where(amax / (sc / 2) <= 448.0, sc / 2, sc)
+            q = (tf / sc[:, None]).to(torch.float8_e4m3fn)
+            out[k] = (q.float() * sc[:, None]).to(t.dtype)
+    return out

@@ -42,6 +42,9 @@ class LlmWeights(C.Structure):
         ("rope_cos", vp), ("rope_sin", vp), ("embed", vp), ("final_norm", vp), ("lm_head", vp),
         ("attn_norm", C.POINTER(vp)), ("wqkv", C.POINTER(vp)), ("wo", C.POINTER(vp)),
         ("mlp_norm", C.POINTER(vp)), ("wgu", C.POINTER(vp)), ("wdown", C.POINTER(vp)),
+        ("lm_head8", vp), ("lm_head_scale", vp),
+        ("wqkv8", C.POINTER(vp)), ("wqkv_scale", C.POINTER(vp)), ("wo8", C.POINTER(vp)), ("wo_scale", C.POINTER(vp)),
+        ("wgu8", C.POINTER(vp)), ("wgu_scale", C.POINTER(vp)), ("wdown8", C.POINTER(vp)), ("wdown_scale", C.POINTER(vp)),
     ]
 
 
@@ -59,6 +62,7 @@ _SIGNATURES = {
     "srgpt_gemm_ws_bytes": (i64, [i32, i32]),
     "srgpt_gemm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
     "srgpt_gemv": (i32, [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "srgpt_gemv_w8": (i32, [vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "srgpt_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, i32, i32, vp]),
     "srgpt_rmsnorm": (i32, [vp, vp, vp, i32, i32, f32, i32, vp]),
     "srgpt_attention": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64, i64,

@@ -86,8 +86,11 @@ def config_from_checkpoint(model_path: str) -> SrgptConfig:
 
 def load_pretrained_model(model_path, model_name, model_base=None, load_8bit=False, load_4bit=False, device_map="auto",
                           device="cuda", dtype=torch.bfloat16, **kwargs):
-    if load_8bit or load_4bit:
-        raise NotImplementedError("bitsandbytes 8/4-bit loading is out of scope (builder.py:40-60)")
+    if load_4bit:
+        raise NotImplementedError("bitsandbytes 4-bit loading is out of scope (builder.py:40-60)")
+    # load_8bit (bitsandbytes int8 in the reference, builder.py:51-52) maps to the engine's 8-bit option: weight-only OCP
+    # fp8 (e4m3fn, one scale per output row) for the LLM matrices the decode step streams
+    llm_weight_format = "fp8" if load_8bit else kwargs.pop("llm_weight_format", "native")
     if model_base is not None or "lora" in model_name.lower():
         raise NotImplementedError("LoRA / delta checkpoints are out of scope (builder.py:64-139)")
     from .model import LlavaLlamaModel
@@ -147,7 +150,7 @@ def load_pretrained_model(model_path, model_name, model_base=None, load_8bit=Fal
             image_processor = SrgptImageProcessor(size=cfg.image_size)
 
     model = LlavaLlamaModel(cfg, sd, device=device, dtype=dtype, tokenizer=tokenizer, image_processor=image_processor,
-                            consume_state_dict=True)
+                            consume_state_dict=True, llm_weight_format=llm_weight_format)
     lc = _read_json(os.path.join(model_path, "llm", "config.json"))
     context_len = _read_json(os.path.join(model_path, "config.json")).get("max_sequence_length", 2048) \
         if "max_sequence_length" in lc else 2048  # builder.py:207-211

@@ -323,17 +323,32 @@ extern "C" int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state
   const LlmWs d = carve_llm(w, B, st->ws_tokens, st->ws);  // same carve as prefill (sized by ws_tokens)
   const size_t layer_kv = (size_t)B * Hkv * st->max_pos * D * es;
   SRGPT_TRY(srgpt_embed_rows(w->embed, st->tok, d.xd, B, Hd, dt, stream));
+  // fp8 copies present -> the decode step streams them (W8A16, half the bytes per token)
+  const bool w8 = w->wqkv8 != nullptr;
+  if (w8)
+    SRGPT_CHECK(dt == SRGPT_BF16 && w->wo8 && w->wgu8 && w->wdown8 && w->lm_head8 && w->wqkv_scale && w->wo_scale &&
+                    w->wgu_scale && w->wdown_scale && w->lm_head_scale,
+                SRGPT_ERR_ARG, "srgpt_llm_decode_step: fp8 weights need bf16 activations and all five matrices + scales");
+  auto mv = [&](const void* x, const void* Wd, const void* W8p, const float* sc, const void* norm, const void* res, void* out,
+                int N, int K, int swiglu, int f32) -> int {
+    if (w8) return srgpt_gemv_w8(x, W8p, sc, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, stream);
+    return srgpt_gemv(x, Wd, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, dt, stream);
+  };
   for (int i = 0; i < w->layers; ++i) {
     char* kc = reinterpret_cast<char*>(st->kcache) + (size_t)i * layer_kv;
     char* vc = reinterpret_cast<char*>(st->vcache) + (size_t)i * layer_kv;
-    SRGPT_TRY(srgpt_gemv(d.xd, w->wqkv[i], w->attn_norm[i], w->rms_eps, nullptr, d.qkvd, B, QW, Hd, 0, 0, dt, stream));
+    SRGPT_TRY(mv(d.xd, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, w->attn_norm[i], nullptr,
+                 d.qkvd, QW, Hd, 0, 0));
     SRGPT_TRY(srgpt_decode_attention(d.qkvd, kc, vc, st->pos, w->rope_cos, w->rope_sin, d.attnd, d.dws, B, Hq, Hkv, D,
                                      st->max_pos, dt, stream));
-    SRGPT_TRY(srgpt_gemv(d.attnd, w->wo[i], nullptr, 0.f, d.xd, d.xd, B, Hd, Hq * D, 0, 0, dt, stream));
-    SRGPT_TRY(srgpt_gemv(d.xd, w->wgu[i], w->mlp_norm[i], w->rms_eps, nullptr, d.actd, B, I, Hd, 1, 0, dt, stream));
-    SRGPT_TRY(srgpt_gemv(d.actd, w->wdown[i], nullptr, 0.f, d.xd, d.xd, B, Hd, I, 0, 0, dt, stream));
+    SRGPT_TRY(mv(d.attnd, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, nullptr, d.xd, d.xd, Hd,
+                 Hq * D, 0, 0));
+    SRGPT_TRY(mv(d.xd, w->wgu[i], w8 ? w->wgu8[i] : nullptr, w8 ? w->wgu_scale[i] : nullptr, w->mlp_norm[i], nullptr,
+                 d.actd, I, Hd, 1, 0));
+    SRGPT_TRY(mv(d.actd, w->wdown[i], w8 ? w->wdown8[i] : nullptr, w8 ? w->wdown_scale[i] : nullptr, nullptr, d.xd, d.xd,
+                 Hd, I, 0, 0));
   }
-  SRGPT_TRY(srgpt_gemv(d.xd, w->lm_head, w->final_norm, w->rms_eps, nullptr, st->logits, B, w->vocab, Hd, 0, 1, dt, stream));
+  SRGPT_TRY(mv(d.xd, w->lm_head, w->lm_head8, w->lm_head_scale, w->final_norm, nullptr, st->logits, w->vocab, Hd, 0, 1));
   return greedy_pick(w, st, d, 1, s);
 }
 

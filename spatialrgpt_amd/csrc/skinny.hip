@@ -31,8 +31,11 @@ constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumu
 
 // NI = x rows staged per wave / 2: 4 (batch <= 8) or 8 (batch <= 16).  NW = waves per block (the K split): 4, or 8 when
 // there are no more units than CUs so that one block per CU still keeps 8 waves streaming.
-template <bool SWIGLU, int NI, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
+// W8: the weights are OCP fp8 e4m3fn bytes with one fp32 scale per weight row (W8A16): a stage is 8 loads of 8 bytes per lane
+// (2 rows x 256 bytes each), widened to bf16 (exact) on the way into LDS; the row scale multiplies the fp32 dot product.
+template <bool SWIGLU, int NI, int NW, bool W8>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const bf16_t* __restrict__ x, const void* __restrict__ Wv,
+                                                                          const float* __restrict__ wscale,
                                                                           const bf16_t* __restrict__ norm_w, float norm_eps,
                                                                           const bf16_t* __restrict__ residual, void* __restrict__ out,
                                                                           int B, int N, int K, int out_f32) {
@@ -40,6 +43,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   constexpr int MAXU = MAXSU / R;
   constexpr int XSTAGEB = 2 * NI * WROWB;
   constexpr int NT = 64 * NW;
+  using WReg = typename std::conditional<W8, u32x2, u32x4>::type;  // one staged weight load per lane
+  constexpr int WEB = W8 ? 1 : 2;                                  // bytes per weight element
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // per wave: [x stage | w stage]; reused for the reduction
   __shared__ float rs_s[16];
   __shared__ float ss_s[16][NW / 2];
@@ -92,19 +97,35 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   };
 
   // weight stage of sub-unit su of (pass, slice): 8 loads, each 2 rows x 512 contiguous bytes
-  auto issue_w = [&](u32x4* w, int pass, int sl, int su) {
+  auto issue_w = [&](WReg* w, int pass, int sl, int su) {
     const int unit = (pass * MAXU + su / R) * grid + (int)blockIdx.x;
     // uniform 64-bit base of the unit's first row + a 32-bit per-lane offset.  The per-lane part is made opaque per call:
     // left visible, LICM hoists the 8 x MAXSU row products out of the K loop and holds them in ~64 VGPRs.
-    const bf16_t* base = W + ((size_t)unit * 16 + (size_t)(su % R) * N) * K;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(Wv) + ((size_t)unit * 16 + (size_t)(su % R) * N) * K * WEB;
     const int rmax = N - 1 - unit * 16;  // last valid row of the unit (>= 15 except in the last unit)
     int kg = min(sl * WSK + lchunk * 8, K - 8);
     asm volatile("" : "+v"(kg));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const unsigned off = (unsigned)min(2 * j + lrow, rmax) * (unsigned)K + (unsigned)kg;
-      w[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + off));
+      const unsigned off = ((unsigned)min(2 * j + lrow, rmax) * (unsigned)K + (unsigned)kg) * WEB;
+      w[j] = __builtin_nontemporal_load(reinterpret_cast<const WReg*>(base + off));
       __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // 8 fp8 -> 8 bf16 (every e4m3 value is exactly representable: the high half of the fp32 conversion is the bf16)
+  auto widen = [&](const WReg& r) -> u32x4 {
+    if constexpr (W8) {
+      u32x4 o;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)r[h], false);
+        const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)r[h], true);
+        o[2 * h] = __builtin_amdgcn_perm(__float_as_uint(lo[1]), __float_as_uint(lo[0]), 0x07060302u);
+        o[2 * h + 1] = __builtin_amdgcn_perm(__float_as_uint(hi[1]), __float_as_uint(hi[0]), 0x07060302u);
+      }
+      return o;
+    } else {
+      return r;
     }
   };
 
@@ -160,32 +181,36 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     __syncthreads();
   };
 
-  // one pass over K for NSU sub-units.  Two register stages alternate (static parity: 2 slices x NSU stages per trip), the
-  // loads of stage t+1 are issued before stage t is multiplied, so a wave keeps 8-16 KiB of weights in flight.
+  // one pass over K for NSU sub-units
   auto run_pass = [&](auto nsu_c, int pass, int nu) {
     constexpr int NSU = decltype(nsu_c)::value;
     f32x4 acc[NSU];
 #pragma unroll
     for (int su = 0; su < NSU; ++su) acc[su] = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 wb[2][8];
-    if (cnt > 0) issue_w(wb[0], pass, wave, 0);
-    for (int i = 0; i < cnt; i += 2) {
+    // register ring of DEPTH weight stages with static slot indices (a trip = DEPTH slices x NSU stages, a multiple of
+    // DEPTH): the loads of stage t+DEPTH-1 are issued before stage t is multiplied.  bf16: 2 x 8 KiB, fp8: 2 x 4 KiB.
+    constexpr int DEPTH = 2;  // measured: a 4-deep ring of 4 KiB fp8 stages is slower than 2-deep (3.61 vs 3.85 TB/s on gate/up)
+    WReg wb[DEPTH][8];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+    for (int f = 0; f < DEPTH - 1; ++f)
+      if (f / NSU < cnt) issue_w(wb[f % DEPTH], pass, wave + NW * (f / NSU), f % NSU);
+    for (int i = 0; i < cnt; i += DEPTH) {
+#pragma unroll
+      for (int h = 0; h < DEPTH; ++h) {
         const int sl = wave + NW * (i + h);
         if (i + h < cnt) {
 #pragma unroll
           for (int su = 0; su < NSU; ++su) {
-            const int cur = (h * NSU + su) & 1;
-            if (su + 1 < NSU) issue_w(wb[cur ^ 1], pass, sl, su + 1);
-            else if (i + h + 1 < cnt) issue_w(wb[cur ^ 1], pass, sl + NW, 0);
+            const int cur = (h * NSU + su) % DEPTH;
+            const int fn = h * NSU + su + DEPTH - 1;  // stage to prefetch, relative to this trip
+            if (i + fn / NSU < cnt) issue_w(wb[fn % DEPTH], pass, wave + NW * (i + fn / NSU), fn % NSU);
             if (su == 0) {
               stage_x(sl);
               if (i + h + 1 < cnt) load_x(sl + NW);
               else if (pass + 1 < npass) load_x(wave);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(wst + (2 * j + lrow) * WROWB + lchunk * 16) = wb[cur][j];
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(wst + (2 * j + lrow) * WROWB + lchunk * 16) = widen(wb[cur][j]);
             __builtin_amdgcn_wave_barrier();
             // x fragments are re-read per sub-unit rather than held: 32 VGPRs buy nothing, LDS has the headroom
             const int xrow = (NI == 8) ? (lane & 15) : (lane & 7);
@@ -219,6 +244,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
         float t = 0.f;
 #pragma unroll
         for (int wv = 0; wv < NW; ++wv) t += redf[((wv * MAXSU + u * R + r) * 64 + l2) * 4 + q];
+        if (W8) t *= wscale[min(n, N - 1) + r * N];
         a[r] = t;
       }
       if (b < B && n < N) {
@@ -253,47 +279,74 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   }
 }
 
-template <bool SWIGLU, int NI, int NW>
-int launch_skinny(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out, int batch,
-                  int N, int K, int out_f32, int grid, hipStream_t s) {
+template <bool SWIGLU, int NI, int NW, bool W8>
+int launch_skinny(const void* x, const void* W, const float* wscale, const void* norm_w, float eps, const void* residual,
+                  void* out, int batch, int N, int K, int out_f32, int grid, hipStream_t s) {
   constexpr int lds = NW * (2 * NI * WROWB + WSTAGEB);
   static_assert(lds >= NW * MAXSU * 64 * 4 * 4, "reduction buffer must fit");
   static_assert(lds <= 160 * 1024, "LDS");
-  auto kfn = skinny_kernel<SWIGLU, NI, NW>;
+  auto kfn = skinny_kernel<SWIGLU, NI, NW, W8>;
   static bool attr_set = false;
   if (lds > 48 * 1024 && !attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * NW), lds, s, (const bf16_t*)x, (const bf16_t*)W, (const bf16_t*)norm_w, eps,
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * NW), lds, s, (const bf16_t*)x, W, wscale, (const bf16_t*)norm_w, eps,
                      (const bf16_t*)residual, out, batch, N, K, out_f32);
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }
 
-template <bool SWIGLU, int NI>
-int launch_skinny_nw(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out, int batch,
-                     int N, int K, int out_f32, hipStream_t s) {
+template <bool SWIGLU, int NI, bool W8>
+int launch_skinny_nw(const void* x, const void* W, const float* wscale, const void* norm_w, float eps, const void* residual,
+                     void* out, int batch, int N, int K, int out_f32, hipStream_t s) {
   const int cus = srgpt_device_cus();
   const int NU = (N + 15) / 16;
-  if (NU <= cus) return launch_skinny<SWIGLU, NI, 8>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, NU, s);
+  if (NU <= cus) return launch_skinny<SWIGLU, NI, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, NU, s);
   // balanced grid: every block gets the same number of units whenever N allows (e.g. 896 SwiGLU units -> 448 blocks x 2)
   const int maxgrid = cus * 2;
   const int per = (NU + maxgrid - 1) / maxgrid;  // units per block (more than MAXSU/R -> several passes in the kernel)
   const int grid = (NU + per - 1) / per;
-  return launch_skinny<SWIGLU, NI, 4>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, grid, s);
+  return launch_skinny<SWIGLU, NI, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, grid, s);
+}
+
+template <bool W8>
+int skinny_dispatch(const void* x, const void* W, const float* wscale, const void* norm_w, float eps, const void* residual,
+                    void* out, int batch, int N, int K, int swiglu, int out_f32, hipStream_t s) {
+  SRGPT_CHECK(batch >= 1 && batch <= 16, SRGPT_ERR_ARG, "skinny: batch %d outside 1..16", batch);
+  SRGPT_CHECK(K % 8 == 0 && K >= 8, SRGPT_ERR_ARG, "skinny: K=%d must be a multiple of 8", K);
+  if (batch <= 8)
+    return swiglu ? launch_skinny_nw<true, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s)
+                  : launch_skinny_nw<false, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s);
+  return swiglu ? launch_skinny_nw<true, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s)
+                : launch_skinny_nw<false, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s);
 }
 
 }  // namespace
 
-// host entry used by srgpt_gemv (gemv.hip) for batches of up to 16 rows, bf16
+// host entry used by srgpt_gemv (gemv.hip) for batches of up to 16 rows, bf16 weights
 int srgpt_skinny_launch(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
                         int batch, int N, int K, int swiglu, int out_f32, hipStream_t s) {
-  SRGPT_CHECK(batch >= 1 && batch <= 16, SRGPT_ERR_ARG, "skinny: batch %d outside 1..16", batch);
-  SRGPT_CHECK(K % 8 == 0 && K >= 8, SRGPT_ERR_ARG, "skinny: K=%d must be a multiple of 8", K);
-  if (batch <= 8)
-    return swiglu ? launch_skinny_nw<true, 4>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, s)
-                  : launch_skinny_nw<false, 4>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, s);
-  return swiglu ? launch_skinny_nw<true, 8>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, s)
-                : launch_skinny_nw<false, 8>(x, W, norm_w, eps, residual, out, batch, N, K, out_f32, s);
+  return skinny_dispatch<false>(x, W, nullptr, norm_w, eps, residual, out, batch, N, K, swiglu, out_f32, s);
+}
+
+// Decode-path product with fp8 (OCP e4m3fn) weights and one fp32 scale per weight row, bf16 activations (W8A16):
+// out[b, n] = bf16( (sum_k x[b, k] * fp8(W8[n, k])) * wscale[n] ), same fusions as srgpt_gemv.  Any batch size
+// (16 rows per weight pass).
+extern "C" int srgpt_gemv_w8(const void* x, const void* W8, const float* wscale, const void* norm_w, float norm_eps,
+                             const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32,
+                             srgpt_stream_t stream) {
+  SRGPT_CHECK(x && W8 && wscale && out, SRGPT_ERR_ARG, "srgpt_gemv_w8: null pointer");
+  SRGPT_CHECK(N > 0 && K > 0 && batch > 0, SRGPT_ERR_ARG, "srgpt_gemv_w8: bad shape");
+  SRGPT_CHECK(K % 8 == 0, SRGPT_ERR_ARG, "srgpt_gemv_w8: K=%d must be a multiple of 8", K);
+  SRGPT_CHECK(!(swiglu && (residual || out_f32)), SRGPT_ERR_ARG, "srgpt_gemv_w8: swiglu excludes residual/out_f32");
+  hipStream_t s = as_stream(stream);
+  const size_t on = out_f32 ? sizeof(float) : 2;
+  for (int b0 = 0; b0 < batch; b0 += 16) {
+    const int nb = batch - b0 < 16 ? batch - b0 : 16;
+    SRGPT_TRY(skinny_dispatch<true>((const char*)x + (size_t)b0 * K * 2, W8, wscale, norm_w, norm_eps,
+                                    residual ? (const char*)residual + (size_t)b0 * N * 2 : nullptr,
+                                    (char*)out + (size_t)b0 * N * on, nb, N, K, swiglu, out_f32, s));
+  }
+  return SRGPT_OK;
 }

@@ -69,7 +69,7 @@ class DecodeState:
 
 class SrgptEngine:
     def __init__(self, cfg: SrgptConfig, state_dict: Dict[str, torch.Tensor], device="cuda", dtype=torch.bfloat16,
-                 rope_positions: int = 0, consume_state_dict: bool = False):
+                 rope_positions: int = 0, consume_state_dict: bool = False, llm_weight_format: str = "native"):
         L.load()  # fail loudly if the HIP extension is missing
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         if self.device.type != "cuda":
@@ -80,7 +80,8 @@ class SrgptEngine:
             raise NotImplementedError(f"{cfg.region_extractor_type} not implemented")  # base_extractor.py:160-161
         if cfg.select_feature not in ("cls_patch", "patch"):
             raise ValueError(f"Unexpected select feature: {cfg.select_feature}")
-        self.w = PreparedWeights(cfg, state_dict, self.device, dtype, rope_positions, consume=consume_state_dict)
+        self.w = PreparedWeights(cfg, state_dict, self.device, dtype, rope_positions, consume=consume_state_dict,
+                                 llm_weight_format=llm_weight_format)
         self._state: Optional[DecodeState] = None
         self._vit_ws: Optional[torch.Tensor] = None
         self.use_graph = True

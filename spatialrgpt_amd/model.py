@@ -106,10 +106,10 @@ class LlavaLlamaModel:
 
     def __init__(self, config: SrgptConfig, state_dict: Dict[str, torch.Tensor], device="cuda",
                  dtype=torch.bfloat16, tokenizer=None, image_processor=None, rope_positions: int = 0,
-                 consume_state_dict: bool = False):
+                 consume_state_dict: bool = False, llm_weight_format: str = "native"):
         self.config = config
         self.engine = SrgptEngine(config, state_dict, device=device, dtype=dtype, rope_positions=rope_positions,
-                                  consume_state_dict=consume_state_dict)
+                                  consume_state_dict=consume_state_dict, llm_weight_format=llm_weight_format)
         self.tokenizer = tokenizer
         self.vision_tower = _VisionTower(self.engine, image_processor)
         self.region_extractor = _RegionExtractor(self.engine) if config.enable_region else None

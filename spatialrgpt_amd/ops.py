@@ -81,6 +81,34 @@ def gemv(x, w, norm_w=None, eps=0.0, residual=None, swiglu=False, out=None, out_
     return out
 
 
+def quantize_fp8_rows(w: torch.Tensor):
+    """Weight-only fp8 quantisation used by the decode path.  Per output row: scale = the smallest power of two with
+    max|row| / scale <= 448 (exact on every device: frexp / ldexp, no division), codes = OCP e4m3fn bytes of row / scale
+    (round to nearest even).  A power-of-two scale costs a floating-point format nothing in relative precision.
+    Returns (codes uint8 [N, K], scale fp32 [N], dequantised weights in w.dtype)."""
+    wf = w.float()
+    m, e = torch.frexp(wf.abs().amax(dim=1).clamp_min(2.0 ** -100))  # amax = m * 2^e, m in [0.5, 1)
+    k = e - 9 + (m > 0.875).to(e.dtype)                              # 448 = 0.875 * 2^9
+    scale = torch.ldexp(torch.ones_like(m), k)
+    q = (wf * torch.ldexp(torch.ones_like(m), -k)[:, None]).to(torch.float8_e4m3fn)
+    deq = (q.float() * scale[:, None]).to(w.dtype)
+    return q.view(torch.uint8).contiguous(), scale.contiguous(), deq.contiguous()
+
+
+def gemv_w8(x, w8, wscale, norm_w=None, eps=0.0, residual=None, swiglu=False, out=None, out_f32=False):
+    """decode product with fp8 weights: x [B,K] bf16, w8 uint8 [N(,2N if swiglu),K], wscale fp32 [rows] -> [B,N]."""
+    _dev(x, w8, wscale, norm_w, residual)
+    if x.dtype != torch.bfloat16 or w8.dtype != torch.uint8 or wscale.dtype != torch.float32:
+        raise ValueError("gemv_w8: x must be bf16, w8 uint8, wscale fp32")
+    B, K = x.shape
+    N = w8.shape[0] // 2 if swiglu else w8.shape[0]
+    if out is None:
+        out = torch.empty((B, N), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    L.check(L.load().srgpt_gemv_w8(_p(_c(x)), _p(w8), _p(wscale), _p(norm_w), float(eps), _p(residual), _p(out), B, N, K,
+                                   int(swiglu), int(out_f32), _stream()))
+    return out
+
+
 def layernorm(x, w, b, eps, act=L.ACT_NONE, out=None):
     _dev(x, w, b)
     x = _c(x)

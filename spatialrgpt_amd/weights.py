@@ -47,8 +47,16 @@ class PreparedWeights:
     """Owns the device tensors and the C structs pointing at them."""
 
     def __init__(self, cfg: SrgptConfig, sd: Dict[str, torch.Tensor], device, dtype, rope_positions: int = 0,
-                 consume: bool = False):
+                 consume: bool = False, llm_weight_format: str = "native"):
+        """llm_weight_format: "native" (the engine dtype) or "fp8" -- weight-only OCP e4m3fn quantisation of the five
+        streamed LLM matrices with one fp32 scale per output row (BASELINE config 5; bf16 engines only): the decode step
+        streams the fp8 bytes, prefill uses the dequantised bf16 values of the SAME quantised weights."""
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        if llm_weight_format not in ("native", "fp8"):
+            raise ValueError(f"unknown llm_weight_format {llm_weight_format!r}")
+        if llm_weight_format == "fp8" and dtype != torch.bfloat16:
+            raise ValueError("fp8 LLM weights need a bf16 engine")
+        self.llm_weight_format = llm_weight_format
         self._keep: List[object] = []
         code = {torch.float32: L.F32, torch.bfloat16: L.BF16}[dtype]
 
@@ -138,6 +146,19 @@ class PreparedWeights:
             lt["wgu"].append(torch.cat([get(q + "mlp.gate_proj.weight"), get(q + "mlp.up_proj.weight")], 0).contiguous())
             lt["wdown"].append(get(q + "mlp.down_proj.weight"))
         self.llm_t = lt
+        self.llm_q = None
+        if llm_weight_format == "fp8":
+            from . import ops  # local import: ops needs the loaded library
+
+            qd = {k: ([], []) for k in ("wqkv", "wo", "wgu", "wdown")}
+            for k in qd:
+                for i in range(cfg.layers):
+                    q8, sc, deq = ops.quantize_fp8_rows(lt[k][i])
+                    lt[k][i] = deq
+                    qd[k][0].append(q8)
+                    qd[k][1].append(sc)
+            self.lm_head8, self.lm_head_scale, self.lm_head = ops.quantize_fp8_rows(self.lm_head)
+            self.llm_q = qd
         n_pos = rope_positions or cfg.max_position_embeddings
         self.rope_len = n_pos
         self.rope_cos, self.rope_sin = rope_tables(cfg, n_pos, dtype, self.device)
@@ -150,15 +171,29 @@ class PreparedWeights:
             arr = _ptr_array(ts)
             self._keep.append(arr)
             setattr(lw, k, arr)
+        if self.llm_q is not None:
+            lw.lm_head8, lw.lm_head_scale = self.lm_head8.data_ptr(), self.lm_head_scale.data_ptr()
+            for k, (qs, scs) in self.llm_q.items():
+                a8, asc = _ptr_array(qs), _ptr_array(scs)
+                self._keep += [a8, asc]
+                setattr(lw, k + "8", a8)
+                setattr(lw, k + "_scale", asc)
         self.llm = lw
         self.vocab = self.embed.shape[0]
 
     def llm_weight_bytes(self) -> int:
         """bytes streamed from HBM per decoded token at batch 1 (everything but embed_tokens)."""
-        n = self.final_norm.numel() + self.lm_head.numel()
-        for ts in self.llm_t.values():
-            n += sum(t.numel() for t in ts)
-        return n * self.embed.element_size()
+        es = self.embed.element_size()
+        if self.llm_q is None:
+            n = self.final_norm.numel() + self.lm_head.numel()
+            for ts in self.llm_t.values():
+                n += sum(t.numel() for t in ts)
+            return n * es
+        n = (self.final_norm.numel() + sum(t.numel() for k in ("attn_norm", "mlp_norm") for t in self.llm_t[k])) * es
+        n += self.lm_head8.numel() + 4 * self.lm_head_scale.numel()
+        for qs, scs in self.llm_q.values():
+            n += sum(t.numel() for t in qs) + 4 * sum(t.numel() for t in scs)
+        return n
 
 
 def weight_shapes(cfg: SrgptConfig) -> Dict[str, tuple]:

@@ -116,6 +116,64 @@ def test_gemv_swiglu(dtype, B, N, K):
     assert_close(ops.gemv(x.to(DEV), w.to(DEV), swiglu=True), ref, _tol(ref, dtype), 0, "swiglu gemv")
 
 
+def test_fp8_decode_matches_torch_float8():
+    """the hardware fp8 -> fp32 conversion (v_cvt_pk_f32_fp8 on gfx950) is OCP e4m3fn: all 256 codes through the W8 kernel
+    equal torch.float8_e4m3fn's decode (NaN codes 0x7f / 0xff excluded)."""
+    ops, L = _ops()
+    codes = torch.arange(256, dtype=torch.uint8)
+    codes = codes[(codes & 0x7F) != 0x7F]
+    n = codes.numel()
+    # W8 row r holds code r at k = 0 and zeros elsewhere; x = e_0 -> out[r] = decode(code r)
+    w8 = torch.zeros((n, 64), dtype=torch.uint8)
+    w8[:, 0] = codes
+    x = torch.zeros((1, 64), dtype=torch.bfloat16)
+    x[0, 0] = 1.0
+    out = ops.gemv_w8(x.to(DEV), w8.to(DEV), torch.ones(n, dtype=torch.float32, device=DEV), out_f32=True)
+    ref = codes.view(torch.float8_e4m3fn).float()
+    assert torch.equal(out[0].cpu(), ref)
+
+
+@pytest.mark.parametrize("B,N,K", [(1, 1000, 4096), (2, 4096, 4096), (4, 1001, 2560), (8, 512, 11008), (16, 333, 1024),
+                                   (20, 130, 264), (1, 33000, 256)])
+def test_gemv_w8_variants(B, N, K):
+    """W8A16 decode product vs fp32 torch on the dequantised weights (tolerance: bf16 output rounding)."""
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    x, w = _rand((B, K), dtype, 21), _rand((N, K), dtype, 22, 0.03)
+    g, r = (1 + 0.1 * _rand((K,), torch.float32, 23)).to(dtype), _rand((B, N), dtype, 24)
+    q8, sc, deq = ops.quantize_fp8_rows(w.to(DEV))
+    assert q8.dtype == torch.uint8 and sc.dtype == torch.float32 and deq.dtype == dtype
+    # the quantiser itself: per-row scale = max|w|/448, codes = round-to-nearest e4m3fn, error <= 2^-4 of the row max
+    assert float(((deq.float().cpu() - w.float()).abs() / w.float().abs().amax(1, keepdim=True)).max()) <= 2 ** -4
+    wq = (q8.cpu().view(torch.float8_e4m3fn).float() * sc.cpu()[:, None])
+    ref = x.float() @ wq.T
+    xd = x.to(DEV)
+    assert_close(ops.gemv_w8(xd, q8, sc), ref, _tol(ref, dtype), 0, "gemv_w8")
+    assert_close(ops.gemv_w8(xd, q8, sc, residual=r.to(DEV)), ref.to(dtype).float() + r.float(), _tol(ref, dtype, 2), 0, "gemv_w8+res")
+    lo = ops.gemv_w8(xd, q8, sc, out_f32=True)
+    assert lo.dtype == torch.float32
+    assert_close(lo, ref, _tol(ref, dtype), 0, "gemv_w8 f32")
+    xf = x.float()
+    xn = g * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(dtype)
+    refn = xn.float() @ wq.T
+    assert_close(ops.gemv_w8(xd, q8, sc, norm_w=g.to(DEV), eps=1e-5), refn, _tol(refn, dtype), 0, "rmsnorm+gemv_w8")
+    # consistency with the bf16 path on the dequantised weights (what prefill multiplies)
+    assert_close(ops.gemv_w8(xd, q8, sc), ops.gemv(xd, deq).float().cpu(), _tol(ref, dtype, 2), 0, "w8 vs bf16(deq)")
+
+
+@pytest.mark.parametrize("B,N,K", [(1, 1024, 4096), (8, 333, 512), (16, 100, 264)])
+def test_gemv_w8_swiglu(B, N, K):
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    x, w = _rand((B, K), dtype, 25), _rand((2 * N, K), dtype, 26, 0.03)
+    q8, sc, deq = ops.quantize_fp8_rows(w.to(DEV))
+    wq = (q8.cpu().view(torch.float8_e4m3fn).float() * sc.cpu()[:, None])
+    gate = (x.float() @ wq[:N].T).to(dtype)
+    up = (x.float() @ wq[N:].T).to(dtype)
+    ref = (F.silu(gate.float()).to(dtype).float() * up.float())
+    assert_close(ops.gemv_w8(x.to(DEV), q8, sc, swiglu=True), ref, _tol(ref, dtype), 0, "swiglu gemv_w8")
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("rows,cols", [(7, 1152), (3, 4608), (5, 64), (2, 72)])

@@ -71,6 +71,13 @@ def test_load_pretrained_model_roundtrip(tmp_path):
     err = (st["inputs_embeds"].float().cpu() - ref["inputs_embeds"].float()).abs().max().item()
     assert err <= 3e-2 * ref["inputs_embeds"].float().abs().max().item()
     with pytest.raises(NotImplementedError):
-        load_pretrained_model(root, "x", load_8bit=True)
+        load_pretrained_model(root, "x", load_4bit=True)
+    # load_8bit -> weight-only fp8 for the streamed LLM matrices (the reference's bitsandbytes int8 slot, builder.py:51-52)
+    _, m8, _, _ = load_pretrained_model(root, "SpatialRGPT-tiny", load_8bit=True)
+    assert m8.engine.w.llm_weight_format == "fp8" and m8.engine.w.llm_q is not None
+    m8.config.mask_token_id, m8.config.depth_token_id = cfgd["mask_token_id"], cfgd["depth_token_id"]
+    out8 = m8.generate(inp["input_ids"].cuda(), images=inp["images"].cuda(), depths=inp["depths"].cuda(),
+                       masks=[m.cuda() for m in inp["masks"]], do_sample=False, max_new_tokens=4, eos_token_id=None)
+    assert out8.shape == (1, 4)
     with pytest.raises(NotImplementedError):
         model.to(dtype=torch.float16)

@@ -201,3 +201,49 @@ def test_mask_token_count_mismatch_behaviour():
     ids_more[0, 1] = m  # one more than masks
     with pytest.raises(RuntimeError):
         model.engine.prepare_inputs(ids_more, d["images"], d["depths"], d["masks"], None)
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_fp8_weight_decode_vs_oracle_on_dequantised_weights(batch):
+    """config 5 (weight-only fp8): the engine quantises the five streamed LLM matrices per output row; decode logits
+    (W8A16 kernel) == prefill logits (bf16 kernels on the dequantised values) == the oracle run on dequant(quant(W))."""
+    from oracle import srgpt_oracle as so
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.engine import SrgptEngine
+    import ctypes as C
+    from spatialrgpt_amd import _lib as L, ops
+
+    dtype = torch.bfloat16
+    kw = dict(vit_hidden=64, vit_inter=128, vit_layers=2, vit_heads=4, image_size=56, patch_size=14, hidden=512, inter=1408,
+              layers=3, heads=8, kv_heads=2, vocab=1000, mask_token_id=998, depth_token_id=999, rope_theta=10000.0)
+    ocfg = so.SrgptConfig(**kw)
+    w = so.synth_weights(ocfg, seed=3, dtype=dtype)
+    wq = so.fp8_dequantised_weights(w)
+    eng = SrgptEngine(SrgptConfig(**kw), dict(w), device=DEV, dtype=dtype, rope_positions=512, llm_weight_format="fp8")
+    # the engine's dequantised matrices are bit-identical to the oracle's
+    assert torch.equal(eng.w.lm_head.cpu(), wq["llm.lm_head.weight"])
+    assert torch.equal(eng.w.llm_t["wdown"][1].cpu(), wq["llm.model.layers.1.mlp.down_proj.weight"])
+    assert eng.w.llm_weight_bytes() < 0.55 * sum(t.numel() * 2 for k, t in w.items() if k.startswith("llm.") and "embed" not in k)
+    g = torch.Generator().manual_seed(5)
+    T, G = 37, 5
+    x = (torch.randn((batch, T, 512), generator=g) * 0.5).to(dtype)
+    st, _, _ = eng.prefill(x.to(DEV), max_new=G + 1)
+    lib = L.load()
+    L.check(lib.srgpt_llm_sample_first(C.byref(eng.w.llm), C.byref(st.c), ops._stream()))
+    dec_logits = [st.logits.clone()]
+    for _ in range(G):
+        L.check(lib.srgpt_llm_decode_step(C.byref(eng.w.llm), C.byref(st.c), ops._stream()))
+        dec_logits.append(st.logits.clone())
+    ids = st.out_ids[:, :G + 1].clone()
+    emb = eng.embed_tokens(ids[:, :G])
+    full = torch.cat([x.to(DEV), emb], dim=1)
+    eng._state = None
+    _, all_logits, _ = eng.prefill(full, max_new=1, all_logits=True)
+    tol = 3e-2 * float(all_logits.abs().max())
+    for s in range(G + 1):
+        assert_close(dec_logits[s], all_logits[:, T - 1 + s], tol, 0, f"fp8 decode step {s} vs prefill on dequantised weights")
+    kv = so.KVCache(ocfg.layers)
+    ref = so.llama_forward(wq, ocfg, full.cpu(), torch.arange(T + G)[None].expand(batch, -1), kv)
+    assert_close(all_logits, ref, tol, 0, "prefill logits vs oracle (dequantised weights)")
+    for s in range(G + 1):
+        assert_close(dec_logits[s], ref[:, T - 1 + s], tol, 0, f"fp8 decode step {s} vs oracle")
