@@ -18,9 +18,14 @@
 // (4 VGPRs each).  The 4 waves of a block split K in interleaved 256-wide slices, so every block uses all its waves
 // even when N/16 is only one tile per CU (o_proj / down_proj); their partial sums are added in a fixed order through
 // LDS at the end of the pass (deterministic).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
+
+int srgpt_gemv_w8_valu(const void* x, const void* W8, const float* wscale, const void* norm_w, float eps,
+                       const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32, hipStream_t s);  // gemv_w8.hip
 
 namespace {
 
@@ -341,6 +346,9 @@ extern "C" int srgpt_gemv_w8(const void* x, const void* W8, const float* wscale,
   SRGPT_CHECK(K % 8 == 0, SRGPT_ERR_ARG, "srgpt_gemv_w8: K=%d must be a multiple of 8", K);
   SRGPT_CHECK(!(swiglu && (residual || out_f32)), SRGPT_ERR_ARG, "srgpt_gemv_w8: swiglu excludes residual/out_f32");
   hipStream_t s = as_stream(stream);
+  static const int valu_max = getenv("SRGPT_W8_VALU_MAX_BATCH") ? atoi(getenv("SRGPT_W8_VALU_MAX_BATCH")) : 2;  // tuning knob
+  if (batch <= valu_max && batch <= 2 && K % 16 == 0)  // 1-2 rows: VALU kernel (gemv_w8.hip), like the bf16 path
+    return srgpt_gemv_w8_valu(x, W8, wscale, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, s);
   const size_t on = out_f32 ? sizeof(float) : 2;
   for (int b0 = 0; b0 < batch; b0 += 16) {
     const int nb = batch - b0 < 16 ? batch - b0 : 16;
