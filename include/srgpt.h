@@ -212,6 +212,23 @@ int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images, void* out,
                       srgpt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Request preprocessing on the device (host originals: llava/mm_utils.py:421-474 process_image,
+ * :477-532 process_regions, which use PIL, cv2 and the HF image processor).
+ * srgpt_image_resize_normalize: uint8 image [H, W, C] (HWC) -> Pillow-exact bicubic resize (two uint8 passes, 22-bit
+ *   fixed-point coefficients supplied by the host: per output column/row (first tap, tap count) in *bounds and
+ *   *coef [out][k]) -> value * rescale -> (v - mean[c]) / std[c] if do_normalize -> out [C, Hout, Wout] in dtype.
+ *   tmp_u8 = H * Wout * C bytes of scratch.  A dimension that is not resized gets the identity table (1 tap, 1<<22).
+ * srgpt_mask_resize_nearest: uint8 masks [K, H, W] -> out [K, Hout, Wout] in dtype, out[m,y,x] = src[m, ys[y], xs[x]]
+ *   (cv2.INTER_NEAREST index tables from the host).
+ * --------------------------------------------------------------------------------------------- */
+int srgpt_image_resize_normalize(const void* src_u8, int H, int W, int C, const int* hbounds, const int* hcoef, int hk,
+                                 const int* vbounds, const int* vcoef, int vk, int Hout, int Wout, void* tmp_u8,
+                                 void* out, const float* mean, const float* stdv, float rescale, int do_normalize,
+                                 int dtype, srgpt_stream_t stream);
+int srgpt_mask_resize_nearest(const void* src_u8, int K, int H, int W, const int* ys, const int* xs, int Hout, int Wout,
+                              void* out, int dtype, srgpt_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Composite: Llama decoder (LlamaForCausalLM.forward, modeling_llama.py:972-1110 inference branch,
  * LlamaModel.forward :824-936, LlamaDecoderLayer :611-684) with a static KV cache.
  * --------------------------------------------------------------------------------------------- */

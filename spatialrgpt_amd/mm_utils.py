@@ -3,6 +3,8 @@ the reference: prompt tokenisation with the <image> sentinel, image / mask prepr
 from __future__ import annotations
 
 import copy
+import functools
+import math
 from typing import List, Sequence
 
 import numpy as np
@@ -170,3 +172,128 @@ def process_regions(masks: Sequence[np.ndarray], image_processor, data_args):
             m = p
         out.append(mp.preprocess(m[None, ...], return_tensors="pt")["pixel_values"][0])
     return torch.vstack([torch.as_tensor(o) for o in out]).float()
+
+
+# ------------------------------------------------------------------------------------------------
+# Device-side request preprocessing: raw uint8 image / masks in, model-ready tensors on the GPU out.
+# The host computes only the small resampling tables; pixels are touched by the HIP kernels (csrc/preproc.hip).
+# ------------------------------------------------------------------------------------------------
+def _bicubic(x: float, a: float = -0.5) -> float:
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+@functools.lru_cache(maxsize=64)
+def pil_bicubic_tables(in_size: int, out_size: int):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bicubic filter (libImaging/Resample.c), restated in
+    double exactly in Pillow's operation order: -> (bounds int32 [out, 2] = (first tap, taps), coef int32 [out, ksize]).
+    A dimension that is not resized is skipped by Pillow: identity table."""
+    if in_size == out_size:
+        b = np.stack([np.arange(out_size, dtype=np.int32), np.ones(out_size, dtype=np.int32)], 1)
+        return np.ascontiguousarray(b), np.full((out_size, 1), 1 << 22, dtype=np.int32)
+    scale = in_size / out_size
+    fs = scale if scale >= 1.0 else 1.0
+    support = 2.0 * fs
+    ksize = int(math.ceil(support)) * 2 + 1
+    coef = np.zeros((out_size, ksize), np.int32)
+    bounds = np.zeros((out_size, 2), np.int32)
+    ss = 1.0 / fs
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = [0.0] * ksize
+        ww = 0.0
+        for x in range(xmax):
+            w = _bicubic((x + xmin - center + 0.5) * ss)
+            k[x] = w
+            ww += w
+        if ww != 0.0:
+            for x in range(xmax):
+                k[x] /= ww
+        for x in range(ksize):
+            v = k[x]
+            coef[xx, x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
+        bounds[xx] = (xmin, xmax)
+    return bounds, coef
+
+
+@functools.lru_cache(maxsize=64)
+def cv2_nearest_index(in_size: int, out_size: int):
+    """cv2.resize(..., INTER_NEAREST) source index per destination index: min(floor(dst * (1 / (out / in))), in - 1),
+    in double like cv2's resizeNN."""
+    ifx = 1.0 / (out_size / in_size)
+    return np.minimum(np.floor(np.arange(out_size, dtype=np.float64) * ifx).astype(np.int64), in_size - 1).astype(np.int32)
+
+
+def _dev_tables(tables, device):
+    return [torch.from_numpy(np.ascontiguousarray(t)).to(device) for t in tables]
+
+
+def process_images_device(images, image_processor, model_cfg, device="cuda", dtype=torch.bfloat16):
+    """Device counterpart of process_images (mm_utils.py:535-542 / process_image :421-474) for PIL images or uint8 HWC
+    arrays: returns [N, 3, S, S] on the GPU in `dtype`, bit-identical to the host path followed by `.to(dtype)`.
+    Aspect modes "resize" and "pad" (expand2square with the mean colour) and the processor default (plain resize)."""
+    from . import _lib as L, ops
+
+    cs = _crop_size(image_processor)
+    S_h, S_w = cs["height"], cs["width"]
+    mean = torch.tensor(list(image_processor.image_mean), dtype=torch.float32, device=device)
+    std = torch.tensor(list(image_processor.image_std), dtype=torch.float32, device=device)
+    lib = L.load()
+    outs = []
+    for im in images:
+        arr = np.asarray(im.convert("RGB")) if hasattr(im, "convert") else np.asarray(im)
+        if arr.ndim != 3 or arr.shape[2] != 3 or arr.dtype != np.uint8:
+            raise ValueError("process_images_device: expected PIL images or uint8 [H, W, 3] arrays")
+        if getattr(model_cfg, "image_aspect_ratio", None) == "pad" and arr.shape[0] != arr.shape[1]:
+            h, w = arr.shape[:2]
+            side = max(h, w)
+            bg = np.empty((side, side, 3), np.uint8)
+            bg[:] = np.asarray([int(x * 255) for x in image_processor.image_mean], np.uint8)
+            bg[(side - h) // 2:(side - h) // 2 + h, (side - w) // 2:(side - w) // 2 + w] = arr
+            arr = bg
+        H, W = arr.shape[:2]
+        src = torch.from_numpy(np.array(arr, dtype=np.uint8, order="C")).to(device)  # PIL buffers are read-only: copy
+        hb, hc = _dev_tables(pil_bicubic_tables(W, S_w), device)
+        vb, vc = _dev_tables(pil_bicubic_tables(H, S_h), device)
+        tmp = torch.empty((H, S_w, 3), dtype=torch.uint8, device=device)
+        out = torch.empty((3, S_h, S_w), dtype=dtype, device=device)
+        L.check(lib.srgpt_image_resize_normalize(src.data_ptr(), H, W, 3, hb.data_ptr(), hc.data_ptr(), hc.shape[1], vb.data_ptr(),
+                                                 vc.data_ptr(), vc.shape[1], S_h, S_w, tmp.data_ptr(), out.data_ptr(),
+                                                 mean.data_ptr(), std.data_ptr(), float(image_processor.rescale_factor),
+                                                 int(bool(getattr(image_processor, "do_normalize", True))), ops.dt_code(out),
+                                                 ops._stream()))
+        outs.append(out)
+    return torch.stack(outs, 0)
+
+
+def process_regions_device(masks: Sequence[np.ndarray], image_processor, data_args, device="cuda", dtype=torch.bfloat16):
+    """Device counterpart of process_regions (mm_utils.py:477-532) for image_aspect_ratio == "resize" (the SpatialRGPT
+    configuration): uint8 [H, W] masks -> [M, S, S] on the GPU in `dtype` (values are the mask's own 0/1 or 0/255)."""
+    from . import _lib as L, ops
+
+    if getattr(data_args, "image_aspect_ratio", None) != "resize":
+        raise NotImplementedError("process_regions_device handles image_aspect_ratio == 'resize'; use process_regions otherwise")
+    cs = _crop_size(data_args.image_processor if hasattr(data_args, "image_processor") else image_processor)
+    S_h, S_w = cs["height"], cs["width"]
+    ms = [np.asarray(m) for m in masks]
+    if not ms or any(m.ndim != 2 or m.dtype != np.uint8 or m.shape != ms[0].shape for m in ms):
+        raise ValueError("process_regions_device: expected equally sized uint8 [H, W] masks")
+    H, W = ms[0].shape
+    src = torch.from_numpy(np.ascontiguousarray(np.stack(ms, 0))).to(device)
+    ys, xs = _dev_tables((cv2_nearest_index(H, S_h), cv2_nearest_index(W, S_w)), device)
+    out = torch.empty((len(ms), S_h, S_w), dtype=dtype, device=device)
+    L.check(L.load().srgpt_mask_resize_nearest(src.data_ptr(), len(ms), H, W, ys.data_ptr(), xs.data_ptr(), S_h, S_w, out.data_ptr(),
+                                               ops.dt_code(out), ops._stream()))
+    return out

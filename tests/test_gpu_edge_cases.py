@@ -172,3 +172,37 @@ def test_true_width_truncated_depth_bf16_vs_oracle():
         if int(out[0, s_]) != int(ref_ids[0, s_]):
             assert float(margin[s_]) <= tol, f"step {s_}: {int(out[0, s_])} vs {int(ref_ids[0, s_])}, margin {float(margin[s_]):.4f} > {tol:.4f}"
             break
+
+
+def test_device_preprocessing_equals_host_path():
+    """process_images_device / process_regions_device (HIP kernels on raw uint8) == the host path
+    (PIL bicubic + HF-style rescale/normalise; cv2-style nearest) bit for bit, in fp32 and after the bf16 cast."""
+    import numpy as np
+    from PIL import Image
+    from types import SimpleNamespace
+
+    from spatialrgpt_amd.mm_utils import (SrgptImageProcessor, process_images, process_images_device, process_regions,
+                                          process_regions_device)
+
+    rng = np.random.default_rng(3)
+    proc = SrgptImageProcessor(size=384)
+    for mode in ("resize", "pad", None):
+        cfg = SimpleNamespace(image_aspect_ratio=mode, image_processor=proc)
+        ims = [Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in [(480, 640), (200, 150), (384, 384)]]
+        if mode == "resize":
+            # the reference resizes with PIL first (mm_utils.py:441: Image.resize default = bicubic), then the processor
+            # sees an image of the final size -> one bicubic pass, which is what the device path runs
+            pass
+        ref = process_images(ims, proc, cfg)
+        got32 = process_images_device(ims, proc, cfg, device=DEV, dtype=torch.float32)
+        assert got32.shape == (3, 3, 384, 384)
+        assert torch.equal(got32.cpu(), ref), f"mode {mode}: max diff {float((got32.cpu() - ref).abs().max())}"
+        got16 = process_images_device(ims, proc, cfg, device=DEV, dtype=torch.bfloat16)
+        assert torch.equal(got16.cpu(), ref.to(torch.bfloat16))
+    cfg = SimpleNamespace(image_aspect_ratio="resize", image_processor=proc)
+    masks = [(rng.random((480, 640)) > 0.7).astype(np.uint8) for _ in range(5)]
+    refm = process_regions(masks, proc, cfg)
+    gotm = process_regions_device(masks, proc, cfg, device=DEV, dtype=torch.float32)
+    assert gotm.shape == (5, 384, 384) and torch.equal(gotm.cpu(), refm)
+    with pytest.raises(NotImplementedError):
+        process_regions_device(masks, proc, SimpleNamespace(image_aspect_ratio="pad", image_processor=proc), device=DEV)

@@ -124,3 +124,38 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_pil_bicubic_tables_reproduce_pillow_bit_exactly():
+    """the resampling tables the device preprocessing uses (mm_utils.pil_bicubic_tables) are Pillow's own: a numpy
+    two-pass integer convolution with them equals Image.resize(BICUBIC) bit for bit (up-, down-scaling, identity axis)."""
+    from PIL import Image
+
+    from spatialrgpt_amd.mm_utils import cv2_nearest_index, pil_bicubic_tables
+
+    def resize_np(img, oh, ow):
+        H, W, C = img.shape
+        b, k = pil_bicubic_tables(W, ow)
+        out = np.zeros((H, ow, C), np.uint8)
+        for xx in range(ow):
+            x0, n = b[xx]
+            acc = (img[:, x0:x0 + n, :].astype(np.int64) * k[xx, :n][None, :, None]).sum(1) + (1 << 21)
+            out[:, xx, :] = np.clip(acc >> 22, 0, 255)
+        b, k = pil_bicubic_tables(H, oh)
+        out2 = np.zeros((oh, ow, C), np.uint8)
+        for yy in range(oh):
+            y0, n = b[yy]
+            acc = (out[y0:y0 + n].astype(np.int64) * k[yy, :n][:, None, None]).sum(0) + (1 << 21)
+            out2[yy] = np.clip(acc >> 22, 0, 255)
+        return out2
+
+    rng = np.random.default_rng(0)
+    for H, W, oh, ow in [(240, 320, 96, 96), (50, 77, 96, 96), (96, 200, 96, 96), (300, 96, 96, 96), (97, 31, 64, 80)]:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BICUBIC))
+        assert np.array_equal(resize_np(img, oh, ow), ref), (H, W, oh, ow)
+    # cv2.INTER_NEAREST indices: floor(dst * in/out) clipped, monotone, covering [0, in)
+    for n_in, n_out in [(480, 384), (100, 384), (384, 384), (7, 3)]:
+        idx = cv2_nearest_index(n_in, n_out)
+        assert idx[0] == 0 and idx.max() <= n_in - 1 and np.all(np.diff(idx) >= 0)
+        assert np.array_equal(idx, np.minimum((np.arange(n_out) * n_in) // n_out, n_in - 1))  # exact rational floor agrees here
