@@ -282,6 +282,12 @@ int64_t srgpt_llm_ws_bytes(const srgpt_llm_weights* w, int batch, int max_tokens
  * (layers+1) pre-norm hidden states [layers+1, B, T, hidden] (parity hook). */
 int srgpt_llm_prefill(const srgpt_llm_weights* w, srgpt_llm_state* st, const void* inputs_embeds, int T,
                       float* all_logits, void* hidden_out, srgpt_stream_t stream);
+/* Ragged batch (prompts of different lengths in one call -- the reference right-pads and hands flash-attn the unpadded
+ * rows, llava_arch.py:549-611 + modeling_llama.py:540-608): inputs_embeds [batch, T, hidden] RIGHT-padded, lens[b] =
+ * valid rows of sequence b (device int32).  Causal attention never looks right, so valid rows are exact whatever the
+ * padding holds; logits come from row lens[b]-1 and decoding continues at position lens[b] per sequence. */
+int srgpt_llm_prefill_ragged(const srgpt_llm_weights* w, srgpt_llm_state* st, const void* inputs_embeds, int T,
+                             const int* lens, float* all_logits, void* hidden_out, srgpt_stream_t stream);
 /* One greedy decode step, entirely device-side: embeds st->tok, runs the layers against the cache,
  * argmax -> st->tok, st->out_ids[:, *step], ++pos, ++*step.  No host sync. */
 int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream);

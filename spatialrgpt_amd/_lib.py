@@ -87,6 +87,7 @@ _SIGNATURES = {
     "srgpt_vit_forward": (i32, [C.POINTER(VitWeights), vp, vp, vp, i32, vp]),
     "srgpt_llm_ws_bytes": (i64, [C.POINTER(LlmWeights), i32, i32]),
     "srgpt_llm_prefill": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp, i32, vp, vp, vp]),
+    "srgpt_llm_prefill_ragged": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp, i32, vp, vp, vp, vp]),
     "srgpt_llm_decode_step": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp]),
     "srgpt_llm_sample_first": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp]),
     "srgpt_llm_decode_graph_create": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp, C.POINTER(vp)]),

@@ -246,8 +246,21 @@ static int check_llm(const srgpt_llm_weights* w, const srgpt_llm_state* st) {
   return SRGPT_OK;
 }
 
-extern "C" int srgpt_llm_prefill(const srgpt_llm_weights* w, srgpt_llm_state* st, const void* inputs_embeds, int T,
-                                 float* all_logits, void* hidden_out, srgpt_stream_t stream) {
+// out[b, :] = x[b, lens[b] - 1, :] (16-byte chunks) and pos[b] = lens[b]
+template <typename T>
+__global__ void gather_last_rows_kernel(const T* __restrict__ x, const int* __restrict__ lens, T* __restrict__ out,
+                                        int* __restrict__ pos, int Tlen, int Hd) {
+  const int b = blockIdx.x;
+  const int len = min(max(lens[b], 1), Tlen);
+  constexpr int VEC = Vec16<T>::N;
+  const Vec16<T>* src = reinterpret_cast<const Vec16<T>*>(x + ((size_t)b * Tlen + (len - 1)) * Hd);
+  Vec16<T>* dst = reinterpret_cast<Vec16<T>*>(out + (size_t)b * Hd);
+  for (int c = threadIdx.x; c < Hd / VEC; c += blockDim.x) dst[c] = src[c];
+  if (threadIdx.x == 0) pos[b] = len;
+}
+
+static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const void* inputs_embeds, int T, const int* lens,
+                        float* all_logits, void* hidden_out, srgpt_stream_t stream) {
   SRGPT_TRY(check_llm(w, st));
   SRGPT_CHECK(inputs_embeds && T > 0 && T <= st->max_pos, SRGPT_ERR_ARG, "srgpt_llm_prefill: T=%d exceeds max_pos=%d", T,
               st->max_pos);
@@ -294,16 +307,38 @@ extern "C" int srgpt_llm_prefill(const srgpt_llm_weights* w, srgpt_llm_state* st
                          0, 0, 1, SRGPT_OUT_PLAIN, 0, nullptr, 0, dt, stream));
   }
   // last position of every sequence -> logits (final norm fused into the GEMV prologue)
-  if (hipMemcpy2DAsync(l.last, (size_t)Hd * es, reinterpret_cast<char*>(l.x) + (size_t)(T - 1) * Hd * es,
-                       (size_t)T * Hd * es, (size_t)Hd * es, B, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-    srgpt_set_error("srgpt_llm_prefill: gather of last rows failed");
-    return SRGPT_ERR_LAUNCH;
+  if (lens) {  // right-padded ragged batch: row b ends at lens[b] - 1 and decoding continues from position lens[b]
+    SRGPT_CHECK(Hd % (16 / (int)es) == 0, SRGPT_ERR_ARG, "srgpt_llm_prefill_ragged: hidden %d not a multiple of 16 bytes", Hd);
+    if (dt == SRGPT_BF16)
+      hipLaunchKernelGGL(gather_last_rows_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)l.x, lens, (bf16_t*)l.last,
+                         st->pos, T, Hd);
+    else
+      hipLaunchKernelGGL(gather_last_rows_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)l.x, lens, (float*)l.last,
+                         st->pos, T, Hd);
+    SRGPT_LAUNCH_CHECK();
+  } else {
+    if (hipMemcpy2DAsync(l.last, (size_t)Hd * es, reinterpret_cast<char*>(l.x) + (size_t)(T - 1) * Hd * es,
+                         (size_t)T * Hd * es, (size_t)Hd * es, B, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+      srgpt_set_error("srgpt_llm_prefill: gather of last rows failed");
+      return SRGPT_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(set_int_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, st->pos, B, T);
+    SRGPT_LAUNCH_CHECK();
   }
   SRGPT_TRY(srgpt_gemv(l.last, w->lm_head, w->final_norm, w->rms_eps, nullptr, st->logits, B, w->vocab, Hd, 0, 1, dt,
                        stream));
-  hipLaunchKernelGGL(set_int_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, st->pos, B, T);
-  SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
+}
+
+extern "C" int srgpt_llm_prefill(const srgpt_llm_weights* w, srgpt_llm_state* st, const void* inputs_embeds, int T,
+                                 float* all_logits, void* hidden_out, srgpt_stream_t stream) {
+  return prefill_impl(w, st, inputs_embeds, T, nullptr, all_logits, hidden_out, stream);
+}
+
+extern "C" int srgpt_llm_prefill_ragged(const srgpt_llm_weights* w, srgpt_llm_state* st, const void* inputs_embeds, int T,
+                                        const int* lens, float* all_logits, void* hidden_out, srgpt_stream_t stream) {
+  SRGPT_CHECK(lens, SRGPT_ERR_ARG, "srgpt_llm_prefill_ragged: lens is null");
+  return prefill_impl(w, st, inputs_embeds, T, lens, all_logits, hidden_out, stream);
 }
 
 extern "C" int srgpt_llm_sample_first(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream) {

@@ -327,16 +327,26 @@ class SrgptEngine:
             self._state = s
         return s
 
-    def prefill(self, inputs_embeds: torch.Tensor, max_new: int = 1, all_logits: bool = False, hidden_states: bool = False):
-        """inputs_embeds [B,T,H] (equal-length rows).  Returns (state, logits_all|None, hiddens|None)."""
+    def prefill(self, inputs_embeds: torch.Tensor, max_new: int = 1, all_logits: bool = False, hidden_states: bool = False,
+                lens: Optional[torch.Tensor] = None):
+        """inputs_embeds [B,T,H]; `lens` (int [B]) marks a RIGHT-padded ragged batch: row b has lens[b] valid positions,
+        its logits come from position lens[b]-1 and decoding continues there.  Returns (state, logits_all|None, hiddens|None)."""
         B, T, H = inputs_embeds.shape
         x = inputs_embeds.to(device=self.device, dtype=self.dtype).contiguous()
         st = self._get_state(B, T, max_new)
         al = torch.empty((B, T, self.w.vocab), device=self.device, dtype=torch.float32) if all_logits else None
         hs = torch.empty((self.cfg.layers + 1, B, T, H), device=self.device, dtype=self.dtype) if hidden_states else None
-        L.check(L.load().srgpt_llm_prefill(C.byref(self.w.llm), C.byref(st.c), x.data_ptr(), T,
-                                           None if al is None else al.data_ptr(), None if hs is None else hs.data_ptr(),
-                                           ops._stream()))
+        if lens is None:
+            L.check(L.load().srgpt_llm_prefill(C.byref(self.w.llm), C.byref(st.c), x.data_ptr(), T,
+                                               None if al is None else al.data_ptr(), None if hs is None else hs.data_ptr(),
+                                               ops._stream()))
+        else:
+            ld = lens.to(device=self.device, dtype=torch.int32).contiguous()
+            if ld.shape != (B,):
+                raise ValueError(f"prefill: lens must have shape ({B},)")
+            L.check(L.load().srgpt_llm_prefill_ragged(C.byref(self.w.llm), C.byref(st.c), x.data_ptr(), T, ld.data_ptr(),
+                                                      None if al is None else al.data_ptr(),
+                                                      None if hs is None else hs.data_ptr(), ops._stream()))
         return st, al, hs
 
     def greedy_decode(self, st: DecodeState, max_new_tokens: int, eos_token_id=None, pad_token_id=None,

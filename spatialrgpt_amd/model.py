@@ -257,21 +257,23 @@ class LlavaLlamaModel:
         if pad_token_id is None:
             pad_token_id = self.config.pad_token_id
         B, T, _ = inputs_embeds.shape
+        lens = None
         if attention_mask is not None and not bool(attention_mask.bool().all()):
-            # ragged batch: the reference right-pads and relies on varlen flash-attn; here rows run one by one
-            outs = []
+            # ragged batch (llava_arch.py:549-611 pads to the longest row, right or left): pack every row's valid positions
+            # to the front (right padding) and hand the lengths to the ragged prefill; decode is batched with one position
+            # per sequence, exactly like the reference's padded generate()
+            keep = attention_mask.bool()
+            lens = keep.sum(dim=1)
+            if int(lens.min()) <= 0:
+                raise ValueError("generate: a row of the batch has no valid position")
+            packed = torch.zeros_like(inputs_embeds)
             for b in range(B):
-                keep = attention_mask[b].bool()
-                outs.append(self._generate_from_embeds(inputs_embeds[b:b + 1][:, keep], None, do_sample, temperature,
-                                                       top_p, top_k, num_beams, max_new_tokens, None, min_new_tokens,
-                                                       use_cache, stopping_criteria, pad_token_id, eos_token_id))
-            G = max(o.shape[1] for o in outs)
-            pad = pad_token_id if pad_token_id is not None else (eos_token_id if isinstance(eos_token_id, int) else 0)
-            res = torch.full((B, G), pad, dtype=torch.int64, device=self.device)
-            for b, o in enumerate(outs):
-                res[b, :o.shape[1]] = o[0]
-            return res
-        st, _, _ = self.engine.prefill(inputs_embeds, max_new=max_new_tokens)
+                packed[b, :int(lens[b])] = inputs_embeds[b][keep[b]]
+            Tmax = int(lens.max())
+            inputs_embeds = packed[:, :Tmax].contiguous()
+            if int(lens.min()) == Tmax:
+                lens = None
+        st, _, _ = self.engine.prefill(inputs_embeds, max_new=max_new_tokens, lens=lens)
         if do_sample and temperature is not None and temperature > 0:
             return self._sample_loop(st, max_new_tokens, temperature, top_p, top_k, eos_token_id, pad_token_id,
                                      stopping_criteria)
