@@ -5,6 +5,8 @@
 //       ds_read_b128), fused epilogue (bias / activation / residual / deconv pixel-shuffle / fp32 out).
 //       Both operands are K-contiguous (nn.Linear weight layout), so A and W tiles stage identically.
 // fp32: plain LDS-tiled FMA kernel; exists for tight-tolerance parity runs of the same host path.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -174,6 +176,121 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel, direct-to-LDS staging (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass, single LDS
+// buffer (BM+BN) x 128 B -> 3 blocks per CU at 128x128, whose independent K loops overlap each other's barriers.
+// A wave-instruction moves 8 rows x 128 B into 1 KiB of LDS at (wave-uniform base + lane * 16); the XOR slot swizzle of
+// the register-staged kernel is kept by permuting WHICH 16-byte chunk of its row a lane fetches (chunk = slot ^ (row & 7)),
+// so the fragment reads below are the same conflict-free ds_read_b128.  Rows past M / N re-read the last valid row
+// (their outputs are never stored); a ragged last K tile (K % 64 != 0) is staged through registers with zero fill.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 3) void gemm_bf16_glds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                         int K, int lda, Epilogue e) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[(BM + BN) * BK];
+  bf16_t* As = lds;
+  bf16_t* Ws = lds + BM * BK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int lr = lane >> 3, lc = (lane & 7) ^ lr;  // row within the 8-row group, logical chunk this lane fetches
+
+  const int nk_all = (K + BK - 1) / BK;
+  const int kt0 = e.splits > 1 ? (int)blockIdx.z * e.tiles_per_split : 0;
+  const int nk = e.splits > 1 ? min(nk_all, kt0 + e.tiles_per_split) : nk_all;
+
+  // per-lane row base pointers (clamped rows), one per 8-row group this wave stages
+  constexpr int GA = BM / 32, GW = BN / 32;  // groups per wave (4 waves x 8 rows)
+  const bf16_t* pa[GA];
+  const bf16_t* pw[GW];
+#pragma unroll
+  for (int i = 0; i < GA; ++i) pa[i] = A + (size_t)min(m0 + (wave + 4 * i) * 8 + lr, e.M - 1) * lda + lc * 8;
+#pragma unroll
+  for (int i = 0; i < GW; ++i) pw[i] = W + (size_t)min(n0 + (wave + 4 * i) * 8 + lr, e.N - 1) * K + lc * 8;
+
+  auto stage = [&](int kt) {
+    const int k0 = kt * BK;
+    if (k0 + BK <= K) {
+#pragma unroll
+      for (int i = 0; i < GA; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(As + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < GW; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw[i] + k0),
+                                         (__attribute__((address_space(3))) void*)(Ws + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+    } else {  // ragged last tile: zero-filled through registers, same swizzled slots
+      const bool ok = k0 + lc * 8 < K;
+#pragma unroll
+      for (int i = 0; i < GA; ++i) {
+        const u32x4 v = ok ? *reinterpret_cast<const u32x4*>(pa[i] + k0) : u32x4{0, 0, 0, 0};
+        *reinterpret_cast<u32x4*>(As + ((wave + 4 * i) * 8 + lr) * BK + ((lane & 7) << 3)) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < GW; ++i) {
+        const u32x4 v = ok ? *reinterpret_cast<const u32x4*>(pw[i] + k0) : u32x4{0, 0, 0, 0};
+        *reinterpret_cast<u32x4*>(Ws + ((wave + 4 * i) * 8 + lr) * BK + ((lane & 7) << 3)) = v;
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = zero16;
+
+  for (int kt = kt0; kt < nk; ++kt) {
+    stage(kt);
+    __syncthreads();  // carries the vmcnt(0) that lands the LDS-DMA
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 fa[TM], fw[TN];
+      const int slot = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = wm * (BM / 2) + i * 32 + (lane & 31);
+        fa[i] = *reinterpret_cast<const bf16x8*>(As + r * BK + ((slot ^ (r & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int r = wn * (BN / 2) + j * 32 + (lane & 31);
+        fw[j] = *reinterpret_cast<const bf16x8*>(Ws + r * BK + ((slot ^ (r & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done reading before the next tile overwrites the buffer
+  }
+
+  // D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma clang loop unroll(full)
+  for (int i = 0; i < TM; ++i)
+#pragma clang loop unroll(full)
+    for (int j = 0; j < TN; ++j) {
+      const f32x16 a = acc[i][j];
+      const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+      if (e.splits > 1) {
+        float* slab = e.partial + (size_t)blockIdx.z * e.M * e.N;
+#pragma clang loop unroll(full)
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < e.M && n < e.N) slab[(size_t)m * e.N + n] = a[r];
+        }
+      } else {
+#pragma clang loop unroll(full)
+        for (int r = 0; r < 16; ++r) epilogue_store<bf16_t>(e, mb + (r & 3) + 8 * (r >> 2), n, a[r]);
+      }
+    }
+}
+
 // split-K second pass: fixed-order sum of the fp32 slabs, then the fused epilogue
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(Epilogue e) {
@@ -268,7 +385,9 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
   int bm = 128, splits = 1;
   long tiles = t128;
   const bool pad_waste = (long)cdiv(M, 128) * 128 * 10 > (long)cdiv(M, 64) * 64 * 11;  // > 10 % fewer padded rows with BM = 64
-  if (t128 < 384 || pad_waste) {
+  // 128x128 only when it alone fills the chip at 4 blocks per CU; below that 64x128 has twice the blocks to overlap
+  // (measured with the direct-to-LDS kernel: M=1458 N=4304 K=1152: 32.5 us vs 46.1 us; equal at 4096^3)
+  if (t128 < 1024 || pad_waste) {
     bm = 64;
     tiles = t64x128;
     if (tiles < 384 && ws) {
@@ -279,18 +398,36 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
       if (splits < 1) splits = 1;
     }
   }
+  {  // tuning knobs (scripts/ubench_gemm.py sweeps them); unset in production
+    static const int f_bm = getenv("SRGPT_GEMM_FORCE_BM") ? atoi(getenv("SRGPT_GEMM_FORCE_BM")) : 0;
+    static const int f_sp = getenv("SRGPT_GEMM_FORCE_SPLITS") ? atoi(getenv("SRGPT_GEMM_FORCE_SPLITS")) : 0;
+    if (f_bm == 64 || f_bm == 128) bm = f_bm;
+    if (f_sp > 0 && ws) {
+      splits = f_sp;
+      if (splits > nk) splits = nk;
+      while (splits > 1 && (int64_t)splits * M * N * 4 > ws_bytes) --splits;
+    }
+    if (bm == 128) splits = 1;
+  }
   if (splits > 1) {
     e.partial = reinterpret_cast<float*>(ws);
     e.tiles_per_split = cdiv(nk, splits);
     splits = cdiv(nk, e.tiles_per_split);  // no empty split
     e.splits = splits;
   }
+  static const int use_glds = getenv("SRGPT_GEMM_GLDS") ? atoi(getenv("SRGPT_GEMM_GLDS")) : 1;  // A/B knob
   if (bm == 128) {
     dim3 grid(cdiv(N, 128), cdiv(M, 128), 1);
-    hipLaunchKernelGGL((gemm_bf16_mfma<128, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+    if (use_glds)
+      hipLaunchKernelGGL((gemm_bf16_glds<128, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+    else
+      hipLaunchKernelGGL((gemm_bf16_mfma<128, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
   } else {
     dim3 grid(cdiv(N, 128), cdiv(M, 64), e.splits);
-    hipLaunchKernelGGL((gemm_bf16_mfma<64, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+    if (use_glds)
+      hipLaunchKernelGGL((gemm_bf16_glds<64, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+    else
+      hipLaunchKernelGGL((gemm_bf16_mfma<64, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
   }
   SRGPT_LAUNCH_CHECK();
   if (e.splits > 1) {
