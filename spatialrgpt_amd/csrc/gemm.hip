@@ -184,13 +184,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__
 // so the fragment reads below are the same conflict-free ds_read_b128.  Rows past M / N re-read the last valid row
 // (their outputs are never stored); a ragged last K tile (K % 64 != 0) is staged through registers with zero fill.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 3) void gemm_bf16_glds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
-                                                         int K, int lda, Epilogue e) {
+// NBUF = 1: single buffer, two barriers per K tile, overlap comes from the other blocks of the CU (large grids).
+// NBUF = 2: the next tile's LDS-DMA is issued before the current tile is multiplied, one barrier per K tile -- for grids that
+//           leave a CU with only 1-2 blocks (the M = 259 prefill and ViT shapes), where each K step would otherwise pay a
+//           full memory latency.
+template <int BM, int BN, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_bf16_glds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                         int K, int lda, Epilogue e) {
   constexpr int TM = BM / 64, TN = BN / 64;
-  __shared__ __attribute__((aligned(1024))) bf16_t lds[(BM + BN) * BK];
-  bf16_t* As = lds;
-  bf16_t* Ws = lds + BM * BK;
+  constexpr int TILE = (BM + BN) * BK;  // elements per stage buffer
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[NBUF * TILE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -210,7 +213,9 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_glds(const bf16_t* __restric
 #pragma unroll
   for (int i = 0; i < GW; ++i) pw[i] = W + (size_t)min(n0 + (wave + 4 * i) * 8 + lr, e.N - 1) * K + lc * 8;
 
-  auto stage = [&](int kt) {
+  auto stage = [&](int kt, int buf) {
+    bf16_t* As = lds + buf * TILE;
+    bf16_t* Ws = As + BM * BK;
     const int k0 = kt * BK;
     if (k0 + BK <= K) {
 #pragma unroll
@@ -243,9 +248,9 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_glds(const bf16_t* __restric
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = zero16;
 
-  for (int kt = kt0; kt < nk; ++kt) {
-    stage(kt);
-    __syncthreads();  // carries the vmcnt(0) that lands the LDS-DMA
+  auto compute = [&](int buf) {
+    const bf16_t* As = lds + buf * TILE;
+    const bf16_t* Ws = As + BM * BK;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 fa[TM], fw[TN];
@@ -266,7 +271,22 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_glds(const bf16_t* __restric
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fw[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();  // every wave is done reading before the next tile overwrites the buffer
+  };
+  if (NBUF == 1) {
+    for (int kt = kt0; kt < nk; ++kt) {
+      stage(kt, 0);
+      __syncthreads();  // carries the vmcnt(0) that lands the LDS-DMA
+      compute(0);
+      __syncthreads();  // every wave is done reading before the next tile overwrites the buffer
+    }
+  } else {
+    stage(kt0, 0);
+    for (int kt = kt0; kt < nk; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      __syncthreads();  // tile kt has landed (vmcnt(0)); every wave has finished tile kt-1, so the other buffer is free
+      if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+      compute(cur);
+    }
   }
 
   // D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -419,13 +439,18 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
   if (bm == 128) {
     dim3 grid(cdiv(N, 128), cdiv(M, 128), 1);
     if (use_glds)
-      hipLaunchKernelGGL((gemm_bf16_glds<128, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+      hipLaunchKernelGGL((gemm_bf16_glds<128, 128, 1>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
     else
       hipLaunchKernelGGL((gemm_bf16_mfma<128, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
   } else {
     dim3 grid(cdiv(N, 128), cdiv(M, 64), e.splits);
-    if (use_glds)
-      hipLaunchKernelGGL((gemm_bf16_glds<64, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+    static const int f_nbuf = getenv("SRGPT_GEMM_FORCE_NBUF") ? atoi(getenv("SRGPT_GEMM_FORCE_NBUF")) : 0;
+    const long blocks = tiles * e.splits;
+    const bool dbuf = f_nbuf ? f_nbuf == 2 : blocks < 3L * srgpt_device_cus();
+    if (use_glds && dbuf)
+      hipLaunchKernelGGL((gemm_bf16_glds<64, 128, 2>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+    else if (use_glds)
+      hipLaunchKernelGGL((gemm_bf16_glds<64, 128, 1>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
     else
       hipLaunchKernelGGL((gemm_bf16_mfma<64, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
   }
