@@ -245,6 +245,144 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
   SRGPT_TS(4);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batch-1 bf16 variant with the activation row held in REGISTERS (no LDS, no block barrier).  Lane l only ever multiplies
+// chunks l, l + 64, ... of the row, so a wave keeps NIT = ceil(K / 512) packed 16-byte chunks per lane (32 VGPRs at
+// K = 4096, 112 at 14336) for all its rows; every wave holds the whole row across its lanes, so the RMSNorm sum of squares
+// is one wave_sum -- no cross-wave reduction, no __syncthreads.  The prologue shrinks to NIT (+NIT gain) loads and a
+// shuffle reduction, the inner loop loses its ds_read per chunk, and a K that is not a multiple of 4096 wastes no load
+// slots (NIT is a template parameter: static register indexing, exact batch sizes).  Residual elements of the wave's first
+// units are fetched up front by lanes 0..3 and broadcast with a shuffle.
+// ------------------------------------------------------------------------------------------------
+template <bool SWIGLU, bool NORM, int NIT>
+__global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
+                                                          const bf16_t* __restrict__ norm_w, float norm_eps,
+                                                          const bf16_t* __restrict__ residual, void* __restrict__ out, int N,
+                                                          int K, int out_f32) {
+  typedef bf16_t T;
+  constexpr int VEC = 8;
+  constexpr int R = SWIGLU ? 2 : 1;
+  constexpr int U = 8 / R;
+  constexpr int RES_MAXU = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunks = K / VEC;
+
+  // ---- prologue: the lane's chunks of x (and gains), straight to registers; nothing here is shared between waves ----
+  u32x4 xp[NIT];
+  float res_pre = 0.f;
+  {
+    if (!SWIGLU && residual != nullptr) {
+      const int ru = (int)blockIdx.x * 4 + wave + min(lane, RES_MAXU - 1) * (int)gridDim.x * 4;
+      res_pre = to_f(residual[min(ru, N - 1)]);
+    }
+    u32x4 gr[NORM ? NIT : 1];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int c = min(j * 64 + lane, nchunks - 1);
+      xp[j] = *reinterpret_cast<const u32x4*>(x + (size_t)c * VEC);
+      if (NORM) gr[j] = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * VEC);
+    }
+    if (NORM) {
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const bool ok = j * 64 + lane < nchunks;
+        float sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = bf16lo(xp[j][q]), hi = bf16hi(xp[j][q]);
+          sq += lo * lo + hi * hi;
+        }
+        ss += ok ? sq : 0.f;
+      }
+      const float r = rsqrtf(wave_sum(ss) / (float)K + norm_eps);
+#pragma unroll
+      for (int j = 0; j < NIT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // weight * hidden.to(dtype): two roundings, as LlamaRMSNorm materialises them
+          bf16x2 p;
+          p[0] = (bf16_t)(bf16lo(gr[j][q]) * rnd<T>(bf16lo(xp[j][q]) * r));
+          p[1] = (bf16_t)(bf16hi(gr[j][q]) * rnd<T>(bf16hi(xp[j][q]) * r));
+          xp[j][q] = __builtin_bit_cast(unsigned int, p);
+        }
+    }
+  }
+
+  int uk = 0;
+  for (int unit = blockIdx.x * 4 + wave; unit < N; unit += gridDim.x * 4, ++uk) {
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int it0 = 0; it0 < NIT; it0 += U) {
+      u32x4 w[R][U];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(unit + r * N) * K);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          if (it0 + j < NIT) {  // static
+            w[r][j] = __builtin_nontemporal_load(p + min((it0 + j) * 64 + lane, nchunks - 1));
+            __builtin_amdgcn_sched_barrier(0);  // issue order == consumption order (see gemv_kernel)
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        if (it0 + j < NIT) {  // static
+          const bool valid = (it0 + j) * 64 + lane < nchunks;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float x0 = bf16lo(xp[it0 + j][q]), x1 = bf16hi(xp[it0 + j][q]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const unsigned int wq = valid ? w[r][j][q] : 0u;
+              acc[r] = fmaf(bf16lo(wq), x0, acc[r]);
+              acc[r] = fmaf(bf16hi(wq), x1, acc[r]);
+            }
+          }
+        }
+      }
+    }
+    float a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = wave_sum(acc[r]);
+    const float res_b = __shfl(res_pre, uk < RES_MAXU ? uk : 0);
+    if (lane == 0) {
+      if (SWIGLU) {
+        const float g = rnd<T>(a[0]), u = rnd<T>(a[R - 1]);
+        reinterpret_cast<T*>(out)[unit] = from_f<T>(rnd<T>(silu(g)) * u);
+      } else {
+        float v = rnd<T>(a[0]);
+        if (residual) v = rnd<T>((uk < RES_MAXU ? res_b : to_f(residual[unit])) + v);
+        if (out_f32)
+          reinterpret_cast<float*>(out)[unit] = v;
+        else
+          reinterpret_cast<T*>(out)[unit] = from_f<T>(v);
+      }
+    }
+  }
+}
+
+template <bool SWIGLU, bool NORM>
+bool launch_gemv_reg(int nit, int grid, hipStream_t s, const void* x, const void* W, const void* norm_w, float eps,
+                     const void* residual, void* out, int N, int K, int out_f32) {
+#define SRGPT_REG_CASE(NITV)                                                                                                   \
+  case NITV:                                                                                                                   \
+    hipLaunchKernelGGL((gemv_reg_kernel<SWIGLU, NORM, NITV>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)W, \
+                       (const bf16_t*)norm_w, eps, (const bf16_t*)residual, out, N, K, out_f32);                               \
+    return true
+  switch (nit) {
+    SRGPT_REG_CASE(5);   // K = 2560
+    SRGPT_REG_CASE(8);   // K = 4096
+    SRGPT_REG_CASE(14);  // K = 6912
+    default: break;
+  }
+  return false;  // longer rows (K = 11008, 14336: 88-112 VGPRs of activations, spills when unrolled) stay on the LDS kernel
+#undef SRGPT_REG_CASE
+}
+
 template <typename T, int B>
 int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out, int N,
                 int K, int swiglu, int out_f32, hipStream_t s) {
@@ -257,6 +395,20 @@ int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, con
   if (grid > cus * per_cu) grid = cus * per_cu;
   if (grid < 1) grid = 1;
   const int chunks = B * (K / WChunk<T>::VEC);
+  static const int use_reg = getenv("SRGPT_GEMV_REG") ? atoi(getenv("SRGPT_GEMV_REG")) : 1;  // A/B knob
+  if (B == 1 && sizeof(T) == 2 && use_reg) {
+    const int nit = (K / 8 + 63) / 64;
+    // measured (scripts/ubench_gemv_c.hip): without the fused RMSNorm the register variant saves 0.6-0.8 us per launch
+    // (o_proj 8.5 -> 7.9 us); with it every wave normalises the whole row redundantly and loses ~1 us -> LDS kernel
+    bool ok = false;
+    if (!norm_w)
+      ok = swiglu ? launch_gemv_reg<true, false>(nit, grid, s, x, W, norm_w, eps, residual, out, N, K, out_f32)
+                  : launch_gemv_reg<false, false>(nit, grid, s, x, W, norm_w, eps, residual, out, N, K, out_f32);
+    if (ok) {
+      SRGPT_LAUNCH_CHECK();
+      return SRGPT_OK;
+    }
+  }
 #define SRGPT_GEMV_LAUNCH(SW, NXV)                                                                              \
   do {                                                                                                          \
     auto kfn = gemv_kernel<T, B, SW, NXV>;                                                                      \
