@@ -174,9 +174,6 @@ int srgpt_scatter_rows(const void* src, const int* src_idx, const int* idx, void
 int srgpt_silu_mul(const void* gu, void* out, int rows, int inter, int dtype, srgpt_stream_t stream);
 int srgpt_argmax(const float* logits, int64_t* ids_out, int B, int V, srgpt_stream_t stream);
 
-/* Streaming read of [ptr, ptr+bytes) that is discarded: warms the 256 MiB memory-side Infinity Cache with weights
- * a later kernel will stream (decode: issued on a second stream while the HBM-idle attention kernels run). */
-int srgpt_prefetch(const void* ptr, int64_t bytes, int blocks, srgpt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Composite: vision tower (VisionTower.forward, multimodal_encoder/vision_encoder.py:115-132 over HF

@@ -145,29 +145,7 @@ __global__ void rope_kv_append_kernel(T* __restrict__ qkv, T* __restrict__ kcach
   }
 }
 
-// streaming read that pulls a byte range through L2 into the memory-side Infinity Cache (256 MiB) and discards it
-__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ p, size_t n16, unsigned* sink) {
-  unsigned acc = 0;
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n16; i += 4 * stride) {
-    const u32x4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
-    acc ^= a[0] ^ b[1] ^ c[2] ^ d[3];
-  }
-  for (; i < n16; i += stride) acc ^= p[i][0];
-  if (acc == 0x9e3779b9u && sink) *sink = acc;  // practically never true; keeps the loads alive
-}
-
 }  // namespace
-
-extern "C" int srgpt_prefetch(const void* ptr, int64_t bytes, int blocks, srgpt_stream_t stream) {
-  SRGPT_CHECK(ptr && bytes > 0 && blocks > 0, SRGPT_ERR_ARG, "srgpt_prefetch: bad args");
-  SRGPT_CHECK(((uintptr_t)ptr % 16) == 0, SRGPT_ERR_ARG, "srgpt_prefetch: pointer must be 16-byte aligned");
-  hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const u32x4*)ptr, (size_t)(bytes / 16),
-                     (unsigned*)nullptr);
-  SRGPT_LAUNCH_CHECK();
-  return SRGPT_OK;
-}
 
 #define DISPATCH_T(dtype, NAME, ...)                   \
   if ((dtype) == SRGPT_BF16) {                         \
