@@ -34,7 +34,7 @@ constexpr int WROWB = WSK * 2 + 16;    // bytes per staged row (padded: fragment
 constexpr int WSTAGEB = 16 * WROWB;    // weight stage per wave
 constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumulated per pass
 
-// NI = x rows staged per wave / 2: 4 (batch <= 8) or 8 (batch <= 16).  NW = waves per block (the K split): 4, or 8 when
+// NI = x rows staged per wave / 2: 2 (batch <= 4), 4 (batch <= 8) or 8 (batch <= 16).  NW = waves per block (the K split): 4, or 8 when
 // there are no more units than CUs so that one block per CU still keeps 8 waves streaming.
 // W8: the weights are OCP fp8 e4m3fn bytes with one fp32 scale per weight row (W8A16): a stage is 8 loads of 8 bytes per lane
 // (2 rows x 256 bytes each), widened to bf16 (exact) on the way into LDS; the row scale multiplies the fp32 dot product.
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
             for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(wst + (2 * j + lrow) * WROWB + lchunk * 16) = widen(wb[cur][j]);
             __builtin_amdgcn_wave_barrier();
             // x fragments are re-read per sub-unit rather than held: 32 VGPRs buy nothing, LDS has the headroom
-            const int xrow = (NI == 8) ? (lane & 15) : (lane & 7);
+            const int xrow = lane & (2 * NI - 1);  // rows past the staged ones alias valid rows: their outputs are never stored
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
               const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xst + xrow * WROWB + (4 * s + (lane >> 4)) * 16);
@@ -320,6 +320,9 @@ int skinny_dispatch(const void* x, const void* W, const float* wscale, const voi
                     void* out, int batch, int N, int K, int swiglu, int out_f32, hipStream_t s) {
   SRGPT_CHECK(batch >= 1 && batch <= 16, SRGPT_ERR_ARG, "skinny: batch %d outside 1..16", batch);
   SRGPT_CHECK(K % 8 == 0 && K >= 8, SRGPT_ERR_ARG, "skinny: K=%d must be a multiple of 8", K);
+  if (batch <= 4)
+    return swiglu ? launch_skinny_nw<true, 2, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s)
+                  : launch_skinny_nw<false, 2, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s);
   if (batch <= 8)
     return swiglu ? launch_skinny_nw<true, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s)
                   : launch_skinny_nw<false, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s);
