@@ -7,6 +7,8 @@
 //  2. simple_attn_kernel -- one wave per (query, head); any dtype / head_dim; fp32 parity path.
 //  3. decode_split/combine -- single new token against the static KV cache, flash-decoding split over
 //     keys, fused RoPE of the new q/k and cache append.  HBM/latency bound.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -242,8 +244,10 @@ constexpr int DEC_CHUNK_MAX = 256;
 constexpr int DEC_SPLIT_MAX = 64;
 
 static inline int decode_nsplit(int max_pos) {
+  static const int env_min = getenv("SRGPT_DECODE_MIN_SPLITS") ? atoi(getenv("SRGPT_DECODE_MIN_SPLITS")) : 16;  // tuning knob
   int n = cdiv(max_pos, DEC_CHUNK_MAX);
-  if (n < 16) n = 16;
+  if (n < env_min) n = env_min;
+  if (n > DEC_SPLIT_MAX) n = DEC_SPLIT_MAX;
   return n;
 }
 

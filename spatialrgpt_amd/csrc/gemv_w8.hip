@@ -132,8 +132,11 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
   int uk = 0;
   for (int unit = blockIdx.x * 4 + wave; unit < NUNIT; unit += gridDim.x * 4, ++uk) {
     // rows of the unit (the second row of an odd-N tail unit is clamped and never stored)
-    const int row0 = SWIGLU ? unit : 2 * unit;
-    const int row1 = SWIGLU ? unit + N : min(2 * unit + 1, N - 1);
+    const int row0 = __builtin_amdgcn_readfirstlane(SWIGLU ? unit : 2 * unit);  // wave-uniform: scalar addressing
+    const int row1 = __builtin_amdgcn_readfirstlane(SWIGLU ? unit + N : min(2 * unit + 1, N - 1));
+    // the row scales are requested BEFORE the weight stream (scalar loads): placed at their use they would queue behind
+    // 8 KiB of weight loads and expose a memory latency per unit (same trap as the residual element, see gemv.hip)
+    const float s0 = wscale[row0], s1 = wscale[row1];
     float acc[R][B];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -188,7 +191,6 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
       }
     }
 
-    const float s0 = wscale[row0], s1 = wscale[row1];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
       const float a0 = wave_sum(acc[0][b]) * s0, a1 = wave_sum(acc[1][b]) * s1;
