@@ -194,6 +194,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     for (int su = 0; su < NSU; ++su) acc[su] = f32x4{0.f, 0.f, 0.f, 0.f};
     // register ring of DEPTH weight stages with static slot indices (a trip = DEPTH slices x NSU stages, a multiple of
     // DEPTH): the loads of stage t+DEPTH-1 are issued before stage t is multiplied.  bf16: 2 x 8 KiB, fp8: 2 x 4 KiB.
+    // epilogue operands that do not depend on the products -- row scales (W8) and residual elements -- are requested now:
+    // fetched at their use they would each add a memory round trip after the last barrier of the pass
+    constexpr int EIT0 = ((NSU / R) * 256 + NT - 1) / NT;  // epilogue iterations per thread
+    constexpr int EIT = EIT0 > 0 ? EIT0 : 1;               // (odd NSU never occurs with SwiGLU; keep the type valid)
+    float pre_sc[EIT][R], pre_res[EIT];
+#pragma unroll
+    for (int i = 0; i < EIT; ++i) {
+      const int e = tid + i * NT;
+      const int u = e >> 8, l2 = e & 63, q = (e >> 6) & 3;
+      const int b = min(4 * (l2 >> 4) + q, B - 1);
+      const int unit = (pass * MAXU + u) * grid + (int)blockIdx.x;
+      const int n = min(unit * 16 + (l2 & 15), N - 1);
+#pragma unroll
+      for (int r = 0; r < R; ++r) pre_sc[i][r] = W8 ? wscale[n + r * N] : 1.f;
+      pre_res[i] = (!SWIGLU && residual) ? (float)residual[(size_t)b * N + n] : 0.f;
+    }
     constexpr int DEPTH = 2;  // measured: a 4-deep ring of 4 KiB fp8 stages is slower than 2-deep (3.61 vs 3.85 TB/s on gate/up)
     WReg wb[DEPTH][8];
 #pragma unroll
@@ -238,7 +254,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
 #pragma unroll
     for (int su = 0; su < NSU; ++su) *reinterpret_cast<f32x4*>(redf + ((wave * MAXSU + su) * 64 + lane) * 4) = acc[su];
     __syncthreads();
-    for (int e = tid; e < (NSU / R) * 256; e += NT) {
+#pragma unroll
+    for (int i = 0; i < EIT; ++i) {
+      const int e = tid + i * NT;
+      if (e >= (NSU / R) * 256) break;
       const int u = e >> 8, l2 = e & 63, q = (e >> 6) & 3;
       const int b = 4 * (l2 >> 4) + q;
       const int unit = (pass * MAXU + u) * grid + (int)blockIdx.x;
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
         float t = 0.f;
 #pragma unroll
         for (int wv = 0; wv < NW; ++wv) t += redf[((wv * MAXSU + u * R + r) * 64 + l2) * 4 + q];
-        if (W8) t *= wscale[min(n, N - 1) + r * N];
+        if (W8) t *= pre_sc[i][r];
         a[r] = t;
       }
       if (b < B && n < N) {
@@ -258,7 +277,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
           reinterpret_cast<bf16_t*>(out)[(size_t)b * N + n] = (bf16_t)(rnd<bf16_t>(silu(g)) * up);
         } else {
           float v = rnd<bf16_t>(a[0]);
-          if (residual) v = rnd<bf16_t>((float)residual[(size_t)b * N + n] + v);
+          if (residual) v = rnd<bf16_t>(pre_res[i] + v);
           if (out_f32)
             reinterpret_cast<float*>(out)[(size_t)b * N + n] = v;
           else
