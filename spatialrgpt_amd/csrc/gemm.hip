@@ -1,8 +1,10 @@
 // GEMM family: C[M,N] = act(A[M,K] @ W[N,K]^T + bias) + residual      (see include/srgpt.h)
 //
 // bf16: LDS-tiled MFMA kernel (v_mfma_f32_32x32x16_bf16), 256 threads = 2x2 waves, BK = 64,
-//       register-staged double buffering, XOR-swizzled 16-byte LDS slots (conflict <= 2-way on
-//       ds_read_b128), fused epilogue (bias / activation / residual / deconv pixel-shuffle / fp32 out).
+//       register-staged double buffering, XOR-swizzled 16-byte LDS slots: slot ^ ((row >> 1) & 7) -- with 128-byte rows the
+//       16 lanes of a ds_read_b128 pass (16 consecutive rows, one slot) then cover all 64 banks exactly once (the row's
+//       parity picks the 128-byte half, the swizzled slot the 16 bytes within it); slot ^ (row & 7) left rows r and r + 8
+//       on the same banks: SQ_LDS_BANK_CONFLICT was 50 % of SQ_LDS_IDX_ACTIVE, fused epilogue (bias / activation / residual / deconv pixel-shuffle / fp32 out).
 //       Both operands are K-contiguous (nn.Linear weight layout), so A and W tiles stage identically.
 // fp32: plain LDS-tiled FMA kernel; exists for tight-tolerance parity runs of the same host path.
 #include <stdlib.h>
@@ -89,12 +91,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int r = sr + 32 * i;
-      *reinterpret_cast<u32x4*>(As + (size_t)buf * BM * BK + r * BK + ((sc ^ (r & 7)) << 3)) = da[i];
+      *reinterpret_cast<u32x4*>(As + (size_t)buf * BM * BK + r * BK + ((sc ^ ((r >> 1) & 7)) << 3)) = da[i];
     }
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
       const int r = sr + 32 * i;
-      *reinterpret_cast<u32x4*>(Ws + (size_t)buf * BN * BK + r * BK + ((sc ^ (r & 7)) << 3)) = dw[i];
+      *reinterpret_cast<u32x4*>(Ws + (size_t)buf * BN * BK + r * BK + ((sc ^ ((r >> 1) & 7)) << 3)) = dw[i];
     }
   };
 
@@ -119,12 +121,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int r = wm * (BM / 2) + i * 32 + (lane & 31);
-        fa[i] = *reinterpret_cast<const bf16x8*>(as + r * BK + ((slot ^ (r & 7)) << 3));
+        fa[i] = *reinterpret_cast<const bf16x8*>(as + r * BK + ((slot ^ ((r >> 1) & 7)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int r = wn * (BN / 2) + j * 32 + (lane & 31);
-        fw[j] = *reinterpret_cast<const bf16x8*>(ws + r * BK + ((slot ^ (r & 7)) << 3));
+        fw[j] = *reinterpret_cast<const bf16x8*>(ws + r * BK + ((slot ^ ((r >> 1) & 7)) << 3));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__
 // bf16 MFMA kernel, direct-to-LDS staging (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass, single LDS
 // buffer (BM+BN) x 128 B -> 3 blocks per CU at 128x128, whose independent K loops overlap each other's barriers.
 // A wave-instruction moves 8 rows x 128 B into 1 KiB of LDS at (wave-uniform base + lane * 16); the XOR slot swizzle of
-// the register-staged kernel is kept by permuting WHICH 16-byte chunk of its row a lane fetches (chunk = slot ^ (row & 7)),
+// the register-staged kernel is kept by permuting WHICH 16-byte chunk of its row a lane fetches (chunk = slot ^ ((row >> 1) & 7)),
 // so the fragment reads below are the same conflict-free ds_read_b128.  Rows past M / N re-read the last valid row
 // (their outputs are never stored); a ragged last K tile (K % 64 != 0) is staged through registers with zero fill.
 // ------------------------------------------------------------------------------------------------
@@ -198,7 +200,9 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_bf16_glds(const b
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int lr = lane >> 3, lc = (lane & 7) ^ lr;  // row within the 8-row group, logical chunk this lane fetches
+  // row within the 8-row group; logical chunk this lane fetches = physical slot ^ swz(row), swz(row) = (row >> 1) & 7
+  // (group base rows are multiples of 8: (row >> 1) & 7 = ((wave & 1) << 2) | (lr >> 1) for every group of this wave)
+  const int lr = lane >> 3, lc = (lane & 7) ^ (((wave & 1) << 2) | (lr >> 1));
 
   const int nk_all = (K + BK - 1) / BK;
   const int kt0 = e.splits > 1 ? (int)blockIdx.z * e.tiles_per_split : 0;
@@ -258,12 +262,12 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_bf16_glds(const b
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int r = wm * (BM / 2) + i * 32 + (lane & 31);
-        fa[i] = *reinterpret_cast<const bf16x8*>(As + r * BK + ((slot ^ (r & 7)) << 3));
+        fa[i] = *reinterpret_cast<const bf16x8*>(As + r * BK + ((slot ^ ((r >> 1) & 7)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int r = wn * (BN / 2) + j * 32 + (lane & 31);
-        fw[j] = *reinterpret_cast<const bf16x8*>(Ws + r * BK + ((slot ^ (r & 7)) << 3));
+        fw[j] = *reinterpret_cast<const bf16x8*>(Ws + r * BK + ((slot ^ ((r >> 1) & 7)) << 3));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
