@@ -133,14 +133,21 @@ def test_sampling_path_runs_and_respects_eos():
         model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], num_beams=2, max_new_tokens=2)
 
 
-def test_true_width_truncated_depth_bf16_vs_oracle():
-    """VILA1.5-8B layer geometry (hidden 4096, GQA 32/8, inter 14336, SigLIP-so400m width) with 2 LLM / 2 ViT layers and a
-    16k vocab, bf16, one full request: stage tensors within bf16 tolerance of the oracle, ids margin-aware."""
+@pytest.mark.parametrize("geom", ["vila15_8b", "llama2_7b", "sheared_3b"])
+def test_true_width_truncated_depth_bf16_vs_oracle(geom):
+    """The three LLM layer geometries of the reference's recipes at TRUE width -- VILA1.5-8B (hidden 4096, GQA 32/8, inter
+    14336), Llama-2-7B (MHA 32/32, inter 11008), Sheared-LLaMA-2.7B (hidden 2560, 20 heads, inter 6912) -- behind the
+    SigLIP-so400m-width tower, with 2 LLM / 2 ViT layers and a 16k vocab, bf16, one full request: stage tensors within bf16
+    tolerance of the oracle, ids margin-aware."""
     from oracle import srgpt_oracle as so
     from spatialrgpt_amd.config import SrgptConfig
     from spatialrgpt_amd.model import LlavaLlamaModel
 
     kw = dict(vit_layers=3, layers=2, vocab=16386, mask_token_id=16384, depth_token_id=16385)
+    if geom == "llama2_7b":
+        kw.update(hidden=4096, inter=11008, heads=32, kv_heads=32, rope_theta=10000.0)
+    elif geom == "sheared_3b":
+        kw.update(hidden=2560, inter=6912, heads=20, kv_heads=20, rope_theta=10000.0)
     ocfg = so.SrgptConfig(**kw)
     w = so.synth_weights(ocfg, seed=11, dtype=torch.bfloat16)
     ids, images, depths, masks = so.synth_inputs(ocfg, batch=1, regions=8, prompt_len=64, seed=2, dtype=torch.bfloat16)
@@ -150,7 +157,7 @@ def test_true_width_truncated_depth_bf16_vs_oracle():
     ref_ids, st = so.generate(w, ocfg, ids, images, depths, masks, max_new_tokens=G, return_stages=True, model_dtype=torch.bfloat16)
     got = {}
     emb, _, _ = model.engine.prepare_inputs(ids.to(DEV), images.to(DEV), depths.to(DEV), [m.to(DEV) for m in masks], None, stages=got)
-    assert emb.shape == (1, 259, 4096)
+    assert emb.shape == (1, 259, kw.get("hidden", 4096))
 
     def chk(a, b, what, rel=4e-2):
         assert_close(a, b, rel * (float(b.float().abs().max()) + 1e-6), 0, what)
