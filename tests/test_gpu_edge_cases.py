@@ -133,11 +133,11 @@ def test_sampling_path_runs_and_respects_eos():
         model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], num_beams=2, max_new_tokens=2)
 
 
-@pytest.mark.parametrize("geom", ["vila15_8b", "llama2_7b", "sheared_3b"])
+@pytest.mark.parametrize("geom", ["vila15_8b", "llama2_7b", "sheared_3b", "clip_l14_336"])
 def test_true_width_truncated_depth_bf16_vs_oracle(geom):
     """The three LLM layer geometries of the reference's recipes at TRUE width -- VILA1.5-8B (hidden 4096, GQA 32/8, inter
     14336), Llama-2-7B (MHA 32/32, inter 11008), Sheared-LLaMA-2.7B (hidden 2560, 20 heads, inter 6912) -- behind the
-    SigLIP-so400m-width tower, with 2 LLM / 2 ViT layers and a 16k vocab, bf16, one full request: stage tensors within bf16
+    SigLIP-so400m-width tower (plus the CLIP-L/14-336 tower in front of the 8B geometry), with 2 LLM / 2 ViT layers and a 16k vocab, bf16, one full request: stage tensors within bf16
     tolerance of the oracle, ids margin-aware."""
     from oracle import srgpt_oracle as so
     from spatialrgpt_amd.config import SrgptConfig
@@ -148,6 +148,8 @@ def test_true_width_truncated_depth_bf16_vs_oracle(geom):
         kw.update(hidden=4096, inter=11008, heads=32, kv_heads=32, rope_theta=10000.0)
     elif geom == "sheared_3b":
         kw.update(hidden=2560, inter=6912, heads=20, kv_heads=20, rope_theta=10000.0)
+    elif geom == "clip_l14_336":  # CLIP-L/14-336 tower (class token, pre-LN, quick-GELU, "patch" features: 576 tokens -> 96x96 hres)
+        kw.update(vit_hidden=1024, vit_inter=4096, vit_heads=16, image_size=336, vit_eps=1e-5, tower="clip", select_feature="patch")
     ocfg = so.SrgptConfig(**kw)
     w = so.synth_weights(ocfg, seed=11, dtype=torch.bfloat16)
     ids, images, depths, masks = so.synth_inputs(ocfg, batch=1, regions=8, prompt_len=64, seed=2, dtype=torch.bfloat16)
