@@ -133,7 +133,7 @@ def test_sampling_path_runs_and_respects_eos():
         model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], num_beams=2, max_new_tokens=2)
 
 
-@pytest.mark.parametrize("geom", ["vila15_8b", "llama2_7b", "sheared_3b", "clip_l14_336"])
+@pytest.mark.parametrize("geom", ["vila15_8b", "llama2_7b", "sheared_3b", "clip_l14_336", "vila15_8b-fp8"])
 def test_true_width_truncated_depth_bf16_vs_oracle(geom):
     """The three LLM layer geometries of the reference's recipes at TRUE width -- VILA1.5-8B (hidden 4096, GQA 32/8, inter
     14336), Llama-2-7B (MHA 32/32, inter 11008), Sheared-LLaMA-2.7B (hidden 2560, 20 heads, inter 6912) -- behind the
@@ -153,7 +153,11 @@ def test_true_width_truncated_depth_bf16_vs_oracle(geom):
     ocfg = so.SrgptConfig(**kw)
     w = so.synth_weights(ocfg, seed=11, dtype=torch.bfloat16)
     ids, images, depths, masks = so.synth_inputs(ocfg, batch=1, regions=8, prompt_len=64, seed=2, dtype=torch.bfloat16)
-    model = LlavaLlamaModel(SrgptConfig(**kw), dict(w), device=DEV, dtype=torch.bfloat16, rope_positions=1024)
+    fp8 = geom.endswith("-fp8")  # weight-only fp8 LLM matrices: the oracle runs on dequant(quant(W)), the engine quantises itself
+    model = LlavaLlamaModel(SrgptConfig(**kw), dict(w), device=DEV, dtype=torch.bfloat16, rope_positions=1024,
+                            llm_weight_format="fp8" if fp8 else "native")
+    if fp8:
+        w = so.fp8_dequantised_weights(w)
     torch.set_num_threads(16)
     G = 6
     ref_ids, st = so.generate(w, ocfg, ids, images, depths, masks, max_new_tokens=G, return_stages=True, model_dtype=torch.bfloat16)
