@@ -1,0 +1,37 @@
+"""Soak / race screen: many generate() calls of mixed batch sizes and lengths on one engine; every repeat of a request must
+return bit-identical ids (any race in the graph replay, the DMA-staged GEMM or the wave-private LDS stages shows up here)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from spatialrgpt_amd.config import SrgptConfig
+from spatialrgpt_amd.model import LlavaLlamaModel
+from spatialrgpt_amd.weights import synth_state_dict
+
+dev = "cuda"
+fmt = sys.argv[1] if len(sys.argv) > 1 else "native"
+cfg = SrgptConfig.vila15_8b()
+cfg = SrgptConfig(**{**cfg.to_dict(), "layers": 8, "vit_layers": 7})  # true widths, reduced depth: more calls per minute
+sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=dev)
+model = LlavaLlamaModel(cfg, sd, device=dev, dtype=torch.bfloat16, rope_positions=2048, consume_state_dict=True, llm_weight_format=fmt)
+g = torch.Generator().manual_seed(0)
+cases = []
+for i in range(8):
+    B = [1, 2, 3, 4, 8, 16, 5, 1][i]
+    P = [64, 40, 64, 100, 64, 32, 200, 512][i]
+    G = [32, 16, 24, 8, 16, 8, 12, 40][i]
+    reqs = [bench.synth_request(cfg, 4 + (i % 3), P, 10 * i + b, dev, torch.bfloat16) for b in range(B)]
+    cases.append((torch.cat([r[0] for r in reqs], 0), torch.cat([r[1] for r in reqs], 0), torch.cat([r[2] for r in reqs], 0), [r[3][0] for r in reqs], G))
+ref = {}
+t0 = time.time()
+n = 0
+order = torch.randint(0, len(cases), (int(sys.argv[2]) if len(sys.argv) > 2 else 60,), generator=g).tolist()
+for k, ci in enumerate(order):
+    ids, im, dp, mk, G = cases[ci]
+    out = model.generate(ids, images=im, depths=dp, masks=mk, do_sample=False, max_new_tokens=G, eos_token_id=None).cpu()
+    n += 1
+    if ci in ref:
+        assert torch.equal(out, ref[ci]), f"call {k}: case {ci} (batch {ids.shape[0]}) differs from its first run"
+    else:
+        ref[ci] = out
+print(f"soak ok: {n} calls, {len(ref)} distinct cases, weights={fmt}, {time.time() - t0:.1f} s")
