@@ -4,8 +4,9 @@
 // Same structure as gemv.hip (wave per unit, 8 independent 1-KiB non-temporal wave loads per batch issued in consumption
 // order, branch-free consumption with counted vmcnt, x in LDS, fused RMSNorm / SwiGLU / residual / fp32-logit epilogues,
 // prologue loads issued up front) with these differences:
-//   * a 16-byte chunk holds 16 weights, so a K = 4096 row is 4 wave loads: a unit is TWO rows (plain: rows 2u, 2u+1;
-//     SwiGLU: gate row u and up row u as before) to keep 8 loads in flight per wave;
+//   * a 16-byte chunk holds 16 weights, so a K = 4096 row is 4 wave loads: a unit is TWO output columns (plain: rows 2u,
+//     2u+1 -> 8 loads per batch; SwiGLU: gate rows 2u, 2u+1 and up rows N+2u, N+2u+1 -> 16 loads = 16 KiB per batch:
+//     at half the bytes per row the per-row latency dominates, fewer and larger rounds win here);
 //   * weights are widened with v_cvt_pk_f32_fp8 (OCP e4m3fn on gfx950), 2 values per instruction; the two rows of a unit
 //     share the fp32 copies of x;
 //   * the per-row scale multiplies the reduced dot product.
@@ -25,8 +26,8 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
                                                          void* __restrict__ out, int N, int K, int out_f32) {
   constexpr int VEC = 8;   // activation elements per 16-byte chunk
   constexpr int WVEC = 16;  // weight elements per 16-byte chunk
-  constexpr int R = 2;      // weight rows per unit
-  constexpr int U = 4;      // K-chunks per row per batch: 8 loads (8 KiB per wave) in flight, then consumed
+  constexpr int R = SWIGLU ? 4 : 2;  // weight rows per unit (SwiGLU: 2 gate + 2 up rows -> 2 outputs; 16 KiB per wave in flight)
+  constexpr int U = 4;               // K-chunks per row per batch
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);  // [B][K]
   __shared__ float red[16];
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
   const int nchunks = K / VEC;           // 16-byte activation chunks per row
   const int wchunks = K / WVEC;          // 16-byte weight chunks per row
   const int nit = (wchunks + 63) >> 6;   // weight-chunk iterations per row (64 lanes each)
-  const int NUNIT = SWIGLU ? N : (N + 1) >> 1;
+  const int NUNIT = (N + 1) >> 1;
 
   // ---- prologue: stage x (and RMSNorm it) into LDS ----
   // All global loads of the prologue (activation chunks AND norm gains) are issued up front, branch-free, so the
@@ -132,11 +133,20 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
   int uk = 0;
   for (int unit = blockIdx.x * 4 + wave; unit < NUNIT; unit += gridDim.x * 4, ++uk) {
     // rows of the unit (the second row of an odd-N tail unit is clamped and never stored)
-    const int row0 = __builtin_amdgcn_readfirstlane(SWIGLU ? unit : 2 * unit);  // wave-uniform: scalar addressing
-    const int row1 = __builtin_amdgcn_readfirstlane(SWIGLU ? unit + N : min(2 * unit + 1, N - 1));
+    // rows of the unit (wave-uniform: scalar addressing).  plain: rows 2u, 2u+1; SwiGLU: gate rows 2u, 2u+1 and up rows
+    // N+2u, N+2u+1.  The second row of an odd-N tail unit is clamped and never stored.
+    int rows[R];
+    rows[0] = __builtin_amdgcn_readfirstlane(2 * unit);
+    rows[1] = __builtin_amdgcn_readfirstlane(min(2 * unit + 1, N - 1));
+    if (SWIGLU) {
+      rows[R - 2] = __builtin_amdgcn_readfirstlane(N + 2 * unit);
+      rows[R - 1] = __builtin_amdgcn_readfirstlane(N + min(2 * unit + 1, N - 1));
+    }
     // the row scales are requested BEFORE the weight stream (scalar loads): placed at their use they would queue behind
-    // 8 KiB of weight loads and expose a memory latency per unit (same trap as the residual element, see gemv.hip)
-    const float s0 = wscale[row0], s1 = wscale[row1];
+    // the weight loads and expose a memory latency per unit (same trap as the residual element, see gemv.hip)
+    float sc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) sc[r] = wscale[rows[r]];
     float acc[R][B];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
       u32x4 w[R][U];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(r == 0 ? row0 : row1) * K);
+        const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)rows[r] * K);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
           w[r][j] = __builtin_nontemporal_load(p + min((it0 + j) * 64 + lane, wchunks - 1));
@@ -193,17 +203,19 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
 
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-      const float a0 = wave_sum(acc[0][b]) * s0, a1 = wave_sum(acc[1][b]) * s1;
-      if (lane == 0) {
-        if (SWIGLU) {
-          const float g = rnd<T>(a0), u = rnd<T>(a1);
-          reinterpret_cast<T*>(out)[(size_t)b * N + unit] = from_f<T>(rnd<T>(silu(g)) * u);
-        } else {
+      float a[R];
 #pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            const int n = 2 * unit + r;
-            if (n < N) {
-              float v = rnd<T>(r == 0 ? a0 : a1);
+      for (int r = 0; r < R; ++r) a[r] = wave_sum(acc[r][b]) * sc[r];
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int n = 2 * unit + r;
+          if (n < N) {
+            if (SWIGLU) {
+              const float g = rnd<T>(a[r]), u = rnd<T>(a[R - 2 + r]);
+              reinterpret_cast<T*>(out)[(size_t)b * N + n] = from_f<T>(rnd<T>(silu(g)) * u);
+            } else {
+              float v = rnd<T>(a[r]);
               if (residual)
                 v = rnd<T>((uk < RES_MAXU ? res_s[b][wave][2 * uk + r] : to_f(residual[(size_t)b * N + n])) + v);
               if (out_f32)
@@ -225,7 +237,7 @@ int launch_gemv_w8(const void* x, const void* W, const float* wscale, const void
   SRGPT_CHECK(lds <= 150 * 1024, SRGPT_ERR_UNSUPPORTED, "srgpt_gemv_w8: batch*K too large for LDS (%zu bytes)", lds);
   const int cus = srgpt_device_cus();
   const int per_cu = lds > 70 * 1024 ? 1 : 2;
-  const int nunit = swiglu ? N : (N + 1) / 2;
+  const int nunit = (N + 1) / 2;
   int grid = (nunit + 3) / 4;
   if (grid > cus * per_cu) grid = cus * per_cu;
   if (grid < 1) grid = 1;
