@@ -74,3 +74,29 @@ def test_oracle_kv_cache_equals_full_forward():
     for t in range(6, 9):
         outs.append(so.llama_forward(w, cfg, x[:, t:t + 1], pos[:, t:t + 1], kv))
     assert_close(torch.cat(outs, 1), full, 2e-5, 0, "incremental vs full")
+
+
+def test_oracle_fp8_weight_quantisation_properties():
+    """fp8_dequantised_weights (BASELINE config 5 semantics): only LLM Linear weights change; row scales are powers of two
+    with max|row|/scale in (224, 448]; the map is idempotent; the error is bounded by half an e4m3 ulp of the row maximum."""
+    import torch
+
+    from oracle import srgpt_oracle as so
+
+    cfg = so.SrgptConfig(vit_hidden=32, vit_inter=64, vit_layers=2, vit_heads=2, image_size=28, patch_size=14, hidden=64, inter=128,
+                         layers=2, heads=4, kv_heads=2, vocab=128, mask_token_id=120, depth_token_id=121)
+    w = so.synth_weights(cfg, seed=5, dtype=torch.bfloat16)
+    q = so.fp8_dequantised_weights(w)
+    changed = {k for k in w if not torch.equal(w[k], q[k])}
+    assert changed and all(k.startswith("llm.") and (k.endswith("_proj.weight") or k == "llm.lm_head.weight") for k in changed)
+    assert torch.equal(q["llm.model.embed_tokens.weight"], w["llm.model.embed_tokens.weight"])
+    again = so.fp8_dequantised_weights(q)
+    for k in changed:
+        assert torch.equal(again[k], q[k]), f"{k}: quantisation is not idempotent"
+        a, b = w[k].float(), q[k].float()
+        amax = a.abs().amax(dim=1, keepdim=True)
+        assert float(((a - b).abs() / amax).max()) <= 2.0 ** -4 + 2.0 ** -8  # 3 mantissa bits (+ the bf16 store)
+        # codes recovered from the dequantised values sit on a power-of-two grid: max|row| / scale in (224, 448]
+        sc = torch.ldexp(torch.ones(a.shape[0]), torch.ceil(torch.log2(b.abs().amax(dim=1).double() / 448.0)).to(torch.int32))
+        r = b.abs().amax(dim=1) / sc
+        assert bool(((r > 223.9) & (r <= 448.0)).all())
