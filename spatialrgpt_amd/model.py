@@ -7,9 +7,8 @@ name BASELINE.json uses, is an alias (the reference never defines it: SURVEY sec
 """
 from __future__ import annotations
 
-import warnings
 from types import SimpleNamespace
-from typing import Dict, List, Optional
+from typing import Dict
 
 import torch
 

@@ -12,7 +12,6 @@ and the ctypes structs (include/srgpt.h) that point at them.
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Dict, List
 
 import torch
