@@ -41,6 +41,16 @@ void srgpt_set_error(const char* fmt, ...);
     }                                                                              \
   } while (0)
 
+// a HIP runtime call whose failure must surface through the C ABI
+#define SRGPT_HIP_TRY(call, what)                                                     \
+  do {                                                                                \
+    const hipError_t e__ = (call);                                                    \
+    if (e__ != hipSuccess) {                                                          \
+      srgpt_set_error("%s failed: %s", (what), hipGetErrorString(e__));               \
+      return SRGPT_ERR_LAUNCH;                                                        \
+    }                                                                                 \
+  } while (0)
+
 #define SRGPT_TRY(expr)        \
   do {                         \
     int rc__ = (expr);         \

@@ -276,7 +276,7 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
     srgpt_set_error("srgpt_llm_prefill: memcpy failed");
     return SRGPT_ERR_LAUNCH;
   }
-  if (hidden_out) hipMemcpyAsync(hidden_out, l.x, hid_bytes, hipMemcpyDeviceToDevice, s);
+  if (hidden_out) SRGPT_HIP_TRY(hipMemcpyAsync(hidden_out, l.x, hid_bytes, hipMemcpyDeviceToDevice, s), "srgpt_llm_prefill: hidden-state copy");
   const float scale = 1.0f / sqrtf((float)D);
   for (int i = 0; i < w->layers; ++i) {
     char* kc = reinterpret_cast<char*>(st->kcache) + (size_t)i * layer_kv;
@@ -298,8 +298,9 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
     SRGPT_TRY(srgpt_gemm(l.act, w->wdown[i], nullptr, l.x, l.x, rows, Hd, I, I, Hd, SRGPT_ACT_NONE, 0, 0, 0,
                          SRGPT_OUT_PLAIN, 0, l.gws, (int64_t)l.gws_bytes, dt, stream));
     if (hidden_out)
-      hipMemcpyAsync(reinterpret_cast<char*>(hidden_out) + (size_t)(i + 1) * hid_bytes, l.x, hid_bytes,
-                     hipMemcpyDeviceToDevice, s);
+      SRGPT_HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(hidden_out) + (size_t)(i + 1) * hid_bytes, l.x, hid_bytes,
+                                   hipMemcpyDeviceToDevice, s),
+                    "srgpt_llm_prefill: hidden-state copy");
   }
   if (all_logits) {
     SRGPT_TRY(srgpt_rmsnorm(l.x, w->final_norm, l.h, rows, Hd, w->rms_eps, dt, stream));
@@ -404,7 +405,7 @@ extern "C" int srgpt_llm_decode_graph_create(const srgpt_llm_weights* w, srgpt_l
   const int rc = srgpt_llm_decode_step(w, st, stream);
   const hipError_t ee = hipStreamEndCapture(s, &graph);
   if (rc != SRGPT_OK) {
-    if (graph) hipGraphDestroy(graph);
+    if (graph) (void)hipGraphDestroy(graph);
     return rc;
   }
   if (ee != hipSuccess || !graph) {
@@ -414,7 +415,7 @@ extern "C" int srgpt_llm_decode_graph_create(const srgpt_llm_weights* w, srgpt_l
   hipGraphExec_t exec = nullptr;
   const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   if (ei != hipSuccess) {
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     srgpt_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ei));
     return SRGPT_ERR_STATE;
   }
@@ -436,8 +437,8 @@ extern "C" int srgpt_graph_launch(srgpt_graph* g, int times, srgpt_stream_t stre
 
 extern "C" int srgpt_graph_destroy(srgpt_graph* g) {
   if (!g) return SRGPT_OK;
-  hipGraphExecDestroy(g->exec);
-  hipGraphDestroy(g->graph);
+  (void)hipGraphExecDestroy(g->exec);  // best effort: nothing useful to report from a destructor path
+  (void)hipGraphDestroy(g->graph);
   delete g;
   return SRGPT_OK;
 }
