@@ -159,3 +159,24 @@ def test_pil_bicubic_tables_reproduce_pillow_bit_exactly():
         idx = cv2_nearest_index(n_in, n_out)
         assert idx[0] == 0 and idx.max() <= n_in - 1 and np.all(np.diff(idx) >= 0)
         assert np.array_equal(idx, np.minimum((np.arange(n_out) * n_in) // n_out, n_in - 1))  # exact rational floor agrees here
+
+
+def test_pil_bicubic_tables_random_sizes_match_pillow():
+    """property check over random (in, out) sizes: one image row resized with the tables == Pillow (covers extreme up/down
+    scaling ratios, sizes 1..700, where the tap count and the clipped bounds at the borders change)."""
+    from PIL import Image
+
+    from spatialrgpt_amd.mm_utils import pil_bicubic_tables
+
+    rng = np.random.default_rng(7)
+    for _ in range(60):
+        w_in, w_out = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+        row = rng.integers(0, 256, (1, w_in, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(row).resize((w_out, 1), Image.BICUBIC))
+        b, k = pil_bicubic_tables(w_in, w_out)
+        out = np.zeros((1, w_out, 3), np.uint8)
+        for xx in range(w_out):
+            x0, n = b[xx]
+            acc = (row[:, x0:x0 + n, :].astype(np.int64) * k[xx, :n][None, :, None]).sum(1) + (1 << 21)
+            out[:, xx, :] = np.clip(acc >> 22, 0, 255)
+        assert np.array_equal(out, ref), (w_in, w_out)
