@@ -173,6 +173,11 @@ int srgpt_scatter_rows(const void* src, const int* src_idx, const int* idx, void
                        int dtype, srgpt_stream_t stream);
 int srgpt_silu_mul(const void* gu, void* out, int rows, int inter, int dtype, srgpt_stream_t stream);
 int srgpt_argmax(const float* logits, int64_t* ids_out, int B, int V, srgpt_stream_t stream);
+/* Causal-LM loss of LlamaForCausalLM.forward(labels=...) (modeling_llama.py:1047-1058) over already SHIFTED operands:
+ * logits fp32 [rows, V] (positions 0..T-2 of every sequence), labels int64 [rows] (positions 1..T-1); rows whose label is
+ * ignore_index (-100) do not count.  row_loss: scratch [rows] fp32; out[0] = mean loss (nan if no target), out[1] = targets. */
+int srgpt_cross_entropy(const float* logits, const int64_t* labels, float* row_loss, float* out, int rows, int V,
+                        int64_t ignore_index, srgpt_stream_t stream);
 
 
 /* ---------------------------------------------------------------------------------------------

@@ -308,12 +308,78 @@ def mint_tokenizer_kat():
         json.dump(out, f, indent=1)
 
 
+def mint_labels_kat():
+    """Teacher-forced forward with labels (llava_llama.py:100-192 -> LlamaForCausalLM loss): the reference's spliced labels,
+    attention mask / position ids and its loss for a ragged batch of two samples, same tiny fp32 model as tiny_fp32.npz
+    (identical seeds -> identical weights; the fixture stores only inputs and reference outputs)."""
+    print("== labels_kat.npz")
+    dtype = torch.float32
+    with tempfile.TemporaryDirectory() as td:
+        model, tok = rh.build_tiny_reference_model(td, llm=TINY_LLM, vit=TINY_VIT, dtype="torch.float32", seed=0)
+    g = torch.Generator().manual_seed(123)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("norm.weight") or "layernorm" in n or "layer_norm" in n or n.endswith("module.1.weight") \
+                    or n == "mm_projector.layers.1.weight":
+                if n.endswith("weight"):
+                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif n.endswith(".bias"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    cfg = cfg_from(model, tok)
+    w = canonical_state_dict(model)
+    gold = np.load(os.path.join(GOLD, "tiny_fp32.npz"))
+    for k, v in w.items():  # the fixture reuses tiny_fp32.npz's weights: they must be the same model
+        assert np.array_equal(gold["w." + k], tensor_np(v)), k
+    ids, images, depths, masks = so.synth_inputs(cfg, batch=1, regions=2, prompt_len=15, seed=1, dtype=dtype)
+    # ragged batch of 2 (right padded): sample 1 drops the last 4 ids; labels supervise the second half of each prompt
+    P = ids.shape[1]
+    ids_b = torch.cat([ids, ids], 0)
+    am = torch.ones_like(ids_b)
+    am[1, P - 4:] = 0
+    ids_b[1, P - 4:] = 0
+    labels = ids_b.clone()
+    labels[:, :6] = so.IGNORE_INDEX
+    labels[ids_b == so.IMAGE_TOKEN_INDEX] = so.IGNORE_INDEX
+    labels[am == 0] = so.IGNORE_INDEX
+    im2, dp2, mk2 = torch.cat([images, images], 0), torch.cat([depths, depths], 0), [masks[0], masks[0]]
+    with torch.no_grad():
+        (_, pos, am_out, _, embeds, new_labels) = model.prepare_inputs_labels_for_multimodal(
+            ids_b, None, am, None, labels, im2, mk2, dp2)
+        out = model(input_ids=ids_b, images=im2, masks=mk2, depths=dp2, attention_mask=am, labels=labels)
+    loss_ref = float(out.loss)
+    # the restatement
+    image_features, mask_embeds, depth_embeds, _ = so.encode_visual(w, cfg, im2, dp2, mk2)
+    o_emb, o_am, o_pid, o_lab = so.splice(w, cfg, ids_b, am, image_features, mask_embeds, depth_embeds, have_depths=True,
+                                          labels=labels)
+    assert torch.equal(o_lab, new_labels), "spliced labels differ from the reference"
+    assert torch.equal(o_am, am_out) and pos is None  # the reference returns position_ids only when the caller passed them
+    check("inputs_embeds", o_emb, embeds, 1e-5, 1e-5)
+    kv = so.KVCache(cfg.layers)
+    logits = so.llama_forward(w, cfg, o_emb, o_pid, kv, key_padding_mask=o_am.bool())
+    loss_o = float(so.causal_lm_loss(logits, o_lab))
+    print(f"  loss reference {loss_ref:.6f}  oracle {loss_o:.6f}")
+    assert abs(loss_o - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
+    valid = o_am.bool()  # padded query rows are unspecified (nobody reads them): compare the valid positions only
+    check("logits", logits[valid], out.logits.float()[valid], 1e-4, 1e-5)
+    np.savez_compressed(os.path.join(GOLD, "labels_kat.npz"), input_ids=ids_b.numpy(), attention_mask=am.numpy(),
+                        labels=labels.numpy(), new_labels=new_labels.numpy(),
+                        attention_mask_out=am_out.numpy(), loss=np.float64(loss_ref),
+                        logits_valid_last=torch.stack([out.logits.float()[b, int(o_am[b].sum()) - 1] for b in range(2)]).numpy())
+    print("  wrote labels_kat.npz")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "labels":  # only the labels / loss fixture (reuses tiny_fp32.npz's weights)
+        mint_labels_kat()
+        sys.exit(0)
     mint_region_kat()
     mint_tokenizer_kat()
     mint_model_case(torch.float32, "tiny_fp32.npz")
     mint_model_case(torch.bfloat16, "tiny_bf16.npz")
     mint_model_case(torch.float32, "tiny_clip_fp32.npz", tower="clip")
+    mint_labels_kat()
     print("golden vectors written to", GOLD)

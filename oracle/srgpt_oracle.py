@@ -263,9 +263,13 @@ def encode_visual(w, cfg: SrgptConfig, images, depths, masks):
     return image_features, mask_embeds, depth_embeds, st
 
 
-def splice(w, cfg: SrgptConfig, input_ids, attention_mask, image_features, mask_embeds, depth_embeds, have_depths):
-    """llava_arch.py:420-611.  Returns (inputs_embeds [B,T,H], attention_mask or None, position_ids or None)."""
+def splice(w, cfg: SrgptConfig, input_ids, attention_mask, image_features, mask_embeds, depth_embeds, have_depths,
+           labels=None):
+    """llava_arch.py:420-611.  Returns (inputs_embeds [B,T,H], attention_mask or None, position_ids or None); with `labels`
+    ([B,P] int64) a 4th value: the spliced labels [B,T] (IGNORE_INDEX over image rows and padding, llava_arch.py:430-431,
+    :446, :513-533, :558-611)."""
     _attention_mask = attention_mask
+    _labels = labels
     if attention_mask is None:
         attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
     else:
@@ -273,14 +277,19 @@ def splice(w, cfg: SrgptConfig, input_ids, attention_mask, image_features, mask_
     ids0 = input_ids.clone()
     ids0[ids0 == IMAGE_TOKEN_INDEX] = 0
     input_embeds = F.embedding(ids0, w[LM + "model.embed_tokens.weight"])
+    if labels is None:
+        labels = torch.full_like(input_ids, IGNORE_INDEX)
     ids_list = [i[m] for i, m in zip(input_ids, attention_mask)]
     emb_list = [e[m] for e, m in zip(input_embeds, attention_mask)]
+    lab_list = [l[m] for l, m in zip(labels, attention_mask)]
     new_embeds = []
+    new_labels = []
     cur_image_idx = 0
     for b, cur_ids in enumerate(ids_list):
         num_images = int((cur_ids == IMAGE_TOKEN_INDEX).sum())
         if num_images == 0:
             new_embeds.append(torch.cat([emb_list[b], image_features[0][0:0]], dim=0))
+            new_labels.append(lab_list[b])
             continue
         cur = emb_list[b]
         img_idx = [-1] + torch.where(cur_ids == IMAGE_TOKEN_INDEX)[0].tolist() + [cur_ids.shape[0]]
@@ -304,22 +313,27 @@ def splice(w, cfg: SrgptConfig, input_ids, attention_mask, image_features, mask_
                 z = torch.zeros_like(cur)
                 z[pos] = de[:num].to(dtype=z.dtype)
                 cur = cur * (~pos).to(cur.dtype).unsqueeze(-1) + z
-        pieces = []
+        pieces, lab_pieces = [], []
         for i in range(num_images + 1):
             pieces.append(cur[img_idx[i] + 1: img_idx[i + 1]])
+            lab_pieces.append(lab_list[b][img_idx[i] + 1: img_idx[i + 1]])
             if i < num_images:
                 pieces.append(image_features[cur_image_idx])
+                lab_pieces.append(torch.full((image_features[cur_image_idx].shape[0],), IGNORE_INDEX, dtype=labels.dtype))
                 cur_image_idx += 1
         new_embeds.append(torch.cat(pieces))
+        new_labels.append(torch.cat(lab_pieces))
     mx = cfg.tokenizer_model_max_length
     if mx is not None:
         if any(len(x) > mx for x in new_embeds):
             warnings.warn("Inputs truncated!")
         new_embeds = [x[:mx] for x in new_embeds]
+        new_labels = [x[:mx] for x in new_labels]
     max_len = max(x.shape[0] for x in new_embeds)
     B = len(new_embeds)
     am = torch.zeros((B, max_len), dtype=torch.bool)
     pid = torch.zeros((B, max_len), dtype=torch.long)
+    lab = torch.full((B, max_len), IGNORE_INDEX, dtype=labels.dtype)
     padded = []
     for i, e in enumerate(new_embeds):
         n = e.shape[0]
@@ -329,14 +343,26 @@ def splice(w, cfg: SrgptConfig, input_ids, attention_mask, image_features, mask_
             if n > 0:
                 am[i, -n:] = True
                 pid[i, -n:] = torch.arange(n)
+                lab[i, -n:] = new_labels[i]
         else:
             padded.append(torch.cat((e, z), dim=0))
             if n > 0:
                 am[i, :n] = True
                 pid[i, :n] = torch.arange(n)
+                lab[i, :n] = new_labels[i]
     out = torch.stack(padded, dim=0)
     am_out = None if _attention_mask is None else am.to(_attention_mask.dtype)
+    if _labels is not None:
+        return out, am_out, pid, lab
     return out, am_out, pid
+
+
+def causal_lm_loss(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """LlamaForCausalLM loss (modeling_llama.py:1047-1058): logits.float(), shift by one, mean cross entropy over the
+    positions whose label is not IGNORE_INDEX."""
+    shift_logits = logits.float()[..., :-1, :].contiguous()
+    shift_labels = labels[..., 1:].contiguous()
+    return F.cross_entropy(shift_logits.view(-1, shift_logits.shape[-1]), shift_labels.view(-1), ignore_index=IGNORE_INDEX)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -79,6 +79,7 @@ _SIGNATURES = {
     "srgpt_scatter_rows": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "srgpt_silu_mul": (i32, [vp, vp, i32, i32, i32, vp]),
     "srgpt_argmax": (i32, [vp, vp, i32, i32, vp]),
+    "srgpt_cross_entropy": (i32, [vp, vp, vp, vp, i32, i32, i64, vp]),
     "srgpt_image_resize_normalize": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp]),
     "srgpt_mask_resize_nearest": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp]),
     "srgpt_vit_assemble_cls": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

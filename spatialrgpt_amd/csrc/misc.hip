@@ -195,6 +195,65 @@ extern "C" int srgpt_silu_mul(const void* gu, void* out, int rows, int inter, in
   return SRGPT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// causal-LM loss (LlamaForCausalLM.forward with labels, modeling_llama.py:1047-1058): per target row
+// logsumexp(logits) - logits[label], then the mean over the rows whose label is not ignore_index -- two deterministic
+// kernels (row losses, fixed-order sum), no float atomics.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                     float* __restrict__ row_loss, int V, int64_t ignore_index) {
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  const int64_t y = labels[r];
+  if (y == ignore_index || y < 0 || y >= V) {  // uniform per block
+    if (threadIdx.x == 0) row_loss[r] = 0.f;
+    return;
+  }
+  const float* p = logits + (size_t)r * V;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < V; i += 256) mx = fmaxf(mx, p[i]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < V; i += 256) sum += expf(p[i] - mx);
+  sum = block_sum(sum, red + 8);
+  if (threadIdx.x == 0) row_loss[r] = logf(sum) + mx - p[y];
+}
+__global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ labels,
+                                                     float* __restrict__ out, int rows, int V, int64_t ignore_index) {
+  __shared__ float red[16];
+  float s = 0.f, n = 0.f;
+  for (int i = threadIdx.x; i < rows; i += 256) {
+    const int64_t y = labels[i];
+    if (y != ignore_index && y >= 0 && y < V) {
+      s += row_loss[i];
+      n += 1.f;
+    }
+  }
+  s = block_sum(s, red);
+  n = block_sum(n, red + 8);
+  if (threadIdx.x == 0) {
+    out[0] = n > 0.f ? s / n : NAN;  // torch's mean over zero targets is nan
+    out[1] = n;
+  }
+}
+}  // namespace
+
+extern "C" int srgpt_cross_entropy(const float* logits, const int64_t* labels, float* row_loss, float* out, int rows, int V,
+                                   int64_t ignore_index, srgpt_stream_t stream) {
+  SRGPT_CHECK(logits && labels && row_loss && out, SRGPT_ERR_ARG, "srgpt_cross_entropy: null pointer");
+  SRGPT_CHECK(rows > 0 && V > 0, SRGPT_ERR_ARG, "srgpt_cross_entropy: bad shape");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(rows), dim3(256), 0, s, logits, labels, row_loss, V, ignore_index);
+  SRGPT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, s, row_loss, labels, out, rows, V, ignore_index);
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
+
 extern "C" int srgpt_argmax(const float* logits, int64_t* ids_out, int B, int V, srgpt_stream_t stream) {
   SRGPT_CHECK(logits && ids_out && B > 0 && V > 0, SRGPT_ERR_ARG, "srgpt_argmax: bad args");
   hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, as_stream(stream), logits, ids_out, V);

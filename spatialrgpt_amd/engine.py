@@ -20,7 +20,7 @@ import torch
 from . import _lib as L
 from . import ops
 from .config import SrgptConfig
-from .constants import IMAGE_TOKEN_INDEX
+from .constants import IGNORE_INDEX, IMAGE_TOKEN_INDEX
 from .weights import PreparedWeights
 
 
@@ -190,10 +190,12 @@ class SrgptEngine:
         return image_features, mask_embeds, depth_embeds
 
     # ------------------------------------------------------------------ A6
-    def splice(self, input_ids: torch.Tensor, attention_mask, image_features, mask_embeds, depth_embeds, have_depths):
+    def splice(self, input_ids: torch.Tensor, attention_mask, image_features, mask_embeds, depth_embeds, have_depths,
+               labels=None):
         """Token-stream splice (llava_arch.py:420-611).  Index arithmetic on the host from the (tiny) id
         tensor -- ONE device->host copy -- then four row gather/scatter kernels.
-        Returns (inputs_embeds [B,T,H], attention_mask|None, lengths list)."""
+        Returns (inputs_embeds [B,T,H], attention_mask|None, lengths list); with `labels` ([B,P] int64) a 4th value: the
+        spliced labels [B,T] on the device (IGNORE_INDEX over image rows and padding, llava_arch.py:513-533, :558-611)."""
         cfg = self.cfg
         ids_cpu = input_ids.detach().to("cpu")
         B, P = ids_cpu.shape
@@ -214,13 +216,18 @@ class SrgptEngine:
             for e in mask_embeds:
                 mask_off.append(n_me)
                 n_me += 0 if e is None else e.shape[0]
+        lab_cpu = None if labels is None else labels.detach().to("cpu")
+        labs = []  # per sample: label of every output row (IGNORE_INDEX for image rows)
         for b in range(B):
             cur = ids_cpu[b][am_cpu[b]].tolist()
+            cur_lab = [IGNORE_INDEX] * len(cur) if lab_cpu is None else lab_cpu[b][am_cpu[b]].tolist()
             n_images = sum(1 for t in cur if t == IMAGE_TOKEN_INDEX)
             seq = []
             if n_images == 0:
                 seqs.append([("t", t) for t in cur])
+                labs.append(cur_lab)
                 continue
+            lab = []
             first_img = cur_image_idx
             nm = nd = 0
             n_mask_tok = sum(1 for t in cur if t == cfg.mask_token_id)
@@ -235,11 +242,14 @@ class SrgptEngine:
                 raise RuntimeError(f"shape mismatch: {n_mask_tok} <mask> tokens but only {me.shape[0]} mask embeddings")
             if de is not None and n_depth_tok > de.shape[0]:
                 raise RuntimeError(f"shape mismatch: {n_depth_tok} <depth> tokens but only {de.shape[0]} depth embeddings")
-            for t in cur:
+            for t, tl in zip(cur, cur_lab):
                 if t == IMAGE_TOKEN_INDEX:
                     seq.extend(("i", cur_image_idx, r) for r in range(nimg_feat))
+                    lab.extend([IGNORE_INDEX] * nimg_feat)
                     cur_image_idx += 1
-                elif me is not None and t == cfg.mask_token_id:
+                    continue
+                lab.append(tl)
+                if me is not None and t == cfg.mask_token_id:
                     seq.append(("m", mask_off[first_img] + nm))
                     nm += 1
                 elif de is not None and t == cfg.depth_token_id:
@@ -248,11 +258,13 @@ class SrgptEngine:
                 else:
                     seq.append(("t", t))
             seqs.append(seq)
+            labs.append(lab)
         mx = cfg.tokenizer_model_max_length
         if mx is not None:
             if any(len(s) > mx for s in seqs):
                 warnings.warn("Inputs truncated!")
             seqs = [s[:mx] for s in seqs]
+            labs = [l[:mx] for l in labs]
         lens = [len(s) for s in seqs]
         T = max(lens)
         left = cfg.padding_side == "left"
@@ -300,15 +312,24 @@ class SrgptEngine:
                 else:
                     am[b, :n] = True
             am_out = am.to(device=dev, dtype=attention_mask.dtype)
+        if labels is not None:
+            new_labels = torch.full((B, T), IGNORE_INDEX, dtype=torch.int64)
+            for b, l in enumerate(labs):
+                if l:
+                    if left:
+                        new_labels[b, T - len(l):] = torch.tensor(l, dtype=torch.int64)
+                    else:
+                        new_labels[b, :len(l)] = torch.tensor(l, dtype=torch.int64)
+            return out.reshape(B, T, H), am_out, lens, new_labels.to(dev)
         return out.reshape(B, T, H), am_out, lens
 
-    def prepare_inputs(self, input_ids, images, depths=None, masks=None, attention_mask=None, stages=None):
+    def prepare_inputs(self, input_ids, images, depths=None, masks=None, attention_mask=None, stages=None, labels=None):
         image_features, mask_embeds, depth_embeds = self.encode_visual(images, depths, masks, stages)
-        embeds, am, lens = self.splice(input_ids, attention_mask, image_features, mask_embeds, depth_embeds,
-                                       have_depths=depths is not None)
+        res = self.splice(input_ids, attention_mask, image_features, mask_embeds, depth_embeds,
+                          have_depths=depths is not None, labels=labels)
         if stages is not None:
-            stages["inputs_embeds"] = embeds
-        return embeds, am, lens
+            stages["inputs_embeds"] = res[0]
+        return res
 
     def embed_tokens(self, input_ids: torch.Tensor) -> torch.Tensor:
         B, P = input_ids.shape

@@ -13,6 +13,7 @@ from typing import Dict
 import torch
 
 from .config import SrgptConfig
+from .constants import IGNORE_INDEX
 from .engine import SrgptEngine
 
 
@@ -184,7 +185,9 @@ class LlavaLlamaModel:
             return input_ids, position_ids, attention_mask, past_key_values, None, labels
         if getattr(self.config, "turn_mm_projector", False) and self.config.mm_use_im_start_end:
             raise NotImplementedError
-        embeds, am, lens = self.engine.prepare_inputs(input_ids, images, depths, masks, attention_mask)
+        res = self.engine.prepare_inputs(input_ids, images, depths, masks, attention_mask, labels=labels)
+        embeds, am, lens = res[0], res[1], res[2]
+        new_labels = res[3] if labels is not None else None  # llava_arch.py:513-533, :558-611
         pos = None
         if position_ids is not None:
             T = embeds.shape[1]
@@ -194,38 +197,61 @@ class LlavaLlamaModel:
                     pos[b, T - n:] = torch.arange(n, device=embeds.device)
                 else:
                     pos[b, :n] = torch.arange(n, device=embeds.device)
-        new_labels = None
-        if labels is not None:
-            raise NotImplementedError("labels (training) are outside the inference hot path")
         return None, pos, am, past_key_values, embeds, new_labels
 
     # ---- llava_llama.py:100-192 (inference branch) ----
     def forward(self, input_ids=None, images=None, masks=None, depths=None, attention_mask=None, position_ids=None,
                 past_key_values=None, seqlens_in_batch=None, inputs_embeds=None, labels=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, return_dict=None, dpo_forward=False):
-        if labels is not None:
-            raise NotImplementedError("labels / loss are outside the inference hot path")
         if inputs_embeds is None:
             if images is None:
                 inputs_embeds = self.engine.embed_tokens(input_ids)
             else:
-                (_, position_ids, attention_mask, past_key_values, inputs_embeds, _) = \
+                (_, position_ids, attention_mask, past_key_values, inputs_embeds, labels) = \
                     self.prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, past_key_values,
-                                                              None, images, masks, depths)
+                                                              labels, images, masks, depths)
         if attention_mask is None:
             # reference: `attention_mask.sum(-1)` on None -> AttributeError (SURVEY 3.2 gotcha)
             raise AttributeError("'NoneType' object has no attribute 'sum'")
         if past_key_values is not None:
             raise NotImplementedError("incremental forward() with an external cache: use generate()")
-        if not bool(attention_mask.bool().all()):
-            raise NotImplementedError("padded (ragged) batches in forward(): run the rows separately")
-        st, logits, hs = self.engine.prefill(inputs_embeds, max_new=1, all_logits=True,
-                                             hidden_states=bool(output_hidden_states))
-        out = SimpleNamespace(loss=None, logits=logits, past_key_values=st,
+        B, T, _ = inputs_embeds.shape
+        keep = attention_mask.bool()
+        ragged = not bool(keep.all())
+        if ragged:
+            # padded batch: valid positions packed to the front for the ragged prefill (causal attention never looks right),
+            # logits scattered back to the caller's padded layout; padded positions are zeros (unspecified in the reference)
+            lens = keep.sum(dim=1)
+            packed = torch.zeros_like(inputs_embeds)
+            for b in range(B):
+                packed[b, :int(lens[b])] = inputs_embeds[b][keep[b]]
+            st, plog, hs = self.engine.prefill(packed, max_new=1, all_logits=True, hidden_states=bool(output_hidden_states),
+                                               lens=lens)
+            logits = torch.zeros_like(plog)
+            for b in range(B):
+                logits[b][keep[b]] = plog[b, :int(lens[b])]
+            if hs is not None:
+                uh = torch.zeros_like(hs)
+                for b in range(B):
+                    uh[:, b][:, keep[b]] = hs[:, b, :int(lens[b])]
+                hs = uh
+        else:
+            st, logits, hs = self.engine.prefill(inputs_embeds, max_new=1, all_logits=True,
+                                                 hidden_states=bool(output_hidden_states))
+        loss = None
+        if labels is not None:
+            # LlamaForCausalLM (modeling_llama.py:1047-1058): shift by one, mean CE over labels != IGNORE_INDEX
+            from . import ops
+
+            lab = labels.to(device=logits.device, dtype=torch.int64)
+            shift_logits = logits[:, :-1, :].reshape(-1, logits.shape[-1])
+            shift_labels = lab[:, 1:].reshape(-1)
+            loss, _ = ops.cross_entropy(shift_logits, shift_labels, IGNORE_INDEX)
+        out = SimpleNamespace(loss=loss, logits=logits, past_key_values=st,
                               hidden_states=None if hs is None else tuple(hs[i] for i in range(hs.shape[0])),
                               attentions=None)
         if dpo_forward:
-            return out.logits, None
+            return out.logits, labels
         return out
 
     __call__ = forward

@@ -253,3 +253,17 @@ def argmax(logits):
     out = torch.empty((B,), device=logits.device, dtype=torch.int64)
     L.check(L.load().srgpt_argmax(_p(logits), _p(out), B, V, _stream()))
     return out
+
+
+def cross_entropy(shift_logits: torch.Tensor, shift_labels: torch.Tensor, ignore_index: int = -100):
+    """mean cross entropy over the rows whose label is not `ignore_index`: shift_logits fp32 [rows, V] (already shifted),
+    shift_labels int64 [rows].  Returns (loss 0-d fp32 tensor, number of targets 0-d tensor)."""
+    _dev(shift_logits, shift_labels)
+    if shift_logits.dtype != torch.float32 or shift_labels.dtype != torch.int64:
+        raise ValueError("cross_entropy: logits must be fp32 and labels int64")
+    rows, V = shift_logits.shape
+    row_loss = torch.empty((rows,), device=shift_logits.device, dtype=torch.float32)
+    out = torch.empty((2,), device=shift_logits.device, dtype=torch.float32)
+    L.check(L.load().srgpt_cross_entropy(_p(_c(shift_logits)), _p(_c(shift_labels)), _p(row_loss), _p(out), rows, V,
+                                         int(ignore_index), _stream()))
+    return out[0], out[1]

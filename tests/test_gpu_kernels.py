@@ -363,3 +363,21 @@ def test_embed_scatter_silu_argmax(dtype):
     logits[1, 77] = logits[1, 90000] = 50.0  # tie -> first index wins, like torch.argmax
     logits[2, 128257] = 60.0
     assert torch.equal(ops.argmax(logits.to(DEV)).cpu(), torch.tensor([int(logits[0].argmax()), 77, 128257]))
+
+
+@pytest.mark.parametrize("rows,V", [(7, 128), (33, 1000), (5, 128258), (1, 17)])
+def test_cross_entropy_vs_torch(rows, V):
+    """srgpt_cross_entropy == F.cross_entropy(mean over labels != -100) in fp32, including rows that are ignored."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(31)
+    logits = torch.randn((rows, V), generator=g) * 3
+    labels = torch.randint(0, V, (rows,), generator=g)
+    if rows > 2:
+        labels[1] = -100
+        labels[rows - 1] = -100
+    ref = F.cross_entropy(logits, labels, ignore_index=-100)
+    loss, n = ops.cross_entropy(logits.to(DEV), labels.to(DEV))
+    assert int(n) == int((labels != -100).sum())
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    loss0, n0 = ops.cross_entropy(logits.to(DEV), torch.full((rows,), -100, dtype=torch.int64, device=DEV))
+    assert int(n0) == 0 and bool(torch.isnan(loss0))  # torch: mean over zero targets is nan

@@ -296,3 +296,33 @@ def test_ragged_prefill_and_batched_decode_equal_single_rows(dtype):
             while same <= G and int(ids[b, same]) == int(ids1[0, same]):
                 same += 1
             assert_close(lg[b, :max(1, same)], lg1[0, :max(1, same)], tol, 0, f"row {b} logits, ragged batch vs alone")
+
+
+def test_forward_with_labels_matches_reference_loss():
+    """llava_llama.py:100-192 with labels on a ragged batch of two: spliced labels / attention mask identical to the
+    reference's (tests/golden/labels_kat.npz, minted from the real reference), loss within 2e-5, last valid logits 2e-4."""
+    import os
+
+    import numpy as np
+
+    from tests.util import GOLD
+
+    model, cfg, dtype, w, inp, ref = _engine("tiny_fp32.npz")
+    z = np.load(os.path.join(GOLD, "labels_kat.npz"))
+    ids, am, labels = (torch.from_numpy(z[k]).to(DEV) for k in ("input_ids", "attention_mask", "labels"))
+    d = _to_dev(inp)
+    im2, dp2 = torch.cat([d["images"]] * 2, 0), torch.cat([d["depths"]] * 2, 0)
+    mk2 = [d["masks"][0], d["masks"][0]]
+    (_, pos, am_out, _, emb, new_labels) = model.prepare_inputs_labels_for_multimodal(ids, None, am, None, labels, im2, mk2, dp2)
+    assert pos is None  # the reference returns position_ids only when the caller passed them (llava_arch.py:627-628)
+    assert torch.equal(new_labels.cpu(), torch.from_numpy(z["new_labels"]))
+    assert torch.equal(am_out.cpu(), torch.from_numpy(z["attention_mask_out"]))
+    out = model(input_ids=ids, images=im2, masks=mk2, depths=dp2, attention_mask=am, labels=labels)
+    assert abs(float(out.loss) - float(z["loss"])) <= 2e-5 * max(1.0, abs(float(z["loss"])))
+    lens = am_out.sum(1)
+    last = torch.stack([out.logits[b, int(lens[b]) - 1] for b in range(2)])
+    assert_close(last, torch.from_numpy(z["logits_valid_last"]), 2e-4 * float(last.abs().max()), 0, "last valid logits")
+    # the same rows alone give the same logits (ragged prefill == single rows)
+    one = model(input_ids=ids[1:2, :int(am[1].sum())], images=im2[:1], masks=mk2[:1], depths=dp2[:1],
+                attention_mask=am[1:2, :int(am[1].sum())])
+    assert_close(out.logits[1, :int(lens[1])], one.logits[0], 2e-4 * float(last.abs().max()), 0, "row 1 alone")

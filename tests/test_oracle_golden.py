@@ -100,3 +100,28 @@ def test_oracle_fp8_weight_quantisation_properties():
         sc = torch.ldexp(torch.ones(a.shape[0]), torch.ceil(torch.log2(b.abs().amax(dim=1).double() / 448.0)).to(torch.int32))
         r = b.abs().amax(dim=1) / sc
         assert bool(((r > 223.9) & (r <= 448.0)).all())
+
+
+def test_oracle_labels_and_loss_match_reference():
+    """teacher-forced forward with labels (llava_llama.py:100-192): the oracle's spliced labels / attention mask equal the
+    reference's (tests/golden/labels_kat.npz, minted from the real reference) and its causal-LM loss matches to 2e-5."""
+    import os
+
+    from tests.util import GOLD
+
+    cfgd, dtype, w, inp, ref = load_tiny("tiny_fp32.npz")
+    cfg = _cfg(cfgd)
+    z = np.load(os.path.join(GOLD, "labels_kat.npz"))
+    ids, am, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
+    im2, dp2 = torch.cat([inp["images"]] * 2, 0), torch.cat([inp["depths"]] * 2, 0)
+    mk2 = [inp["masks"][0], inp["masks"][0]]
+    image_features, mask_embeds, depth_embeds, _ = so.encode_visual(w, cfg, im2, dp2, mk2)
+    emb, am_out, pid, new_labels = so.splice(w, cfg, ids, am, image_features, mask_embeds, depth_embeds, have_depths=True,
+                                             labels=labels)
+    assert torch.equal(new_labels, torch.from_numpy(z["new_labels"]))
+    assert torch.equal(am_out, torch.from_numpy(z["attention_mask_out"]))
+    logits = so.llama_forward(w, cfg, emb, pid, so.KVCache(cfg.layers), key_padding_mask=am_out.bool())
+    loss = float(so.causal_lm_loss(logits, new_labels))
+    assert abs(loss - float(z["loss"])) <= 2e-5 * max(1.0, abs(float(z["loss"])))
+    last = torch.stack([logits[b, int(am_out[b].sum()) - 1] for b in range(2)])
+    assert_close(last, torch.from_numpy(z["logits_valid_last"]), 1e-4, 0, "last valid logits")
