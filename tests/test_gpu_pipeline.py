@@ -326,3 +326,11 @@ def test_forward_with_labels_matches_reference_loss():
     one = model(input_ids=ids[1:2, :int(am[1].sum())], images=im2[:1], masks=mk2[:1], depths=dp2[:1],
                 attention_mask=am[1:2, :int(am[1].sum())])
     assert_close(out.logits[1, :int(lens[1])], one.logits[0], 2e-4 * float(last.abs().max()), 0, "row 1 alone")
+    # hidden states of a padded batch come back in the caller's padded layout (zeros at the padding)
+    outh = model(input_ids=ids, images=im2, masks=mk2, depths=dp2, attention_mask=am, output_hidden_states=True)
+    oneh = model(input_ids=ids[1:2, :int(am[1].sum())], images=im2[:1], masks=mk2[:1], depths=dp2[:1],
+                 attention_mask=am[1:2, :int(am[1].sum())], output_hidden_states=True)
+    assert len(outh.hidden_states) == len(oneh.hidden_states) == cfg.layers + 1
+    hl, h1 = outh.hidden_states[-1], oneh.hidden_states[-1]
+    assert_close(hl[1, :int(lens[1])], h1[0], 2e-4 * float(h1.abs().max()), 0, "last hidden state of row 1")
+    assert float(hl[1, int(lens[1]):].abs().max()) == 0.0
