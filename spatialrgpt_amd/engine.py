@@ -49,8 +49,13 @@ class DecodeState:
         st.pos, st.tok, st.out_ids, st.step = self.pos.data_ptr(), self.tok.data_ptr(), self.out_ids.data_ptr(), self.step.data_ptr()
         st.ws, st.logits = self.ws.data_ptr(), self.logits.data_ptr()
         self.c = st
+        self.host_len = [0] * batch  # cached positions per row as known on the host (prefill lengths + steps taken)
         self.graph = None
         self._eng = eng
+
+    def seq_len(self) -> int:
+        """cached positions (longest row) -- what `past_key_values[-1][-1].shape[-2]` is for the reference (llava_arch.py:364)."""
+        return max(self.host_len)
 
     def ensure_graph(self):
         if self.graph is None:
@@ -368,7 +373,20 @@ class SrgptEngine:
             L.check(L.load().srgpt_llm_prefill_ragged(C.byref(self.w.llm), C.byref(st.c), x.data_ptr(), T, ld.data_ptr(),
                                                       None if al is None else al.data_ptr(),
                                                       None if hs is None else hs.data_ptr(), ops._stream()))
+        st.host_len = [T] * B if lens is None else [int(v) for v in lens.tolist()]
         return st, al, hs
+
+    def step(self, st: DecodeState, input_ids: torch.Tensor) -> torch.Tensor:
+        """One incremental forward over a cached state (HF `forward(input_ids[B,1], past_key_values=...)`): appends the
+        tokens at every row's next position and returns the fp32 logits [B, vocab]."""
+        if input_ids.shape != (st.batch, 1):
+            raise ValueError(f"step: input_ids must be [{st.batch}, 1]")
+        if max(st.host_len) >= st.max_pos:
+            raise ValueError(f"KV cache full ({st.max_pos} positions): re-run forward() with a larger cache_reserve")
+        st.tok.copy_(input_ids[:, 0].to(device=self.device, dtype=torch.int64))
+        L.check(L.load().srgpt_llm_decode_step(C.byref(self.w.llm), C.byref(st.c), ops._stream()))
+        st.host_len = [n + 1 for n in st.host_len]
+        return st.logits.clone()
 
     def greedy_decode(self, st: DecodeState, max_new_tokens: int, eos_token_id=None, pad_token_id=None,
                       stopping_criteria=None, check_every: int = 8) -> torch.Tensor:

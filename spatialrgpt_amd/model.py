@@ -117,6 +117,7 @@ class LlavaLlamaModel:
         self.llm = _Llm(self)
         self.is_loaded = True
         self.training = False
+        self.cache_reserve = 128  # forward(use_cache=True): cache positions reserved beyond the prompt
 
     # ---- nn.Module / PreTrainedModel look-alikes used by the reference's callers ----
     @property
@@ -203,6 +204,15 @@ class LlavaLlamaModel:
     def forward(self, input_ids=None, images=None, masks=None, depths=None, attention_mask=None, position_ids=None,
                 past_key_values=None, seqlens_in_batch=None, inputs_embeds=None, labels=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, return_dict=None, dpo_forward=False):
+        if past_key_values is not None:
+            # incremental step over the state a previous forward(use_cache=True) returned (what HF's generate loop does with
+            # the reference model: llava_arch.py:355-385 early-out, then the LLM with a cache)
+            if input_ids is None or input_ids.shape[1] != 1 or labels is not None:
+                raise NotImplementedError("forward() with past_key_values takes input_ids [B, 1] and no labels")
+            logits = self.engine.step(past_key_values, input_ids)
+            out = SimpleNamespace(loss=None, logits=logits[:, None, :], past_key_values=past_key_values, hidden_states=None,
+                                  attentions=None)
+            return (out.logits, None) if dpo_forward else out
         if inputs_embeds is None:
             if images is None:
                 inputs_embeds = self.engine.embed_tokens(input_ids)
@@ -213,8 +223,7 @@ class LlavaLlamaModel:
         if attention_mask is None:
             # reference: `attention_mask.sum(-1)` on None -> AttributeError (SURVEY 3.2 gotcha)
             raise AttributeError("'NoneType' object has no attribute 'sum'")
-        if past_key_values is not None:
-            raise NotImplementedError("incremental forward() with an external cache: use generate()")
+        reserve = self.cache_reserve if use_cache else 1  # positions kept free after the prompt for incremental steps
         B, T, _ = inputs_embeds.shape
         keep = attention_mask.bool()
         ragged = not bool(keep.all())
@@ -225,8 +234,8 @@ class LlavaLlamaModel:
             packed = torch.zeros_like(inputs_embeds)
             for b in range(B):
                 packed[b, :int(lens[b])] = inputs_embeds[b][keep[b]]
-            st, plog, hs = self.engine.prefill(packed, max_new=1, all_logits=True, hidden_states=bool(output_hidden_states),
-                                               lens=lens)
+            st, plog, hs = self.engine.prefill(packed, max_new=reserve, all_logits=True,
+                                               hidden_states=bool(output_hidden_states), lens=lens)
             logits = torch.zeros_like(plog)
             for b in range(B):
                 logits[b][keep[b]] = plog[b, :int(lens[b])]
@@ -236,7 +245,7 @@ class LlavaLlamaModel:
                     uh[:, b][:, keep[b]] = hs[:, b, :int(lens[b])]
                 hs = uh
         else:
-            st, logits, hs = self.engine.prefill(inputs_embeds, max_new=1, all_logits=True,
+            st, logits, hs = self.engine.prefill(inputs_embeds, max_new=reserve, all_logits=True,
                                                  hidden_states=bool(output_hidden_states))
         loss = None
         if labels is not None:

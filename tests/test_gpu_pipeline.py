@@ -334,3 +334,29 @@ def test_forward_with_labels_matches_reference_loss():
     hl, h1 = outh.hidden_states[-1], oneh.hidden_states[-1]
     assert_close(hl[1, :int(lens[1])], h1[0], 2e-4 * float(h1.abs().max()), 0, "last hidden state of row 1")
     assert float(hl[1, int(lens[1]):].abs().max()) == 0.0
+
+
+def test_incremental_forward_with_cached_state_equals_generate():
+    """HF-style loop over the reference surface: forward(use_cache=True) -> past_key_values, then forward(input_ids [B,1],
+    past_key_values=...) step by step (llava_arch.py:355-385 early-out + cached LLM step): the argmax chain equals
+    generate()'s greedy ids bit for bit (fp32), and the state reports its length like the reference's cache does."""
+    model, cfg, dtype, w, inp, ref = _engine("tiny_fp32.npz")
+    d = _to_dev(inp)
+    n = 6
+    want = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], do_sample=False,
+                          max_new_tokens=n, eos_token_id=None)
+    am = torch.ones_like(d["input_ids"])
+    out = model(input_ids=d["input_ids"], images=d["images"], masks=d["masks"], depths=d["depths"], attention_mask=am,
+                use_cache=True)
+    st = out.past_key_values
+    T = out.logits.shape[1]
+    assert st.seq_len() == T
+    got = [out.logits[:, -1].argmax(-1)]
+    for i in range(n - 1):
+        step = model(input_ids=got[-1][:, None], past_key_values=st, attention_mask=torch.ones((1, T + i + 1), device=DEV))
+        assert step.logits.shape == (1, 1, model.config.vocab if hasattr(model.config, "vocab") else step.logits.shape[-1])
+        got.append(step.logits[:, 0].argmax(-1))
+        assert st.seq_len() == T + i + 1
+    assert torch.equal(torch.stack(got, 1), want)
+    with pytest.raises(NotImplementedError):
+        model(input_ids=d["input_ids"], past_key_values=st, attention_mask=am)  # only single-token steps over a cache
