@@ -370,9 +370,44 @@ def mint_labels_kat():
     print("  wrote labels_kat.npz")
 
 
+def mint_posembed_kat():
+    """vision_resolution elevation: run the reference's OWN `VisionTower._maybe_resize_pos_embeds`
+    (llava/model/multimodal_encoder/vision_encoder.py:36-113, interpolate_mode "linear") on stand-in objects that carry exactly
+    the attributes the method touches (the transformers-5 SiglipVisionModel has no `.vision_model`), and store
+    old/new position tables for an up-sizing (27^2 -> 32^2 tokens) and a down-sizing (27^2 -> 24^2 = the 336-px case)."""
+    from types import SimpleNamespace
+
+    rh.install_shims()
+    from llava.model.multimodal_encoder.vision_encoder import VisionTower
+
+    blob = {}
+    g = torch.Generator().manual_seed(11)
+    for tag, old_res, new_res, patch in (("up", 378, 448, 14), ("down", 384, 336, 14)):
+        n_old = (old_res // patch) ** 2
+        emb = torch.nn.Embedding(n_old, 48)
+        emb.weight.data = torch.randn((n_old, 48), generator=g)
+        old = emb.weight.data.clone()
+        embeddings = SimpleNamespace(patch_size=patch, position_embedding=emb, image_size=old_res, num_patches=n_old,
+                                     num_positions=n_old, position_ids=None)
+        model = SimpleNamespace(config=SimpleNamespace(image_size=old_res), vision_model=SimpleNamespace(embeddings=embeddings))
+        proc = SimpleNamespace(size={"height": old_res, "width": old_res})
+        tower = VisionTower.__new__(VisionTower)
+        VisionTower._maybe_resize_pos_embeds(tower, model, proc, resolution=new_res, interpolate_mode="linear")
+        new = embeddings.position_embedding.weight.data
+        assert new.shape == ((new_res // patch) ** 2, 48) and model.config.image_size == new_res
+        assert proc.size == {"height": new_res, "width": new_res}
+        blob[f"{tag}_old"], blob[f"{tag}_new"] = old.numpy(), new.numpy()
+        print(f"  posembed {tag}: {n_old} -> {new.shape[0]} rows")
+    np.savez_compressed(os.path.join(GOLD, "posembed_kat.npz"), **blob)
+    print("  wrote posembed_kat.npz")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "posembed":
+        mint_posembed_kat()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "labels":  # only the labels / loss fixture (reuses tiny_fp32.npz's weights)
         mint_labels_kat()
         sys.exit(0)
@@ -382,4 +417,5 @@ if __name__ == "__main__":
     mint_model_case(torch.bfloat16, "tiny_bf16.npz")
     mint_model_case(torch.float32, "tiny_clip_fp32.npz", tower="clip")
     mint_labels_kat()
+    mint_posembed_kat()
     print("golden vectors written to", GOLD)

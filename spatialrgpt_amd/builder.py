@@ -84,6 +84,137 @@ def config_from_checkpoint(model_path: str) -> SrgptConfig:
     )
 
 
+def resize_position_embeddings(pos_emb: torch.Tensor, num_new_tokens: int) -> torch.Tensor:
+    """`VisionTower._maybe_resize_pos_embeds`, interpolate_mode "linear" (multimodal_encoder/vision_encoder.py:36-113): the
+    learned position table [M, C] is resampled to N = (resolution // patch)^2 rows along the FLATTENED token index --
+    pid = i / (N - 1) * (M - 1), new[i] = (pid - floor) * old[ceil] + (ceil - pid) * old[floor] (so rows that land exactly
+    on an old index get weight 0 on both sides, exactly like the reference).  Load-time layout work, done once on the host."""
+    M = pos_emb.shape[0]
+    if num_new_tokens == M:
+        return pos_emb
+    mapped = torch.arange(num_new_tokens) / (num_new_tokens - 1) * (M - 1)
+    fl = torch.clamp(mapped.floor().long(), min=0, max=M - 1)
+    ce = torch.clamp(mapped.ceil().long(), min=0, max=M - 1)
+    w = pos_emb.detach().cpu()
+    return (mapped - fl)[:, None] * w[ce, :] + (ce - mapped)[:, None] * w[fl, :]
+
+
+def read_checkpoint(model_path: str, vision_resolution: int = -1, interpolate_mode: str = "linear"):
+    """-> (SrgptConfig, state dict with the reference's key names on the host)."""
+    cfg = config_from_checkpoint(model_path)
+    sd = {}
+    _load_dir(os.path.join(model_path, "llm"), "llm.", sd)
+    _load_dir(os.path.join(model_path, "vision_tower"), "vision_tower.vision_tower.", sd)
+    _load_dir(os.path.join(model_path, "mm_projector"), "mm_projector.", sd)
+    if cfg.enable_region:
+        _load_dir(os.path.join(model_path, "region_extractor"), "region_extractor.", sd)
+    if vision_resolution not in (-1, None, cfg.image_size):
+        # vision_resolution elevation (llava/train/utils.py:126-134 -> vision_encoder.py:36-113) applied at load: the only way
+        # a SigLIP-384 checkpoint serves 336-px inputs (24 x 24 = 576 tokens)
+        if interpolate_mode != "linear":
+            raise NotImplementedError(interpolate_mode)  # vision_encoder.py:97-98
+        if cfg.tower == "clip":
+            raise NotImplementedError("position-embedding resize of a class-token tower is not defined by the reference formula")
+        key = "vision_tower.vision_tower.vision_model.embeddings.position_embedding.weight"
+        n_new = int((vision_resolution // cfg.patch_size) ** 2)
+        print(f"Resizing vision model's position embeddings to support higher vision resolution: from {cfg.image_size} "
+              f"to {vision_resolution} ...")
+        sd[key] = resize_position_embeddings(sd[key], n_new).to(sd[key].dtype)
+        cfg.image_size = int(vision_resolution)
+    return cfg, sd
+
+
+def load_tokenizer(model_path: str, cfg: SrgptConfig, sd=None):
+    """Tokenizer side effects of the loader (llava/model/builder.py:186-199): add <mask>/<depth> (and the optional
+    <im_patch>/<im_start>/<im_end>) as special tokens, record their ids, grow the embedding / lm_head tables to
+    len(tokenizer) (new rows = mean of the old ones, what `resize_token_embeddings` initialises them to)."""
+    from transformers import AutoTokenizer
+
+    try:
+        tokenizer = AutoTokenizer.from_pretrained(os.path.join(model_path, "llm"), use_fast=False, legacy=False)
+    except Exception as e:  # tokenizer problems must not hide the model; callers that need it fail on use
+        import warnings
+
+        warnings.warn(f"could not load tokenizer from {model_path}/llm: {e}")
+        return None
+    if cfg.enable_region:
+        tokenizer.add_tokens([DEFAULT_MASK_TOKEN, DEFAULT_DEPTH_TOKEN], special_tokens=True)
+        cfg.mask_token_id = tokenizer.convert_tokens_to_ids(DEFAULT_MASK_TOKEN)
+        cfg.depth_token_id = tokenizer.convert_tokens_to_ids(DEFAULT_DEPTH_TOKEN)
+    if cfg.mm_use_im_patch_token:
+        tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
+    if cfg.mm_use_im_start_end:
+        tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
+    if sd is not None:
+        n_tok, emb = len(tokenizer), sd["llm.model.embed_tokens.weight"]
+        if n_tok > emb.shape[0]:
+            extra = n_tok - emb.shape[0]
+            sd["llm.model.embed_tokens.weight"] = torch.cat([emb, emb.float().mean(0, keepdim=True).to(emb.dtype).expand(extra, -1)], 0)
+            head = sd["llm.lm_head.weight"]
+            sd["llm.lm_head.weight"] = torch.cat([head, head.float().mean(0, keepdim=True).to(head.dtype).expand(extra, -1)], 0)
+        cfg.vocab = sd["llm.model.embed_tokens.weight"].shape[0]
+    if cfg.eos_token_id is None:
+        cfg.eos_token_id = tokenizer.eos_token_id
+    if cfg.pad_token_id is None:
+        cfg.pad_token_id = tokenizer.pad_token_id
+    return tokenizer
+
+
+def load_image_processor(model_path: str, cfg: SrgptConfig):
+    """SiglipImageProcessor for SigLIP towers (siglip_encoder.py:10), CLIPImageProcessor for CLIP towers (clip_encoder.py:11);
+    the built-in processor of the same semantics when transformers cannot build its own (no torchvision in this image)."""
+    vt = os.path.join(model_path, "vision_tower")
+    pp = os.path.join(vt, "preprocessor_config.json")
+    try:
+        if cfg.tower == "clip":
+            from transformers import CLIPImageProcessor as Proc
+        else:
+            from transformers import SiglipImageProcessor as Proc
+        proc = Proc.from_pretrained(vt)
+    except Exception:
+        j = _read_json(pp) if os.path.exists(pp) else {}
+        size = j.get("size", {})
+        if cfg.tower == "clip":
+            crop = j.get("crop_size", {"height": cfg.image_size, "width": cfg.image_size})
+            crop = crop if isinstance(crop, dict) else {"height": crop, "width": crop}
+            proc = SrgptImageProcessor(size=crop["height"], image_mean=j.get("image_mean", (0.48145466, 0.4578275, 0.40821073)),
+                                       image_std=j.get("image_std", (0.26862954, 0.26130258, 0.27577711)),
+                                       shortest_edge=(size.get("shortest_edge") if isinstance(size, dict) else size) or crop["height"],
+                                       center_crop=True)
+        else:
+            proc = SrgptImageProcessor(size=size.get("height", cfg.image_size) if isinstance(size, dict) else (size or cfg.image_size),
+                                       image_mean=j.get("image_mean", (0.5, 0.5, 0.5)), image_std=j.get("image_std", (0.5, 0.5, 0.5)))
+    # a vision_resolution-elevated tower: the processor follows (vision_encoder.py:103-109)
+    def _get(d, k):
+        try:
+            return d[k]
+        except (KeyError, TypeError, AttributeError):
+            return getattr(d, k, None)
+
+    if getattr(proc, "crop_size", None) is not None:  # CLIP
+        if _get(proc.crop_size, "height") != cfg.image_size:
+            proc.crop_size = {"height": cfg.image_size, "width": cfg.image_size}
+            if _get(getattr(proc, "size", None), "shortest_edge") is not None:
+                proc.size = {"shortest_edge": cfg.image_size}
+    elif getattr(proc, "size", None) is not None and _get(proc.size, "height") != cfg.image_size:  # SigLIP
+        proc.size = {"height": cfg.image_size, "width": cfg.image_size}
+    return proc
+
+
+def load_model(model_path, device="cuda", dtype=torch.bfloat16, llm_weight_format="native", vision_resolution=-1,
+               interpolate_mode="linear"):
+    """-> (tokenizer, LlavaLlamaModel, image_processor): everything `load_pretrained_model` and the HF-registry entry points
+    (`AutoModel.from_pretrained`, `LlavaLlamaModel(config=...)`) share."""
+    from .model import LlavaLlamaModel
+
+    cfg, sd = read_checkpoint(model_path, vision_resolution, interpolate_mode)
+    tokenizer = load_tokenizer(model_path, cfg, sd)
+    image_processor = load_image_processor(model_path, cfg)
+    model = LlavaLlamaModel(cfg, sd, device=device, dtype=dtype, tokenizer=tokenizer, image_processor=image_processor,
+                            consume_state_dict=True, llm_weight_format=llm_weight_format)
+    return tokenizer, model, image_processor
+
+
 def load_pretrained_model(model_path, model_name, model_base=None, load_8bit=False, load_4bit=False, device_map="auto",
                           device="cuda", dtype=torch.bfloat16, **kwargs):
     if load_4bit:
@@ -93,64 +224,9 @@ def load_pretrained_model(model_path, model_name, model_base=None, load_8bit=Fal
     llm_weight_format = "fp8" if load_8bit else kwargs.pop("llm_weight_format", "native")
     if model_base is not None or "lora" in model_name.lower():
         raise NotImplementedError("LoRA / delta checkpoints are out of scope (builder.py:64-139)")
-    from .model import LlavaLlamaModel
-
-    cfg = config_from_checkpoint(model_path)
-    sd = {}
-    _load_dir(os.path.join(model_path, "llm"), "llm.", sd)
-    _load_dir(os.path.join(model_path, "vision_tower"), "vision_tower.vision_tower.", sd)
-    _load_dir(os.path.join(model_path, "mm_projector"), "mm_projector.", sd)
-    if cfg.enable_region:
-        _load_dir(os.path.join(model_path, "region_extractor"), "region_extractor.", sd)
-
-    tokenizer = None
-    try:
-        from transformers import AutoTokenizer
-
-        tokenizer = AutoTokenizer.from_pretrained(os.path.join(model_path, "llm"), use_fast=False, legacy=False)
-    except Exception as e:  # tokenizer problems must not hide the model; callers that need it fail on use
-        import warnings
-
-        warnings.warn(f"could not load tokenizer from {model_path}/llm: {e}")
-    if tokenizer is not None:
-        if cfg.enable_region:  # builder.py:186-192
-            tokenizer.add_tokens([DEFAULT_MASK_TOKEN, DEFAULT_DEPTH_TOKEN], special_tokens=True)
-            cfg.mask_token_id = tokenizer.convert_tokens_to_ids(DEFAULT_MASK_TOKEN)
-            cfg.depth_token_id = tokenizer.convert_tokens_to_ids(DEFAULT_DEPTH_TOKEN)
-        if cfg.mm_use_im_patch_token:
-            tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
-        if cfg.mm_use_im_start_end:
-            tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
-        # resize_token_embeddings(len(tokenizer)) (builder.py:199): append rows initialised to the mean embedding
-        n_tok, emb = len(tokenizer), sd["llm.model.embed_tokens.weight"]
-        if n_tok > emb.shape[0]:
-            extra = n_tok - emb.shape[0]
-            sd["llm.model.embed_tokens.weight"] = torch.cat([emb, emb.float().mean(0, keepdim=True).to(emb.dtype).expand(extra, -1)], 0)
-            head = sd["llm.lm_head.weight"]
-            sd["llm.lm_head.weight"] = torch.cat([head, head.float().mean(0, keepdim=True).to(head.dtype).expand(extra, -1)], 0)
-        cfg.vocab = sd["llm.model.embed_tokens.weight"].shape[0]
-        if cfg.eos_token_id is None:
-            cfg.eos_token_id = tokenizer.eos_token_id
-        if cfg.pad_token_id is None:
-            cfg.pad_token_id = tokenizer.pad_token_id
-
-    image_processor = None
-    pp = os.path.join(model_path, "vision_tower", "preprocessor_config.json")
-    try:
-        from transformers import SiglipImageProcessor
-
-        image_processor = SiglipImageProcessor.from_pretrained(os.path.join(model_path, "vision_tower"))
-    except Exception:
-        if os.path.exists(pp):
-            j = _read_json(pp)
-            image_processor = SrgptImageProcessor(size=j.get("size", {}).get("height", cfg.image_size),
-                                                  image_mean=j.get("image_mean", (0.5, 0.5, 0.5)),
-                                                  image_std=j.get("image_std", (0.5, 0.5, 0.5)))
-        else:
-            image_processor = SrgptImageProcessor(size=cfg.image_size)
-
-    model = LlavaLlamaModel(cfg, sd, device=device, dtype=dtype, tokenizer=tokenizer, image_processor=image_processor,
-                            consume_state_dict=True, llm_weight_format=llm_weight_format)
+    tokenizer, model, image_processor = load_model(model_path, device=device, dtype=dtype, llm_weight_format=llm_weight_format,
+                                                   vision_resolution=kwargs.pop("vision_resolution", -1),
+                                                   interpolate_mode=kwargs.pop("interpolate_mode", "linear"))
     lc = _read_json(os.path.join(model_path, "llm", "config.json"))
     context_len = _read_json(os.path.join(model_path, "config.json")).get("max_sequence_length", 2048) \
         if "max_sequence_length" in lc else 2048  # builder.py:207-211

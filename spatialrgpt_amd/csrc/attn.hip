@@ -244,7 +244,7 @@ constexpr int DEC_CHUNK_MAX = 256;
 constexpr int DEC_SPLIT_MAX = 64;
 
 static inline int decode_nsplit(int max_pos) {
-  static const int env_min = getenv("SRGPT_DECODE_MIN_SPLITS") ? atoi(getenv("SRGPT_DECODE_MIN_SPLITS")) : 16;  // tuning knob
+  const int env_min = SRGPT_KNOB("SRGPT_DECODE_MIN_SPLITS", 16);  // tuning knob
   int n = cdiv(max_pos, DEC_CHUNK_MAX);
   if (n < env_min) n = env_min;
   if (n > DEC_SPLIT_MAX) n = DEC_SPLIT_MAX;
@@ -523,7 +523,9 @@ int launch_decode(const void* qkv, void* kc, void* vc, const int* pos, const voi
                   float* ws, int B, int Hq, int Hkv, int D, int max_pos, hipStream_t s) {
   const int G = Hq / Hkv;
   const int nsplit = decode_nsplit(max_pos);
-  SRGPT_CHECK(nsplit <= DEC_SPLIT_MAX, SRGPT_ERR_UNSUPPORTED, "srgpt_decode_attention: max_pos %d too large", max_pos);
+  // a split's scores live in LDS (sc[G][DEC_CHUNK_MAX]): the longest chunk is ceil(max_pos / nsplit) keys
+  SRGPT_CHECK(cdiv(max_pos, nsplit) <= DEC_CHUNK_MAX, SRGPT_ERR_UNSUPPORTED,
+              "srgpt_decode_attention: max_pos %d exceeds %d cached positions", max_pos, DEC_SPLIT_MAX * DEC_CHUNK_MAX);
   const float scale = 1.0f / sqrtf((float)D);
   int rc;
   switch (D) {

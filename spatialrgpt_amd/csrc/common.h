@@ -57,6 +57,34 @@ void srgpt_set_error(const char* fmt, ...);
     if (rc__ != 0) return rc__; \
   } while (0)
 
+// Tuning knobs: the product library is built WITHOUT SRGPT_TUNING_KNOBS and every knob is its compile-time default (no
+// getenv, no globals).  `make TUNING=1` builds libsrgpt_hip_tuning.so for the A/B scripts under scripts/, where the same
+// sites read the environment once.
+#ifdef SRGPT_TUNING_KNOBS
+#include <stdlib.h>
+#define SRGPT_KNOB(name, dflt) ([]() -> int { static const int v__ = getenv(name) ? atoi(getenv(name)) : (dflt); return v__; }())
+#else
+#define SRGPT_KNOB(name, dflt) (dflt)
+#endif
+
+// Raise a kernel's dynamic-LDS limit once per (kernel, device).  hipFuncSetAttribute is per device, so the "done" state is a
+// per-device bit behind an atomic (thread-safe, idempotent): `done` is the call site's own function-local atomic.
+#include <atomic>
+static inline int srgpt_ensure_dyn_lds(std::atomic<uint64_t>& done, const void* kfn, int bytes) {
+  if (bytes <= 48 * 1024) return 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  const hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    srgpt_set_error("hipFuncSetAttribute(dynamic LDS %d B) failed: %s", bytes, hipGetErrorString(e));
+    return SRGPT_ERR_LAUNCH;
+  }
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
+
 static inline hipStream_t as_stream(srgpt_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline size_t dtype_size(int dtype) { return dtype == SRGPT_BF16 ? 2 : 4; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

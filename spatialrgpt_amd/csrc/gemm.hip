@@ -57,6 +57,7 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& e, int m, int n, 
 // ------------------------------------------------------------------------------------------------
 constexpr int BK = 64;  // bf16 elements per K tile = 8 slots of 16 B
 
+#ifdef SRGPT_TUNING_KNOBS  // register-staged predecessor: only in the A/B build (make TUNING=1, SRGPT_GEMM_GLDS=0)
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                       int K, int lda, Epilogue e) {
@@ -177,6 +178,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__
       }
     }
 }
+
+#endif  // SRGPT_TUNING_KNOBS
 
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel, direct-to-LDS staging (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass, single LDS
@@ -423,8 +426,8 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
     }
   }
   {  // tuning knobs (scripts/ubench_gemm.py sweeps them); unset in production
-    static const int f_bm = getenv("SRGPT_GEMM_FORCE_BM") ? atoi(getenv("SRGPT_GEMM_FORCE_BM")) : 0;
-    static const int f_sp = getenv("SRGPT_GEMM_FORCE_SPLITS") ? atoi(getenv("SRGPT_GEMM_FORCE_SPLITS")) : 0;
+    const int f_bm = SRGPT_KNOB("SRGPT_GEMM_FORCE_BM", 0);
+    const int f_sp = SRGPT_KNOB("SRGPT_GEMM_FORCE_SPLITS", 0);
     if (f_bm == 64 || f_bm == 128) bm = f_bm;
     if (f_sp > 0 && ws) {
       splits = f_sp;
@@ -439,24 +442,30 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
     splits = cdiv(nk, e.tiles_per_split);  // no empty split
     e.splits = splits;
   }
-  static const int use_glds = getenv("SRGPT_GEMM_GLDS") ? atoi(getenv("SRGPT_GEMM_GLDS")) : 1;  // A/B knob
+  const int use_glds = SRGPT_KNOB("SRGPT_GEMM_GLDS", 1);  // A/B knob (tuning build only)
+  (void)use_glds;
   if (bm == 128) {
     dim3 grid(cdiv(N, 128), cdiv(M, 128), 1);
-    if (use_glds)
-      hipLaunchKernelGGL((gemm_bf16_glds<128, 128, 1>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
-    else
+#ifdef SRGPT_TUNING_KNOBS
+    if (!use_glds)
       hipLaunchKernelGGL((gemm_bf16_mfma<128, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+    else
+#endif
+      hipLaunchKernelGGL((gemm_bf16_glds<128, 128, 1>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
   } else {
     dim3 grid(cdiv(N, 128), cdiv(M, 64), e.splits);
-    static const int f_nbuf = getenv("SRGPT_GEMM_FORCE_NBUF") ? atoi(getenv("SRGPT_GEMM_FORCE_NBUF")) : 0;
+    const int f_nbuf = SRGPT_KNOB("SRGPT_GEMM_FORCE_NBUF", 0);
     const long blocks = tiles * e.splits;
     const bool dbuf = f_nbuf ? f_nbuf == 2 : blocks < 3L * srgpt_device_cus();
-    if (use_glds && dbuf)
-      hipLaunchKernelGGL((gemm_bf16_glds<64, 128, 2>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
-    else if (use_glds)
-      hipLaunchKernelGGL((gemm_bf16_glds<64, 128, 1>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
-    else
+#ifdef SRGPT_TUNING_KNOBS
+    if (!use_glds)
       hipLaunchKernelGGL((gemm_bf16_mfma<64, 128>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+    else
+#endif
+    if (dbuf)
+      hipLaunchKernelGGL((gemm_bf16_glds<64, 128, 2>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+    else
+      hipLaunchKernelGGL((gemm_bf16_glds<64, 128, 1>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
   }
   SRGPT_LAUNCH_CHECK();
   if (e.splits > 1) {

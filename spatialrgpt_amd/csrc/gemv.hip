@@ -389,13 +389,13 @@ int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, con
   const size_t lds = (size_t)B * K * sizeof(T);
   SRGPT_CHECK(lds <= 150 * 1024, SRGPT_ERR_UNSUPPORTED, "srgpt_gemv: batch*K too large for LDS (%zu bytes)", lds);
   const int cus = srgpt_device_cus();
-  static const int env_per_cu = getenv("SRGPT_GEMV_BLOCKS_PER_CU") ? atoi(getenv("SRGPT_GEMV_BLOCKS_PER_CU")) : 0;  // tuning knob
+  const int env_per_cu = SRGPT_KNOB("SRGPT_GEMV_BLOCKS_PER_CU", 0);  // tuning knob
   const int per_cu = lds > 70 * 1024 ? 1 : (env_per_cu > 0 ? env_per_cu : 2);
   int grid = (N + 3) / 4;
   if (grid > cus * per_cu) grid = cus * per_cu;
   if (grid < 1) grid = 1;
   const int chunks = B * (K / WChunk<T>::VEC);
-  static const int use_reg = getenv("SRGPT_GEMV_REG") ? atoi(getenv("SRGPT_GEMV_REG")) : 1;  // A/B knob
+  const int use_reg = SRGPT_KNOB("SRGPT_GEMV_REG", 1);  // A/B knob
   if (B == 1 && sizeof(T) == 2 && use_reg) {
     const int nit = (K / 8 + 63) / 64;
     // measured (scripts/ubench_gemv_c.hip): without the fused RMSNorm the register variant saves 0.6-0.8 us per launch
@@ -412,11 +412,8 @@ int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, con
 #define SRGPT_GEMV_LAUNCH(SW, NXV)                                                                              \
   do {                                                                                                          \
     auto kfn = gemv_kernel<T, B, SW, NXV>;                                                                      \
-    static bool attr_set = false;                                                                               \
-    if (lds > 48 * 1024 && !attr_set) {                                                                         \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);      \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
+    static std::atomic<uint64_t> attr_done{0};                                                                  \
+    SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)kfn, lds > 48 * 1024 ? 150 * 1024 : 0));             \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, (const T*)x, (const T*)W, (const T*)norm_w, eps,     \
                        (const T*)residual, out, N, K, out_f32);                                                 \
   } while (0)
@@ -433,7 +430,7 @@ int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, con
 template <typename T>
 int dispatch_b(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
                int batch, int N, int K, int swiglu, int out_f32, hipStream_t s) {
-  static const int skinny_min = getenv("SRGPT_SKINNY_MIN_BATCH") ? atoi(getenv("SRGPT_SKINNY_MIN_BATCH")) : 3;  // measured: VALU wins at 1-2 rows, MFMA from 3
+  const int skinny_min = SRGPT_KNOB("SRGPT_SKINNY_MIN_BATCH", 3);  // measured: VALU wins at 1-2 rows, MFMA from 3
   if (batch > 4 || (sizeof(T) == 2 && batch >= skinny_min)) {
     // bf16: rows go through the MFMA skinny kernel 16 at a time (skinny.hip); fp32 (parity dtype of the tiny models):
     // 4 rows at a time through the VALU kernel.  Each chunk streams the weights once.

@@ -245,11 +245,8 @@ int launch_gemv_w8(const void* x, const void* W, const float* wscale, const void
 #define SRGPT_W8_LAUNCH(SW, NXV)                                                                               \
   do {                                                                                                         \
     auto kfn = gemv_w8_kernel<B, SW, NXV>;                                                                     \
-    static bool attr_set = false;                                                                              \
-    if (lds > 48 * 1024 && !attr_set) {                                                                        \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);     \
-      attr_set = true;                                                                                         \
-    }                                                                                                          \
+    static std::atomic<uint64_t> attr_done{0};                                                                 \
+    SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)kfn, lds > 48 * 1024 ? 150 * 1024 : 0));            \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, (const T*)x, (const unsigned char*)W, wscale,       \
                        (const T*)norm_w, eps, (const T*)residual, out, N, K, out_f32);                         \
   } while (0)

@@ -17,16 +17,18 @@ void srgpt_set_error(const char* fmt, ...) {
 extern "C" const char* srgpt_last_error(void) { return g_err; }
 extern "C" int srgpt_abi_version(void) { return 1; }
 extern "C" int srgpt_device_cus(void) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-      cus = p.multiProcessorCount;
-    else
-      cus = 256;  // MI355X
+  // per device ordinal, filled once each (benign race: every writer stores the same value)
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<int>& c = cus[dev & 63];
+  int v = c.load(std::memory_order_relaxed);
+  if (v == 0) {
+    int n = 0;
+    v = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;  // MI355X
+    c.store(v, std::memory_order_relaxed);
   }
-  return cus;
+  return v;
 }
 
 namespace {

@@ -310,11 +310,8 @@ int launch_skinny(const void* x, const void* W, const float* wscale, const void*
   static_assert(lds >= NW * MAXSU * 64 * 4 * 4, "reduction buffer must fit");
   static_assert(lds <= 160 * 1024, "LDS");
   auto kfn = skinny_kernel<SWIGLU, NI, NW, W8>;
-  static bool attr_set = false;
-  if (lds > 48 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)kfn, lds));
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * NW), lds, s, (const bf16_t*)x, W, wscale, (const bf16_t*)norm_w, eps,
                      (const bf16_t*)residual, out, batch, N, K, out_f32);
   SRGPT_LAUNCH_CHECK();
@@ -368,7 +365,7 @@ extern "C" int srgpt_gemv_w8(const void* x, const void* W8, const float* wscale,
   SRGPT_CHECK(K % 8 == 0, SRGPT_ERR_ARG, "srgpt_gemv_w8: K=%d must be a multiple of 8", K);
   SRGPT_CHECK(!(swiglu && (residual || out_f32)), SRGPT_ERR_ARG, "srgpt_gemv_w8: swiglu excludes residual/out_f32");
   hipStream_t s = as_stream(stream);
-  static const int valu_max = getenv("SRGPT_W8_VALU_MAX_BATCH") ? atoi(getenv("SRGPT_W8_VALU_MAX_BATCH")) : 2;  // tuning knob
+  const int valu_max = SRGPT_KNOB("SRGPT_W8_VALU_MAX_BATCH", 2);  // tuning knob
   if (batch <= valu_max && batch <= 2 && K % 16 == 0)  // 1-2 rows: VALU kernel (gemv_w8.hip), like the bf16 path
     return srgpt_gemv_w8_valu(x, W8, wscale, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, s);
   const size_t on = out_f32 ? sizeof(float) : 2;

@@ -94,9 +94,10 @@ class SrgptEngine:
         self.stream = torch.cuda.Stream(device=self.device)
 
     # ------------------------------------------------------------------ A1
-    def vit(self, images: torch.Tensor) -> torch.Tensor:
-        """[n,3,S,S] -> hidden_states[select_layer] [n, grid^2, C], returned in images.dtype."""
-        in_dtype = images.dtype
+    def vit(self, images: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """[n,3,S,S] (any float dtype: cast to the engine dtype at the boundary, vision_encoder.py:127) ->
+        hidden_states[select_layer] [n, grid^2, C] in the ENGINE dtype; `out_dtype` reproduces the module-level cast back
+        to the caller's image dtype (vision_encoder.py:130) for callers that use the tower on its own."""
         x = images.to(device=self.device, dtype=self.dtype).contiguous()  # vision_encoder.py:127
         n, ch, S, S2 = x.shape
         if ch != 3 or S != self.cfg.image_size or S2 != S:
@@ -109,10 +110,11 @@ class SrgptEngine:
         L.check(lib.srgpt_vit_forward(C.byref(self.w.vit), x.data_ptr(), out.data_ptr(), self._vit_ws.data_ptr(), n, ops._stream()))
         if self.cfg.select_feature == "patch":
             out = out[:, 1:]  # feature_select drops token 0 whatever the tower (vision_encoder.py:28-29)
-        return out.to(in_dtype)  # vision_encoder.py:130
+        return out if out_dtype is None or out_dtype == out.dtype else out.to(out_dtype)  # vision_encoder.py:130
 
     # ------------------------------------------------------------------ A2
     def feature_refinement(self, tower: torch.Tensor):
+        tower = tower.to(device=self.device, dtype=self.dtype)
         n, HW, Cc = tower.shape
         g = int(HW ** 0.5)
         if g * g != HW:
@@ -135,7 +137,7 @@ class SrgptEngine:
         out = []
         for i in range(n):
             m = masks[i]
-            out.append(None if m is None else ops.region_pool(feats[i], m.to(self.device)))
+            out.append(None if m is None else ops.region_pool(feats[i].to(self.dtype), m.to(self.device)))
         return out
 
     def region_extractor(self, hres, depth_features, masks):
@@ -153,6 +155,7 @@ class SrgptEngine:
     # ------------------------------------------------------------------ A5
     def mm_projector(self, lres: torch.Tensor) -> torch.Tensor:
         w = self.w
+        lres = lres.to(device=self.device, dtype=self.dtype)
         n = lres.shape[0]
         x = ops.s2d(lres)
         tokens = x.shape[1]
@@ -176,7 +179,10 @@ class SrgptEngine:
         n = images.shape[0]
         use_depth = cfg.enable_region and cfg.enable_depth and depths is not None
         # RGB and depth go through the tower as ONE batch of 2n images (same weights)
-        both = torch.cat([images, depths.to(images.dtype)], dim=0) if use_depth else images
+        # fp16 / fp32 callers (the reference's loader builds fp16: builder.py:62, eval_region_cls.py:316-317) are cast to the
+        # engine dtype here and every intermediate stays in it -- the weights are only held in the engine dtype
+        images = images.to(device=self.device, dtype=self.dtype)
+        both = torch.cat([images, depths.to(device=self.device, dtype=self.dtype)], dim=0) if use_depth else images
         feats = self.vit(both)
         tower = feats[:n]
         mask_embeds = depth_embeds = None
@@ -301,6 +307,7 @@ class SrgptEngine:
                              src_idx=torch.tensor(src_rows, device=dev, dtype=torch.int32))
 
         if ids_tok:
+            self._check_ids(ids_tok)
             emb = ops.embed_rows(self.w.embed, torch.tensor(ids_tok, device=dev, dtype=torch.int64))
             place(emb, list(range(len(ids_tok))), rows_tok)
         place(image_features.reshape(-1, H), img_src, img_dst)
@@ -336,30 +343,51 @@ class SrgptEngine:
             stages["inputs_embeds"] = res[0]
         return res
 
+    def _check_ids(self, ids) -> None:
+        """nn.Embedding raises IndexError for ids outside [0, vocab); the row-gather kernel would read out of bounds
+        (e.g. the -200 sentinel on an images=None path, or <mask>/<depth> ids past a table that was never resized)."""
+        if isinstance(ids, torch.Tensor):
+            if ids.numel() == 0:
+                return
+            lo, hi = int(ids.min()), int(ids.max())
+        else:
+            if not ids:
+                return
+            lo, hi = min(ids), max(ids)
+        if lo < 0 or hi >= self.w.vocab:
+            raise IndexError(f"index out of range in self: token ids must be in [0, {self.w.vocab}), got [{lo}, {hi}]")
+
     def embed_tokens(self, input_ids: torch.Tensor) -> torch.Tensor:
         B, P = input_ids.shape
+        self._check_ids(input_ids)
         return ops.embed_rows(self.w.embed, input_ids.to(self.device)).reshape(B, P, -1)
 
     # ------------------------------------------------------------------ A7-A13
-    def _get_state(self, batch: int, T: int, max_new: int) -> DecodeState:
+    def _get_state(self, batch: int, T: int, max_new: int, fresh: bool = False) -> DecodeState:
+        """Cache/workspace for `batch` sequences of T prompt positions + max_new generated ones.  The pooled state serves the
+        internal generate() path; `fresh=True` allocates an independent one (a handle returned to the caller as
+        `past_key_values` must not be overwritten by the next call -- the reference returns independent caches)."""
         need_pos = T + max_new
         if need_pos > self.w.rope_len:
             raise ValueError(f"sequence of {need_pos} positions exceeds the RoPE table ({self.w.rope_len})")
+        # positions are capped by the RoPE table: a cache longer than it would let decode steps index past its end
+        max_pos = min((need_pos + 127) // 128 * 128, self.w.rope_len)
+        if fresh:
+            return DecodeState(self, batch, max_pos, max(T, 1), max_new)
         s = self._state
         if s is None or s.batch != batch or s.max_pos < need_pos or s.ws_tokens < T or s.max_new < max_new:
-            max_pos = (need_pos + 127) // 128 * 128
             self._state = None
             s = DecodeState(self, batch, max_pos, max(T, 1), max_new)
             self._state = s
         return s
 
     def prefill(self, inputs_embeds: torch.Tensor, max_new: int = 1, all_logits: bool = False, hidden_states: bool = False,
-                lens: Optional[torch.Tensor] = None):
+                lens: Optional[torch.Tensor] = None, fresh_state: bool = False):
         """inputs_embeds [B,T,H]; `lens` (int [B]) marks a RIGHT-padded ragged batch: row b has lens[b] valid positions,
         its logits come from position lens[b]-1 and decoding continues there.  Returns (state, logits_all|None, hiddens|None)."""
         B, T, H = inputs_embeds.shape
         x = inputs_embeds.to(device=self.device, dtype=self.dtype).contiguous()
-        st = self._get_state(B, T, max_new)
+        st = self._get_state(B, T, max_new, fresh=fresh_state)
         al = torch.empty((B, T, self.w.vocab), device=self.device, dtype=torch.float32) if all_logits else None
         hs = torch.empty((self.cfg.layers + 1, B, T, H), device=self.device, dtype=self.dtype) if hidden_states else None
         if lens is None:
@@ -381,8 +409,10 @@ class SrgptEngine:
         tokens at every row's next position and returns the fp32 logits [B, vocab]."""
         if input_ids.shape != (st.batch, 1):
             raise ValueError(f"step: input_ids must be [{st.batch}, 1]")
-        if max(st.host_len) >= st.max_pos:
-            raise ValueError(f"KV cache full ({st.max_pos} positions): re-run forward() with a larger cache_reserve")
+        if max(st.host_len) >= min(st.max_pos, self.w.rope_len):
+            raise ValueError(f"KV cache full ({min(st.max_pos, self.w.rope_len)} positions): re-run forward() with a larger "
+                             "cache_reserve / a longer RoPE table")
+        self._check_ids(input_ids)
         st.tok.copy_(input_ids[:, 0].to(device=self.device, dtype=torch.int64))
         L.check(L.load().srgpt_llm_decode_step(C.byref(self.w.llm), C.byref(st.c), ops._stream()))
         st.host_len = [n + 1 for n in st.host_len]

@@ -77,13 +77,33 @@ class KeywordsStoppingCriteria:
 
 
 class SrgptImageProcessor:
-    """Minimal SigLIP-style processor (resize -> rescale 1/255 -> normalise) for when no HF processor is at hand."""
+    """Built-in processor for when transformers cannot build its own (no torchvision here).  Two shapes:
+      * SigLIP (siglip_encoder.py:10 `SiglipImageProcessor`): resize to size x size (bicubic) -> rescale 1/255 -> normalise
+      * CLIP   (clip_encoder.py:11 `CLIPImageProcessor`; `center_crop=True`): resize the SHORTEST edge to `shortest_edge`
+        keeping the aspect ratio (bicubic) -> centre crop size x size -> rescale -> normalise; exposes `crop_size`, which is how
+        the reference's helpers tell the two apart (mm_utils.py:437-441)."""
 
     def __init__(self, size=384, image_mean=(0.5, 0.5, 0.5), image_std=(0.5, 0.5, 0.5), rescale_factor=1 / 255.0,
-                 do_normalize=True, do_convert_rgb=True, resample=3):
-        self.size = {"height": size, "width": size}
+                 do_normalize=True, do_convert_rgb=True, resample=3, shortest_edge=None, center_crop=False):
+        self.center_crop = bool(center_crop)
+        if self.center_crop:
+            self.crop_size = {"height": size, "width": size}
+            self.size = {"shortest_edge": shortest_edge or size}
+        else:
+            self.crop_size = None
+            self.size = {"height": size, "width": size}
         self.image_mean, self.image_std = list(image_mean), list(image_std)
         self.rescale_factor, self.do_normalize, self.do_convert_rgb, self.resample = rescale_factor, do_normalize, do_convert_rgb, resample
+
+    def _target(self, h, w):
+        """-> ((resize_h, resize_w), (crop_h, crop_w) | None)"""
+        if not self.center_crop:
+            return (self.size["height"], self.size["width"]), None
+        se = self.size["shortest_edge"]
+        short, long = (w, h) if w <= h else (h, w)
+        new_short, new_long = se, int(se * long / short)  # HF get_resize_output_image_size(default_to_square=False)
+        rh, rw = (new_long, new_short) if w <= h else (new_short, new_long)
+        return (rh, rw), (self.crop_size["height"], self.crop_size["width"])
 
     def preprocess(self, image, return_tensors="pt"):
         from PIL import Image
@@ -92,15 +112,23 @@ class SrgptImageProcessor:
             arr = image.astype(np.float32)
             if arr.ndim == 2:
                 arr = arr[None]
-            if arr.shape[-2:] != (self.size["height"], self.size["width"]):
-                chans = [np.asarray(Image.fromarray(c, mode="F").resize((self.size["width"], self.size["height"]), self.resample))
-                         for c in arr]
+            (rh, rw), crop = self._target(arr.shape[-2], arr.shape[-1])
+            if arr.shape[-2:] != (rh, rw):
+                chans = [np.asarray(Image.fromarray(c, mode="F").resize((rw, rh), self.resample)) for c in arr]
                 arr = np.stack(chans, 0)
         else:
             if self.do_convert_rgb:
                 image = image.convert("RGB")
-            image = image.resize((self.size["width"], self.size["height"]), self.resample)
+            (rh, rw), crop = self._target(image.size[1], image.size[0])
+            if (image.size[1], image.size[0]) != (rh, rw):
+                image = image.resize((rw, rh), self.resample)
             arr = np.asarray(image).astype(np.float32).transpose(2, 0, 1)
+        if crop is not None:
+            ch, cw = crop
+            top, left = (arr.shape[-2] - ch) // 2, (arr.shape[-1] - cw) // 2
+            if top < 0 or left < 0:
+                raise ValueError("centre crop larger than the resized image")
+            arr = arr[..., top:top + ch, left:left + cw]
         arr = arr * self.rescale_factor
         if self.do_normalize:
             m = np.asarray(self.image_mean, np.float32)[:, None, None]

@@ -13,12 +13,9 @@ from typing import Dict
 import torch
 
 from .config import SrgptConfig
+from .configuration import LlavaConfig, LlavaLlamaConfig, register_auto_classes
 from .constants import IGNORE_INDEX
 from .engine import SrgptEngine
-
-
-class LlavaLlamaConfig(SrgptConfig):
-    model_type = "llava_llama"
 
 
 class _Facade:
@@ -46,9 +43,12 @@ class _VisionTower(_Facade):
                                       llm_mask_token_id=c.mask_token_id, llm_depth_token_id=c.depth_token_id)
 
     def __call__(self, images):
+        # module-level contract (vision_encoder.py:115-132): features come back in the caller's image dtype
         if isinstance(images, list):
-            return [self._eng.vit(im.unsqueeze(0)) for im in images]
-        return self._eng.vit(images)
+            return [self._eng.vit(im.unsqueeze(0), out_dtype=im.dtype) for im in images]
+        return self._eng.vit(images, out_dtype=images.dtype)
+
+    forward = __call__
 
     @property
     def device(self):
@@ -68,7 +68,8 @@ class _RegionExtractor(_Facade):
         return self._eng.feature_refinement(tower_features.to(self._eng.dtype).contiguous())
 
     def __call__(self, image_features, depth_features, masks, *a, **k):
-        return self._eng.region_extractor(image_features, depth_features, masks)
+        dt = self._eng.dtype
+        return self._eng.region_extractor(image_features.to(dt), None if depth_features is None else depth_features.to(dt), masks)
 
     forward = __call__
 
@@ -101,12 +102,49 @@ class _Llm(_Facade):
 
 
 class LlavaLlamaModel:
+    """`LlavaLlamaModel` of llava/model/language_model/llava_llama.py:48-213 on the MI355X engine.
+
+    Two construction forms:
+      * `LlavaLlamaModel(SrgptConfig, state_dict, ...)`           -- weights in memory (tests, benchmarks)
+      * `LlavaLlamaModel(config=LlavaLlamaConfig, low_cpu_mem_usage=True, **kw)` / `LlavaLlamaModel.from_pretrained(path)` /
+        `AutoModel.from_pretrained(path)`                         -- the reference's own sequence (builder.py:142-158): the
+        checkpoint directory is `config._name_or_path` or `config.resume_path` (llava/model/utils.py:28-31)
+
+    dtype policy: the engine holds its weights in ONE dtype (bfloat16 by default, float32 for bit-exact checks) and computes
+    in it.  The reference's loader builds float16 (builder.py:62) and some callers feed float16 tensors without ever casting
+    the model (eval_region_cls.py:316-317, model_vqa.py:71, the demo's non-bf16 branch): every float input is cast to the
+    engine dtype at the boundary (exactly where the reference casts: vision_encoder.py:127, llava_llama.py:210), logits come
+    back float32 (modeling_llama.py:1045), and `model.to(torch.float16)` / `.half()` / `.to(torch.float32)` are accepted as
+    requests about the INTERFACE dtype only -- they never raise and never re-materialise weights (one warning per model)."""
+
     config_class = LlavaLlamaConfig
     main_input_name = "input_embeds"
+    supports_gradient_checkpointing = True
 
-    def __init__(self, config: SrgptConfig, state_dict: Dict[str, torch.Tensor], device="cuda",
+    def __init__(self, config=None, state_dict: Dict[str, torch.Tensor] = None, device="cuda",
                  dtype=torch.bfloat16, tokenizer=None, image_processor=None, rope_positions: int = 0,
-                 consume_state_dict: bool = False, llm_weight_format: str = "native"):
+                 consume_state_dict: bool = False, llm_weight_format: str = "native", **hf_kwargs):
+        self.hf_config = None
+        if isinstance(config, LlavaConfig):
+            # the reference's construction path: config carries the checkpoint location
+            from .builder import load_image_processor, load_tokenizer, read_checkpoint
+
+            root = config.checkpoint_root()
+            if root is None:
+                raise ValueError("LlavaLlamaModel(config): config has neither `_name_or_path` nor `resume_path`")
+            self.hf_config = config
+            vr = config.vision_resolution if config.vision_resolution not in (None,) else -1
+            cfg, state_dict = read_checkpoint(root, vr, config.interpolate_mode or "linear")
+            tokenizer = load_tokenizer(root, cfg, state_dict)
+            image_processor = load_image_processor(root, cfg)
+            consume_state_dict = True
+            md = hf_kwargs.pop("torch_dtype", None) or config.model_dtype
+            if isinstance(md, str):
+                md = getattr(torch, md.replace("torch.", ""))
+            dtype = md if md in (torch.bfloat16, torch.float32) else dtype
+            config = cfg
+        elif state_dict is None:
+            raise TypeError("LlavaLlamaModel needs (SrgptConfig, state_dict) or a LlavaLlamaConfig that points at a checkpoint")
         self.config = config
         self.engine = SrgptEngine(config, state_dict, device=device, dtype=dtype, rope_positions=rope_positions,
                                   consume_state_dict=consume_state_dict, llm_weight_format=llm_weight_format)
@@ -118,6 +156,30 @@ class LlavaLlamaModel:
         self.is_loaded = True
         self.training = False
         self.cache_reserve = 128  # forward(use_cache=True): cache positions reserved beyond the prompt
+        self._warned_dtype = False
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, **kwargs):
+        """llava_llama.py:58-94: the entry `AutoModel.from_pretrained` lands on.  Only the arguments that mean something for
+        this engine are honoured (`torch_dtype`, `device_map`/`device`, `load_in_8bit`); hub downloads are not attempted."""
+        import os
+
+        from .builder import load_model
+
+        if not os.path.isdir(str(pretrained_model_name_or_path)):
+            raise OSError(f"{pretrained_model_name_or_path} is not a local checkpoint directory")
+        dtype = kwargs.pop("torch_dtype", None) or kwargs.pop("dtype", None) or torch.bfloat16
+        if isinstance(dtype, str):
+            dtype = getattr(torch, dtype.replace("torch.", ""))
+        if dtype not in (torch.bfloat16, torch.float32):
+            dtype = torch.bfloat16  # float16 requests: see the dtype policy above
+        device = kwargs.pop("device", None) or "cuda"
+        vr = getattr(config, "vision_resolution", None) if config is not None else None
+        _, model, _ = load_model(str(pretrained_model_name_or_path), device=device, dtype=dtype,
+                                 llm_weight_format="fp8" if kwargs.pop("load_in_8bit", False) else "native",
+                                 vision_resolution=-1 if vr is None else vr)
+        model.hf_config = config
+        return model
 
     # ---- nn.Module / PreTrainedModel look-alikes used by the reference's callers ----
     @property
@@ -131,18 +193,39 @@ class LlavaLlamaModel:
     def eval(self):
         return self
 
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("this is the inference path; training is out of scope")
+        return self
+
+    def requires_grad_(self, *a, **k):
+        return self
+
     def cuda(self, *a, **k):
         return self
 
     def to(self, *args, **kwargs):
+        """device moves are no-ops (the engine lives on its GPU); dtype requests follow the dtype policy of the class."""
         dtype = kwargs.get("dtype")
         for a in args:
             if isinstance(a, torch.dtype):
                 dtype = a
-        if dtype is not None and dtype != self.engine.dtype:
-            raise NotImplementedError(
-                f"this engine was built in {self.engine.dtype}; re-load with dtype={dtype} (supported: bfloat16, float32)")
+        if dtype is not None and dtype != self.engine.dtype and not self._warned_dtype:
+            import warnings
+
+            warnings.warn(f"LlavaLlamaModel.to({dtype}): the MI355X engine keeps computing in {self.engine.dtype}; "
+                          f"{dtype} inputs are cast at the boundary (documented dtype policy)")
+            self._warned_dtype = True
         return self
+
+    def half(self):
+        return self.to(torch.float16)
+
+    def bfloat16(self):
+        return self.to(torch.bfloat16)
+
+    def float(self):
+        return self.to(torch.float32)
 
     def get_llm(self):
         return self.llm
@@ -213,6 +296,8 @@ class LlavaLlamaModel:
             out = SimpleNamespace(loss=None, logits=logits[:, None, :], past_key_values=past_key_values, hidden_states=None,
                                   attentions=None)
             return (out.logits, None) if dpo_forward else out
+        if inputs_embeds is not None:
+            inputs_embeds = inputs_embeds.to(self.dtype)
         if inputs_embeds is None:
             if images is None:
                 inputs_embeds = self.engine.embed_tokens(input_ids)
@@ -223,8 +308,9 @@ class LlavaLlamaModel:
         if attention_mask is None:
             # reference: `attention_mask.sum(-1)` on None -> AttributeError (SURVEY 3.2 gotcha)
             raise AttributeError("'NoneType' object has no attribute 'sum'")
-        reserve = self.cache_reserve if use_cache else 1  # positions kept free after the prompt for incremental steps
         B, T, _ = inputs_embeds.shape
+        # positions kept free after the prompt for incremental steps, clamped to what the RoPE table can still address
+        reserve = max(1, min(self.cache_reserve, self.engine.w.rope_len - T)) if use_cache else 1
         keep = attention_mask.bool()
         ragged = not bool(keep.all())
         if ragged:
@@ -235,7 +321,7 @@ class LlavaLlamaModel:
             for b in range(B):
                 packed[b, :int(lens[b])] = inputs_embeds[b][keep[b]]
             st, plog, hs = self.engine.prefill(packed, max_new=reserve, all_logits=True,
-                                               hidden_states=bool(output_hidden_states), lens=lens)
+                                               hidden_states=bool(output_hidden_states), lens=lens, fresh_state=bool(use_cache))
             logits = torch.zeros_like(plog)
             for b in range(B):
                 logits[b][keep[b]] = plog[b, :int(lens[b])]
@@ -246,7 +332,7 @@ class LlavaLlamaModel:
                 hs = uh
         else:
             st, logits, hs = self.engine.prefill(inputs_embeds, max_new=reserve, all_logits=True,
-                                                 hidden_states=bool(output_hidden_states))
+                                                 hidden_states=bool(output_hidden_states), fresh_state=bool(use_cache))
         loss = None
         if labels is not None:
             # LlamaForCausalLM (modeling_llama.py:1047-1058): shift by one, mean CE over labels != IGNORE_INDEX
@@ -366,3 +452,5 @@ class LlavaLlamaModel:
 
 
 LlavaLlamaForCausalLM = LlavaLlamaModel
+
+register_auto_classes(LlavaLlamaModel)  # llava_llama.py:216-217

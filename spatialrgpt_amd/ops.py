@@ -34,6 +34,15 @@ def _dev(*ts):
             raise RuntimeError("srgpt ops need tensors on the GPU (no CPU fallback)")
 
 
+def _same_dtype(op: str, ref: torch.Tensor, **others):
+    """The kernels take ONE dtype code per call (the activation's): a weight / bias / residual buffer in another dtype would
+    be read with the wrong element size (bf16 weights read as fp32 run 2x past their end).  torch raises a dtype-mismatch
+    RuntimeError for the same call; so do we."""
+    for name, t in others.items():
+        if t is not None and t.dtype != ref.dtype:
+            raise RuntimeError(f"{op}: expected {name} to have the activation dtype {ref.dtype}, got {t.dtype}")
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -55,6 +64,7 @@ def gemm(a, w, bias=None, residual=None, act=L.ACT_NONE, out=None, out_f32=False
          out_mode=L.OUT_PLAIN, gw=0, out_shape=None):
     """act(a @ w.T + bias) + residual.  a [M,K] (row stride may exceed K), w [N,K]."""
     _dev(a, w, bias, residual)
+    _same_dtype("gemm", a, weight=w, bias=bias, residual=residual)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and a.stride(1) == 1 and w.is_contiguous()
@@ -72,6 +82,7 @@ def gemm(a, w, bias=None, residual=None, act=L.ACT_NONE, out=None, out_f32=False
 def gemv(x, w, norm_w=None, eps=0.0, residual=None, swiglu=False, out=None, out_f32=False):
     """decode GEMV: x [B,K], w [N(,2N if swiglu),K] -> [B,N]."""
     _dev(x, w, norm_w, residual)
+    _same_dtype("gemv", x, weight=w, norm_weight=norm_w, residual=residual)
     B, K = x.shape
     N = w.shape[0] // 2 if swiglu else w.shape[0]
     if out is None:
@@ -98,6 +109,7 @@ def quantize_fp8_rows(w: torch.Tensor):
 def gemv_w8(x, w8, wscale, norm_w=None, eps=0.0, residual=None, swiglu=False, out=None, out_f32=False):
     """decode product with fp8 weights: x [B,K] bf16, w8 uint8 [N(,2N if swiglu),K], wscale fp32 [rows] -> [B,N]."""
     _dev(x, w8, wscale, norm_w, residual)
+    _same_dtype("gemv_w8", x, norm_weight=norm_w, residual=residual)
     if x.dtype != torch.bfloat16 or w8.dtype != torch.uint8 or wscale.dtype != torch.float32:
         raise ValueError("gemv_w8: x must be bf16, w8 uint8, wscale fp32")
     B, K = x.shape
@@ -111,6 +123,7 @@ def gemv_w8(x, w8, wscale, norm_w=None, eps=0.0, residual=None, swiglu=False, ou
 
 def layernorm(x, w, b, eps, act=L.ACT_NONE, out=None):
     _dev(x, w, b)
+    _same_dtype("layernorm", x, weight=w, bias=b, out=out)
     x = _c(x)
     cols = x.shape[-1]
     rows = x.numel() // cols
@@ -122,6 +135,7 @@ def layernorm(x, w, b, eps, act=L.ACT_NONE, out=None):
 
 def rmsnorm(x, w, eps, out=None):
     _dev(x, w)
+    _same_dtype("rmsnorm", x, weight=w, out=out)
     x = _c(x)
     cols = x.shape[-1]
     rows = x.numel() // cols
@@ -134,6 +148,7 @@ def rmsnorm(x, w, eps, out=None):
 def attention(q, k, v, causal=False, scale=None, kv_len=None):
     """q [B,Tq,Hq,D], k/v [B,Tk,Hkv,D] (arbitrary strides with unit last stride) -> [B,Tq,Hq,D]."""
     _dev(q, k, v)
+    _same_dtype("attention", q, k=k, v=v)
     B, Tq, Hq, D = q.shape
     Tk, Hkv = k.shape[1], k.shape[2]
     assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
@@ -219,6 +234,7 @@ def im2col(images, patch, kp):
 
 
 def embed_rows(table, ids):
+    """rows of `table` at `ids`; ids must already be validated against the table height (engine._check_ids)."""
     _dev(table, ids)
     ids = _c(ids.to(torch.int64)).reshape(-1)
     out = torch.empty((ids.numel(), table.shape[1]), device=table.device, dtype=table.dtype)
@@ -229,6 +245,7 @@ def embed_rows(table, ids):
 def scatter_rows(src, idx, dst, src_idx=None):
     """dst[idx[i]] = src[src_idx[i] if src_idx is given else i]"""
     _dev(src, idx, dst, src_idx)
+    _same_dtype("scatter_rows", src, dst=dst)
     assert idx.dtype == torch.int32 and src.is_contiguous() and dst.is_contiguous()
     assert src_idx is None or (src_idx.dtype == torch.int32 and src_idx.numel() == idx.numel())
     n = idx.numel()

@@ -1,0 +1,109 @@
+"""GPU: FULL-DEPTH parity of BASELINE.json's headline configurations against the CPU oracle (oracle/srgpt_oracle.py, the
+restatement pinned bit-for-bit to the real reference by oracle/make_golden.py).
+
+  configs[1]  SpatialRGPT-VILA1.5-8B geometry: 32-layer Llama-3-8B shape (GQA 32/8, vocab 128258) behind the 27-layer
+              SigLIP-so400m shape (26 layers run), 384 px RGB + depth, 8 region masks, 64-id prompt -> T = 259
+  configs[3]  Llama-2-7B shape (MHA 32/32, inter 11008, vocab 32002), 16 regions, 512-id prompt -> T = 707
+
+The same seeded bf16 weights are generated on the GPU, copied to the host and handed to the oracle (16 threads).  The oracle
+runs the whole request (both tower passes, refinement, pooling, projector, splice, all-position prefill logits, G greedy
+steps); the engine is compared at every stage boundary, on the all-position prefill logits, and on the per-step DECODE logits
+under TEACHER FORCING (the oracle's ids are fed, every step is compared, nothing stops at the first flip).
+
+Stated tolerances (bf16 arithmetic end to end, fp32 accumulation; the two sides differ in accumulation order and in where
+attention rounds P -- flash keeps fp32 scores and a bf16 P, HF-eager rounds the probabilities to bf16 after an fp32 softmax):
+  stage tensors      max|d| <= 3e-2 of the tensor's max (27-layer tower: 5e-2, it sums 26 residual updates)
+  logits             max|d| <= 6e-2 and rms <= 1.5e-2 of the logit range, over ALL positions / ALL steps
+  greedy ids         argmax equal wherever the oracle's top-1/top-2 margin exceeds 2x the max tolerance
+The measured numbers are printed and written to gpurun_out/fulldepth_parity_<config>.json."""
+import json
+import os
+import sys
+import time
+
+import pytest
+import torch
+
+from tests.util import assert_close, logit_parity_report, teacher_forced_decode_logits
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+LOGIT_MAX, LOGIT_RMS = 6e-2, 1.5e-2
+
+
+def _run(geom, regions, prompt_len, G):
+    from oracle import srgpt_oracle as so
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.model import LlavaLlamaModel
+    from spatialrgpt_amd.weights import synth_state_dict
+
+    cfg = getattr(SrgptConfig, geom)()
+    ocfg = so.SrgptConfig(**{k: v for k, v in cfg.to_dict().items() if k in so.SrgptConfig.__dataclass_fields__})
+    dtype = torch.bfloat16
+    t0 = time.perf_counter()
+    sd = synth_state_dict(cfg, seed=0, dtype=dtype, device=DEV)
+    w_cpu = {k: v.cpu() for k, v in sd.items()}  # the SAME weights for the checker (16 GB of host memory at the 8B shape)
+    model = LlavaLlamaModel(cfg, sd, device=DEV, dtype=dtype, rope_positions=1024, consume_state_dict=True)
+    del sd
+    eng = model.engine
+    ids, images, depths, masks = so.synth_inputs(ocfg, batch=1, regions=regions, prompt_len=prompt_len, seed=2, dtype=dtype)
+    t_build = time.perf_counter() - t0
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    ref_ids, st = so.generate(w_cpu, ocfg, ids, images, depths, masks, max_new_tokens=G, return_stages=True, model_dtype=dtype)
+    t_oracle = time.perf_counter() - t0
+    del w_cpu
+
+    got = {}
+    emb, _, lens = eng.prepare_inputs(ids.to(DEV), images.to(DEV), depths.to(DEV), [m.to(DEV) for m in masks], None, stages=got)
+    T = prompt_len - 1 + 196
+    assert emb.shape == (1, T, cfg.hidden) and lens == [T]
+    report = {"config": geom, "regions": regions, "prompt_len": prompt_len, "T": T, "G": G, "oracle_s": round(t_oracle, 1),
+              "build_s": round(t_build, 1), "oracle_threads": torch.get_num_threads(), "stages": {}}
+
+    def chk(a, b, what, rel=3e-2):
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        scale = float(b.abs().max()) + 1e-6
+        report["stages"][what] = {"max_abs_over_max": float((a - b).abs().max()) / scale,
+                                  "rms_over_max": float((a - b).pow(2).mean().sqrt()) / scale, "tol": rel}
+        assert_close(a, b, rel * scale, 0, what)
+
+    chk(got["tower_features"], st["tower_features"], "tower_features (26 ViT layers, RGB)", 5e-2)
+    chk(got["depth_features"], st["depth_features"], "depth_features (26 ViT layers, depth)", 5e-2)
+    chk(got["hres"], st["hres"], "hres")
+    chk(got["lres"], st["lres"], "lres")
+    chk(torch.stack(got["mask_embeds"]), torch.stack(st["mask_embeds"]), "mask_embeds")
+    chk(torch.stack(got["depth_embeds"]), torch.stack(st["depth_embeds"]), "depth_embeds")
+    chk(got["image_features"], st["image_features"], "image_features")
+    chk(emb, st["inputs_embeds"], "inputs_embeds")
+
+    # prefill over the ENGINE's own embeddings (end to end), logits at every position vs the oracle's
+    stt, logits, _ = eng.prefill(emb, max_new=G + 1, all_logits=True)
+    rp = logit_parity_report(logits, st["prefill_logits"], LOGIT_MAX, "prefill logits, all positions")
+    del logits
+    # decode path, teacher forced with the oracle's ids: every step compared
+    dec = teacher_forced_decode_logits(eng, stt, ref_ids)
+    rd = logit_parity_report(dec, st["step_logits"], LOGIT_MAX, "decode logits, teacher forced")
+    rd["own_argmax_equals_oracle_ids"] = int((dec.argmax(-1).cpu() == ref_ids).sum())
+    report["prefill"], report["decode"] = rp, rd
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"fulldepth_parity_{geom}.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    print("\nFULLDEPTH", json.dumps(report))
+    for r in (rp, rd):
+        assert r["max_abs_over_range"] <= LOGIT_MAX, r
+        assert r["rms_over_range"] <= LOGIT_RMS, r
+        assert r["argmax_disagree_out_of_margin"] == 0, r
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_full_depth_vila15_8b_config1_teacher_forced_vs_oracle():
+    _run("vila15_8b", regions=8, prompt_len=64, G=6)
+
+
+def test_full_depth_llama2_7b_config3_teacher_forced_vs_oracle():
+    _run("llama2_7b", regions=16, prompt_len=512, G=4)

@@ -6,78 +6,174 @@ import os
 import pytest
 import torch
 
+from tests.test_host_loader import write_checkpoint as _write_checkpoint
+from tests.test_host_loader import write_tiny_tokenizer  # noqa: F401
 from tests.util import load_tiny
 
 pytestmark = pytest.mark.gpu
 
 
-def _write_checkpoint(root, cfgd, w):
-    from safetensors.torch import save_file
-
-    os.makedirs(root, exist_ok=True)
-    groups = {"llm": {}, "vision_tower": {}, "mm_projector": {}, "region_extractor": {}}
-    for k, v in w.items():
-        if k.startswith("llm."):
-            groups["llm"][k[len("llm."):]] = v.contiguous()
-        elif k.startswith("vision_tower.vision_tower."):
-            groups["vision_tower"][k[len("vision_tower.vision_tower."):]] = v.contiguous()
-        elif k.startswith("mm_projector."):
-            groups["mm_projector"][k[len("mm_projector."):]] = v.contiguous()
-        elif k.startswith("region_extractor."):
-            groups["region_extractor"][k[len("region_extractor."):]] = v.contiguous()
-    for name, sd in groups.items():
-        os.makedirs(os.path.join(root, name), exist_ok=True)
-        save_file(sd, os.path.join(root, name, "model.safetensors"))
-    json.dump({"architectures": ["LlavaLlamaModel"], "model_type": "llava_llama", "enable_region": True, "enable_depth": True,
-               "mm_vision_select_layer": -2, "mm_vision_select_feature": "cls_patch", "image_aspect_ratio": "resize",
-               "mm_use_im_start_end": False, "mm_use_im_patch_token": False,
-               "llm_cfg": {"architectures": ["LlamaForCausalLM"]}, "vision_tower_cfg": {"architectures": ["SiglipVisionModel"]},
-               "mm_projector_cfg": {"mm_projector_type": "mlp_downsample"}, "region_extractor_cfg": {"region_extractor_type": "regiongpt"}},
-              open(os.path.join(root, "config.json"), "w"))
-    json.dump({"architectures": ["LlamaForCausalLM"], "model_type": "llama", "hidden_size": cfgd["hidden"], "intermediate_size": cfgd["inter"],
-               "num_hidden_layers": cfgd["layers"], "num_attention_heads": cfgd["heads"], "num_key_value_heads": cfgd["kv_heads"],
-               "vocab_size": cfgd["vocab"], "rms_norm_eps": cfgd["rms_eps"], "rope_theta": cfgd["rope_theta"],
-               "max_position_embeddings": 2048, "eos_token_id": 2, "bos_token_id": 1},
-              open(os.path.join(root, "llm", "config.json"), "w"))
-    json.dump({"architectures": ["SiglipVisionModel"], "model_type": "siglip_vision_model", "hidden_size": cfgd["vit_hidden"],
-               "intermediate_size": cfgd["vit_inter"], "num_hidden_layers": cfgd["vit_layers"],
-               "num_attention_heads": cfgd["vit_heads"], "image_size": cfgd["image_size"], "patch_size": cfgd["patch_size"],
-               "layer_norm_eps": cfgd["vit_eps"]},
-              open(os.path.join(root, "vision_tower", "config.json"), "w"))
-    json.dump({"image_processor_type": "SiglipImageProcessor", "size": {"height": cfgd["image_size"], "width": cfgd["image_size"]},
-               "image_mean": [0.5, 0.5, 0.5], "image_std": [0.5, 0.5, 0.5], "rescale_factor": 1 / 255.0, "do_normalize": True,
-               "do_resize": True, "do_rescale": True, "resample": 3},
-              open(os.path.join(root, "vision_tower", "preprocessor_config.json"), "w"))
-
-
-def test_load_pretrained_model_roundtrip(tmp_path):
-    from spatialrgpt_amd import load_pretrained_model
-
-    cfgd, dtype, w, inp, ref = load_tiny("tiny_bf16.npz")
+def _ckpt(tmp_path, name="tiny_bf16.npz"):
+    """synthetic checkpoint in the reference layout WITH tokenizer files: the checkpoint's embedding table has exactly the
+    tokenizer's base vocabulary, so the loader must add <mask>/<depth>, record their ids and grow the tables (builder.py:186-199)."""
+    cfgd, dtype, w, inp, ref = load_tiny(name)
+    base = 100  # sentencepiece pieces incl. <unk>/<s>/</s> (the trainer hits this size exactly on the toy corpus)
+    w = dict(w)
+    for k in ("llm.model.embed_tokens.weight", "llm.lm_head.weight"):
+        w[k] = w[k][:base].clone()
+    cfgd = dict(cfgd, vocab=base)
     root = str(tmp_path / "SpatialRGPT-tiny")
-    _write_checkpoint(root, cfgd, w)
+    _write_checkpoint(root, cfgd, w, tokenizer_vocab=base)
+    return root, cfgd, dtype, w, inp, ref
+
+
+def _remap_ids(ids, cfgd, model):
+    """fixture ids were minted for the fixture's vocabulary: move <mask>/<depth> to the loaded tokenizer's ids and fold the
+    other text ids into the (smaller) base vocabulary; the -200 sentinel stays."""
+    mid, did = model.config.mask_token_id, model.config.depth_token_id
+    out = ids.clone()
+    text = (ids >= 0) & (ids != cfgd["mask_token_id"]) & (ids != cfgd["depth_token_id"])
+    out[text] = 3 + ids[text] % (mid - 3)
+    out[ids == cfgd["mask_token_id"]] = mid
+    out[ids == cfgd["depth_token_id"]] = did
+    return out
+
+
+def test_load_pretrained_model_tokenizer_side_effects_and_roundtrip(tmp_path):
+    from spatialrgpt_amd import load_pretrained_model, tokenizer_image_token
+    from spatialrgpt_amd.constants import IMAGE_TOKEN_INDEX
+
+    root, cfgd, dtype, w, inp, ref = _ckpt(tmp_path)
     tokenizer, model, image_processor, context_len = load_pretrained_model(root, "SpatialRGPT-tiny")
+    assert tokenizer is not None, "the tokenizer written into the checkpoint must load"
     assert context_len == 2048 and image_processor is not None
     assert model.config.enable_region and model.config.enable_depth and model.config.vit_layers_run == cfgd["vit_layers"] - 1
-    # no tokenizer files in this synthetic checkpoint: ids come from the fixture (the token ids of <mask>/<depth> too)
-    model.config.mask_token_id, model.config.depth_token_id = cfgd["mask_token_id"], cfgd["depth_token_id"]
-    model.to(dtype=torch.bfloat16)  # the reference's callers do this; must be a no-op
-    out = model.generate(inp["input_ids"].cuda(), images=inp["images"].cuda(), depths=inp["depths"].cuda(),
-                         masks=[m.cuda() for m in inp["masks"]], do_sample=False, max_new_tokens=4, eos_token_id=None)
-    assert out.shape == (1, 4)
-    st = {}
-    model.engine.prepare_inputs(inp["input_ids"].cuda(), inp["images"].cuda(), inp["depths"].cuda(), [m.cuda() for m in inp["masks"]],
-                                None, stages=st)
-    err = (st["inputs_embeds"].float().cpu() - ref["inputs_embeds"].float()).abs().max().item()
-    assert err <= 3e-2 * ref["inputs_embeds"].float().abs().max().item()
+    # builder.py:186-192: <mask>/<depth> added as special tokens, ids recorded on the tower config, tables resized (builder.py:199)
+    mid, did = tokenizer.convert_tokens_to_ids("<mask>"), tokenizer.convert_tokens_to_ids("<depth>")
+    n_base = len(tokenizer) - 2
+    assert (mid, did) == (n_base, n_base + 1)
+    vt = model.get_vision_tower()
+    assert vt.config.llm_mask_token_id == mid and vt.config.llm_depth_token_id == did
+    assert model.config.mask_token_id == mid and model.config.depth_token_id == did
+    assert model.engine.w.vocab == len(tokenizer) == model.engine.w.lm_head.shape[0]
+    # new embedding rows = mean of the old ones (what resize_token_embeddings initialises them to)
+    old = w["llm.model.embed_tokens.weight"].float()
+    assert torch.allclose(model.engine.w.embed[mid].float().cpu(), old.mean(0).to(torch.bfloat16).float(), atol=1e-2)
+    # a real prompt through the reference's tokenisation path, then generate
+    prompt = "<image>\nhow far is region <mask> <depth> from region <mask> <depth> ?"
+    ids = tokenizer_image_token(prompt, tokenizer, IMAGE_TOKEN_INDEX, return_tensors="pt").unsqueeze(0).cuda()
+    assert int((ids == IMAGE_TOKEN_INDEX).sum()) == 1 and int((ids == mid).sum()) == 2 and int((ids == did).sum()) == 2
+    model.to(dtype=torch.bfloat16)  # eval_spatial.py:221
+    out = model.generate(ids, images=inp["images"].cuda(), depths=inp["depths"].cuda(), masks=[inp["masks"][0][:2].cuda()],
+                         do_sample=False, max_new_tokens=4, eos_token_id=None, pad_token_id=tokenizer.pad_token_id)
+    assert out.shape == (1, 4) and int(out.max()) < len(tokenizer)
+    assert isinstance(tokenizer.batch_decode(out, skip_special_tokens=True)[0], str)
+    with pytest.raises(IndexError):  # ids past the table: nn.Embedding semantics, not an out-of-bounds read
+        model.generate(torch.tensor([[1, len(tokenizer) + 5]]).cuda(), do_sample=False, max_new_tokens=1)
     with pytest.raises(NotImplementedError):
         load_pretrained_model(root, "x", load_4bit=True)
     # load_8bit -> weight-only fp8 for the streamed LLM matrices (the reference's bitsandbytes int8 slot, builder.py:51-52)
     _, m8, _, _ = load_pretrained_model(root, "SpatialRGPT-tiny", load_8bit=True)
     assert m8.engine.w.llm_weight_format == "fp8" and m8.engine.w.llm_q is not None
-    m8.config.mask_token_id, m8.config.depth_token_id = cfgd["mask_token_id"], cfgd["depth_token_id"]
-    out8 = m8.generate(inp["input_ids"].cuda(), images=inp["images"].cuda(), depths=inp["depths"].cuda(),
-                       masks=[m.cuda() for m in inp["masks"]], do_sample=False, max_new_tokens=4, eos_token_id=None)
+    out8 = m8.generate(ids, images=inp["images"].cuda(), depths=inp["depths"].cuda(), masks=[inp["masks"][0][:2].cuda()],
+                       do_sample=False, max_new_tokens=4, eos_token_id=None)
     assert out8.shape == (1, 4)
-    with pytest.raises(NotImplementedError):
-        model.to(dtype=torch.float16)
+
+
+def test_hf_registry_routes_reach_the_engine(tmp_path):
+    """llava_llama.py:216-217: AutoConfig / AutoModel know "llava_llama"; builder.py:142-158's own sequence
+    (AutoConfig.from_pretrained -> config.resume_path -> LlavaLlamaModel(config=..., low_cpu_mem_usage=True)) builds the engine."""
+    from transformers import AutoConfig, AutoModel
+
+    import spatialrgpt_amd
+    from spatialrgpt_amd.configuration import LlavaLlamaConfig
+
+    root, cfgd, dtype, w, inp, ref = _ckpt(tmp_path)
+    assert spatialrgpt_amd.LlavaLlamaModel.config_class is LlavaLlamaConfig
+    config = AutoConfig.from_pretrained(root)
+    assert isinstance(config, LlavaLlamaConfig) and config.enable_region and config.model_type == "llava_llama"
+    config.resume_path = root
+    config.model_dtype = "torch.bfloat16"  # prepare_config_for_eval (builder.py:228-240)
+    m1 = spatialrgpt_amd.LlavaLlamaModel(config=config, low_cpu_mem_usage=True)
+    m2 = AutoModel.from_pretrained(root, torch_dtype=torch.bfloat16)
+    for m in (m1, m2):
+        assert isinstance(m, spatialrgpt_amd.LlavaLlamaModel) and m.tokenizer is not None and m.dtype == torch.bfloat16
+        assert m.get_vision_tower().image_processor is not None
+    ids = _remap_ids(inp["input_ids"], cfgd, m1).cuda()
+    kw = dict(images=inp["images"].cuda(), depths=inp["depths"].cuda(), masks=[m_.cuda() for m_ in inp["masks"]], do_sample=False,
+              max_new_tokens=4, eos_token_id=None)
+    assert torch.equal(m1.generate(ids, **kw), m2.generate(ids, **kw))
+
+
+def test_reference_callers_dtype_flows(tmp_path):
+    """The dtype flow of every reference caller, replayed verbatim against the loaded model: none of them may raise, all of them
+    must produce the ids the bf16 flow produces (inputs are cast at the boundary, compute stays in the engine dtype)."""
+    from spatialrgpt_amd import load_pretrained_model
+
+    root, cfgd, dtype, w, inp, ref = _ckpt(tmp_path)
+    tokenizer, model, image_processor, _ = load_pretrained_model(root, "SpatialRGPT-tiny")
+    ids = _remap_ids(inp["input_ids"], cfgd, model)
+    images_tensor, depths_tensor, masks = inp["images"].float(), inp["depths"].float(), inp["masks"][0].float()  # processor output: fp32
+    input_ids = ids.to(device="cuda", non_blocking=True)
+    gen = dict(do_sample=False, temperature=0, top_p=None, num_beams=1, use_cache=True)
+
+    # eval_spatial.py:221-237
+    model.to(dtype=torch.bfloat16)
+    with torch.inference_mode():
+        want = model.generate(input_ids, images=images_tensor.to(dtype=torch.bfloat16, device="cuda", non_blocking=True),
+                              depths=depths_tensor.to(dtype=torch.bfloat16, device="cuda", non_blocking=True),
+                              masks=[masks.to(dtype=torch.bfloat16, device="cuda", non_blocking=True)], max_new_tokens=6,
+                              eos_token_id=None, **gen)
+    assert want.shape == (1, 6)
+
+    # eval_region_cls.py:313-325: fp16 images and masks, the model is never cast, no depths
+    with torch.inference_mode():
+        a16 = model.generate(input_ids, images=images_tensor.to(dtype=torch.float16, device="cuda", non_blocking=True),
+                             masks=[masks.to(dtype=torch.float16, device="cuda", non_blocking=True)], max_new_tokens=6,
+                             pad_token_id=tokenizer.pad_token_id, eos_token_id=None, **gen)
+        abf = model.generate(input_ids, images=images_tensor.to(dtype=torch.bfloat16, device="cuda"),
+                             masks=[masks.to(dtype=torch.bfloat16, device="cuda")], max_new_tokens=6, eos_token_id=None, **gen)
+    assert torch.equal(a16, abf)  # the fixture's pixels are multiples of 1/32: exact in fp16 and bf16 alike
+
+    # model_vqa.py:68-80: one image, .half().cuda(), no regions in the prompt
+    text_ids = input_ids[:, :4]
+    text_ids = torch.cat([text_ids[text_ids >= 0][None], torch.tensor([[-200]], device="cuda"), input_ids[:, 4:6].clamp(min=3)], 1)
+    with torch.inference_mode():
+        v = model.generate(text_ids, images=images_tensor[0].unsqueeze(0).half().cuda(), max_new_tokens=5, eos_token_id=None, **gen)
+    assert v.shape == (1, 5)
+
+    # demo/gradio_web_server_multi.py:171-213, both branches: fp16 tensors from process_*, model.to(selected_dtype), lists of tensors
+    from spatialrgpt_amd import KeywordsStoppingCriteria
+
+    for selected_dtype in (torch.bfloat16, torch.float16):
+        it = images_tensor.to("cuda", dtype=torch.float16)
+        dt_ = depths_tensor.to("cuda", dtype=torch.float16)
+        mt = masks.to("cuda", dtype=torch.float16)
+        with pytest.warns(UserWarning) if selected_dtype == torch.float16 else _nullcontext():
+            model.to(dtype=selected_dtype)
+        model._warned_dtype = False
+        sc = KeywordsStoppingCriteria(["</s>"], tokenizer, input_ids)
+        with torch.inference_mode():
+            d = model.generate(input_ids, images=[it.to(dtype=selected_dtype).cuda()], depths=[dt_.to(dtype=selected_dtype).cuda()],
+                               masks=[mt], do_sample=False, temperature=0, max_new_tokens=6, use_cache=True, stopping_criteria=[sc],
+                               eos_token_id=None)
+        assert torch.equal(d[:, :d.shape[1]], want[:, :d.shape[1]]) and d.shape[1] >= 1
+    assert model.half() is model and model.dtype == torch.bfloat16  # documented policy: interface request only
+
+    # module-level contract of the tower (vision_encoder.py:127-130): features return in the caller's image dtype
+    f16 = model.get_vision_tower()(images_tensor.half().cuda())
+    assert f16.dtype == torch.float16
+    # fp32 images into a bf16 engine (the processor's default output): same result as casting first (ADVICE r1 #1)
+    st32, stbf = {}, {}
+    model.engine.prepare_inputs(input_ids, images_tensor.cuda(), depths_tensor.cuda(), [masks.cuda()], None, stages=st32)
+    model.engine.prepare_inputs(input_ids, images_tensor.cuda().bfloat16(), depths_tensor.cuda().bfloat16(), [masks.cuda().bfloat16()],
+                                None, stages=stbf)
+    assert torch.equal(st32["inputs_embeds"], stbf["inputs_embeds"])
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False

@@ -1,0 +1,180 @@
+"""CPU: the loader's host-side effects (llava/model/builder.py:186-199, multimodal_encoder/*_encoder.py processors, the
+HF registry of llava_llama.py:216-217, vision_resolution position-embedding resize) on a synthetic checkpoint written in the
+reference's on-disk layout (llava_arch.py:181-250).  No engine is built here (that needs the GPU: tests/test_gpu_loader.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import GOLD, load_tiny
+
+
+def write_tiny_tokenizer(path, vocab_size):
+    """sentencepiece BPE tokenizer trained on a toy corpus + LlamaTokenizer config (no tokenizer ships offline)."""
+    import sentencepiece as spm
+
+    os.makedirs(path, exist_ok=True)
+    corpus = os.path.join(path, "_corpus.txt")
+    words = ("the quick brown fox jumps over lazy dog region mask depth image left right behind front wide tall big small "
+             "distance between and of is how far from to what which object meters").split()
+    with open(corpus, "w") as f:
+        for i in range(400):
+            f.write(" ".join(words[(i * 7 + j * 3) % len(words)] for j in range(9)) + "\n")
+    spm.SentencePieceTrainer.train(input=corpus, model_prefix=os.path.join(path, "tokenizer"), vocab_size=vocab_size, model_type="bpe",
+                                   bos_id=1, eos_id=2, unk_id=0, pad_id=-1, character_coverage=1.0, hard_vocab_limit=False, minloglevel=2)
+    os.remove(corpus)
+    json.dump({"tokenizer_class": "LlamaTokenizer", "bos_token": "<s>", "eos_token": "</s>", "unk_token": "<unk>", "add_bos_token": True,
+               "add_eos_token": False, "model_max_length": 4096, "legacy": False}, open(os.path.join(path, "tokenizer_config.json"), "w"))
+
+
+def write_checkpoint(root, cfgd, w, tokenizer_vocab=None):
+    from safetensors.torch import save_file
+
+    os.makedirs(root, exist_ok=True)
+    groups = {"llm": {}, "vision_tower": {}, "mm_projector": {}, "region_extractor": {}}
+    for k, v in w.items():
+        if k.startswith("llm."):
+            groups["llm"][k[len("llm."):]] = v.contiguous()
+        elif k.startswith("vision_tower.vision_tower."):
+            groups["vision_tower"][k[len("vision_tower.vision_tower."):]] = v.contiguous()
+        elif k.startswith("mm_projector."):
+            groups["mm_projector"][k[len("mm_projector."):]] = v.contiguous()
+        elif k.startswith("region_extractor."):
+            groups["region_extractor"][k[len("region_extractor."):]] = v.contiguous()
+    for name, sd in groups.items():
+        os.makedirs(os.path.join(root, name), exist_ok=True)
+        save_file(sd, os.path.join(root, name, "model.safetensors"))
+    json.dump({"architectures": ["LlavaLlamaModel"], "model_type": "llava_llama", "enable_region": True, "enable_depth": True,
+               "mm_vision_select_layer": -2, "mm_vision_select_feature": "cls_patch", "image_aspect_ratio": "resize",
+               "mm_use_im_start_end": False, "mm_use_im_patch_token": False,
+               "llm_cfg": {"architectures": ["LlamaForCausalLM"]}, "vision_tower_cfg": {"architectures": ["SiglipVisionModel"]},
+               "mm_projector_cfg": {"mm_projector_type": "mlp_downsample"}, "region_extractor_cfg": {"region_extractor_type": "regiongpt"}},
+              open(os.path.join(root, "config.json"), "w"))
+    json.dump({"architectures": ["LlamaForCausalLM"], "model_type": "llama", "hidden_size": cfgd["hidden"], "intermediate_size": cfgd["inter"],
+               "num_hidden_layers": cfgd["layers"], "num_attention_heads": cfgd["heads"], "num_key_value_heads": cfgd["kv_heads"],
+               "vocab_size": cfgd["vocab"], "rms_norm_eps": cfgd["rms_eps"], "rope_theta": cfgd["rope_theta"],
+               "max_position_embeddings": 2048, "eos_token_id": 2, "bos_token_id": 1},
+              open(os.path.join(root, "llm", "config.json"), "w"))
+    json.dump({"architectures": ["SiglipVisionModel"], "model_type": "siglip_vision_model", "hidden_size": cfgd["vit_hidden"],
+               "intermediate_size": cfgd["vit_inter"], "num_hidden_layers": cfgd["vit_layers"],
+               "num_attention_heads": cfgd["vit_heads"], "image_size": cfgd["image_size"], "patch_size": cfgd["patch_size"],
+               "layer_norm_eps": cfgd["vit_eps"]},
+              open(os.path.join(root, "vision_tower", "config.json"), "w"))
+    json.dump({"image_processor_type": "SiglipImageProcessor", "size": {"height": cfgd["image_size"], "width": cfgd["image_size"]},
+               "image_mean": [0.5, 0.5, 0.5], "image_std": [0.5, 0.5, 0.5], "rescale_factor": 1 / 255.0, "do_normalize": True,
+               "do_resize": True, "do_rescale": True, "resample": 3},
+              open(os.path.join(root, "vision_tower", "preprocessor_config.json"), "w"))
+    if tokenizer_vocab:
+        write_tiny_tokenizer(os.path.join(root, "llm"), tokenizer_vocab)
+
+
+
+
+def _ckpt(tmp_path, name="tiny_fp32.npz", base=100):
+    cfgd, dtype, w, inp, ref = load_tiny(name)
+    w = dict(w)
+    for k in ("llm.model.embed_tokens.weight", "llm.lm_head.weight"):
+        w[k] = w[k][:base].clone()
+    cfgd = dict(cfgd, vocab=base)
+    root = str(tmp_path / "SpatialRGPT-tiny")
+    write_checkpoint(root, cfgd, w, tokenizer_vocab=base)
+    return root, cfgd, w
+
+
+def test_tokenizer_side_effects_of_the_loader(tmp_path):
+    """builder.py:186-199 without a GPU: special tokens added in the reference's order, ids recorded, tables grown by the
+    mean row, eos/pad taken from the tokenizer."""
+    from spatialrgpt_amd import tokenizer_image_token
+    from spatialrgpt_amd.builder import load_tokenizer, read_checkpoint
+
+    root, cfgd, w = _ckpt(tmp_path)
+    cfg, sd = read_checkpoint(root)
+    assert cfg.vocab == 100 and cfg.enable_region and cfg.enable_depth and cfg.tower == "siglip"
+    tok = load_tokenizer(root, cfg, sd)
+    assert tok is not None and len(tok) == 102
+    assert (cfg.mask_token_id, cfg.depth_token_id) == (100, 101) == (tok.convert_tokens_to_ids("<mask>"), tok.convert_tokens_to_ids("<depth>"))
+    assert cfg.vocab == 102 and sd["llm.model.embed_tokens.weight"].shape[0] == 102 and sd["llm.lm_head.weight"].shape[0] == 102
+    old = w["llm.model.embed_tokens.weight"].float()
+    assert torch.allclose(sd["llm.model.embed_tokens.weight"][100].float(), old.mean(0), atol=1e-6)
+    assert torch.equal(sd["llm.model.embed_tokens.weight"][:100], w["llm.model.embed_tokens.weight"])
+    assert cfg.eos_token_id == 2
+    ids = tokenizer_image_token("<image>\nhow far is region <mask> <depth> ?", tok, return_tensors="pt")
+    assert ids[0] == tok.bos_token_id and int((ids == -200).sum()) == 1 and 100 in ids.tolist() and 101 in ids.tolist()
+    # mm_use_im_patch_token / mm_use_im_start_end add their tokens AFTER <mask>/<depth> (builder.py:193-198)
+    cfg2, sd2 = read_checkpoint(root)
+    cfg2.mm_use_im_patch_token, cfg2.mm_use_im_start_end = True, True
+    tok2 = load_tokenizer(root, cfg2, sd2)
+    assert len(tok2) == 105 and tok2.convert_tokens_to_ids("<im_patch>") == 102 and cfg2.vocab == 105
+
+
+def test_hf_registry_resolves_llava_llama(tmp_path):
+    """llava_llama.py:216-217 on the host: AutoConfig maps "llava_llama" to our config class, the reference's top-level fields
+    survive the round trip, and AutoModel is wired to LlavaLlamaModel (whose construction needs the GPU)."""
+    from transformers import AutoConfig
+    from transformers.models.auto.modeling_auto import MODEL_MAPPING
+
+    import spatialrgpt_amd
+    from spatialrgpt_amd.configuration import LlavaConfig, LlavaLlamaConfig
+
+    root, cfgd, w = _ckpt(tmp_path)
+    model_cls = spatialrgpt_amd.LlavaLlamaModel  # importing the model module performs the registration
+    config = AutoConfig.from_pretrained(root)
+    assert isinstance(config, LlavaLlamaConfig) and isinstance(config, LlavaConfig)
+    assert config.model_type == "llava_llama" and config.enable_region is True and config.enable_depth is True
+    assert config.mm_vision_select_layer == -2 and config.mm_vision_select_feature == "cls_patch"
+    assert config.mm_projector_cfg == {"mm_projector_type": "mlp_downsample"} and config.resume_path is None
+    assert config.checkpoint_root() == root  # _name_or_path, as llava/model/utils.py:28-31 resolves it
+    assert MODEL_MAPPING[LlavaLlamaConfig] is model_cls and model_cls.config_class is LlavaLlamaConfig
+    c2 = LlavaLlamaConfig(enable_region=True, resume_path="/x", vision_resolution=336)
+    assert c2.checkpoint_root() == "/x" and c2.vision_resolution == 336 and c2.mm_use_im_patch_token is True
+    d = c2.to_dict()
+    assert d["model_type"] == "llava_llama" and d["resume_path"] == "/x"
+
+
+def test_clip_checkpoint_gets_clip_image_processor(tmp_path):
+    """clip_encoder.py:8-13: CLIP towers come with a CLIPImageProcessor (shortest-edge resize + centre crop, `crop_size`)."""
+    from spatialrgpt_amd.builder import config_from_checkpoint, load_image_processor
+
+    cfgd, dtype, w, inp, ref = load_tiny("tiny_clip_fp32.npz")
+    root = str(tmp_path / "clip")
+    write_checkpoint(root, cfgd, w)
+    json.dump({"architectures": ["CLIPVisionModel"], "model_type": "clip_vision_model", "hidden_size": cfgd["vit_hidden"],
+               "intermediate_size": cfgd["vit_inter"], "num_hidden_layers": cfgd["vit_layers"], "num_attention_heads": cfgd["vit_heads"],
+               "image_size": cfgd["image_size"], "patch_size": cfgd["patch_size"], "layer_norm_eps": cfgd["vit_eps"]},
+              open(os.path.join(root, "vision_tower", "config.json"), "w"))
+    S = cfgd["image_size"]
+    json.dump({"image_processor_type": "CLIPImageProcessor", "do_resize": True, "size": {"shortest_edge": S}, "do_center_crop": True,
+               "crop_size": {"height": S, "width": S}, "do_rescale": True, "rescale_factor": 1 / 255.0, "do_normalize": True,
+               "image_mean": [0.48145466, 0.4578275, 0.40821073], "image_std": [0.26862954, 0.26130258, 0.27577711], "resample": 3,
+               "do_convert_rgb": True}, open(os.path.join(root, "vision_tower", "preprocessor_config.json"), "w"))
+    cfg = config_from_checkpoint(root)
+    assert cfg.tower == "clip"
+    proc = load_image_processor(root, cfg)
+    assert "CLIP" in type(proc).__name__ or getattr(proc, "center_crop", False)
+    assert proc.crop_size["height"] == S and abs(proc.image_mean[0] - 0.48145466) < 1e-6
+
+
+def test_vision_resolution_position_embedding_resize_matches_reference_kat(tmp_path):
+    """`VisionTower._maybe_resize_pos_embeds` (vision_encoder.py:36-113, "linear"): tests/golden/posembed_kat.npz was minted by
+    running the reference's own method (oracle/make_golden.py) -- bit-identical here; and the loader applies it: a 27x27-token
+    SigLIP-style checkpoint read with vision_resolution=336 has 24x24 = 576 rows and a 336-px processor."""
+    from spatialrgpt_amd.builder import load_image_processor, read_checkpoint, resize_position_embeddings
+
+    z = np.load(os.path.join(GOLD, "posembed_kat.npz"))
+    for tag in ("up", "down"):
+        old, new = torch.from_numpy(z[f"{tag}_old"]), torch.from_numpy(z[f"{tag}_new"])
+        got = resize_position_embeddings(old, new.shape[0])
+        assert got.shape == new.shape and torch.equal(got, new), f"{tag}: max diff {float((got - new).abs().max())}"
+    root, cfgd, w = _ckpt(tmp_path)
+    S, p = cfgd["image_size"], cfgd["patch_size"]
+    res = (S // p - 3) * p
+    cfg, sd = read_checkpoint(root, vision_resolution=res)
+    key = "vision_tower.vision_tower.vision_model.embeddings.position_embedding.weight"
+    assert cfg.image_size == res and sd[key].shape[0] == (res // p) ** 2 == cfg.tower_tokens
+    assert torch.equal(sd[key].float(), resize_position_embeddings(w[key].float(), (res // p) ** 2).to(w[key].dtype).float())
+    proc = load_image_processor(root, cfg)
+    assert proc.size["height"] == res and proc.size["width"] == res
+    with pytest.raises(NotImplementedError):
+        read_checkpoint(root, vision_resolution=res, interpolate_mode="bicubic")

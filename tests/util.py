@@ -45,11 +45,54 @@ def max_err(a, b):
     return (a.detach().float().cpu() - b.detach().float().cpu()).abs().max().item()
 
 
+def _log_measured(what, err, ref, atol):
+    """SRGPT_PARITY_LOG=<file>: append the measured error of every comparison (so tolerances are set from data)."""
+    path = os.environ.get("SRGPT_PARITY_LOG")
+    if not path or not err.numel():
+        return
+    scale = float(ref.abs().max()) + 1e-30
+    with open(path, "a") as f:
+        f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), "what": what, "max_err_over_ref_max": float(err.max()) / scale,
+                            "atol_over_ref_max": atol / scale, "dtype_note": str(ref.dtype)}) + "\n")
+
+
 def assert_close(a, b, atol, rtol=0.0, what=""):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     err = (a - b).abs()
     tol = atol + rtol * b.abs()
+    _log_measured(what, err, b, atol)
     bad = err > tol
     assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance, "
                                  f"max err {err.max().item():.4e} (ref max {b.abs().max().item():.4e})")
+
+
+def teacher_forced_decode_logits(eng, st, teacher_ids):
+    """Per-step logits of the DECODE path under teacher forcing: `st` is the state a prefill just returned (st.logits =
+    logits of the last prompt position = step 0); teacher_ids [B, G] are the ids the checker (oracle / reference golden)
+    generated.  Step t+1 feeds teacher_ids[:, t] through `eng.step` (GEMV kernels + decode attention over the appended cache),
+    whatever the engine's own argmax was, so EVERY step is compared -- an in-margin flip never hides the rest.
+    Returns fp32 [B, G, V]."""
+    out = [st.logits.clone()]
+    G = teacher_ids.shape[1]
+    for t in range(G - 1):
+        out.append(eng.step(st, teacher_ids[:, t:t + 1].to(eng.device)))
+    return torch.stack(out, dim=1)
+
+
+def logit_parity_report(got, ref, tol_rel, what=""):
+    """got/ref fp32 [..., V].  Returns a dict: max|d| and rms as fractions of the reference logit range, argmax agreement, and
+    the number of argmax disagreements whose reference top-1/top-2 margin exceeds 2*tol (those are failures)."""
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    rng = float(ref.abs().max())
+    d = got - ref
+    flat_g, flat_r = got.reshape(-1, got.shape[-1]), ref.reshape(-1, ref.shape[-1])
+    top2 = flat_r.topk(2, dim=-1).values
+    margin = top2[:, 0] - top2[:, 1]
+    agree = flat_g.argmax(-1) == flat_r.argmax(-1)
+    bad = (~agree) & (margin > 2 * tol_rel * rng)
+    return {"what": what, "rows": int(flat_r.shape[0]), "logit_range": rng, "max_abs_over_range": float(d.abs().max()) / rng,
+            "rms_over_range": float(d.pow(2).mean().sqrt()) / rng, "argmax_agree": int(agree.sum()),
+            "argmax_disagree_in_margin": int((~agree).sum() - bad.sum()), "argmax_disagree_out_of_margin": int(bad.sum()),
+            "tol_rel": tol_rel}
