@@ -2,7 +2,9 @@
 """bench.py -- region-grounded output tokens/sec of the MI355X path (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 works both ways: under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (the
+  ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env) and as a plain `python bench.py --gpus N`, which forks its
+  own N ranks -- one process per GPU, like the reference's launcher (scripts/srgpt/eval/srgpt_bench.sh:23-34) -- over RCCL.
 
 One "step" = one whole request pass per rank: synthetic 384x384 image + depth map (SigLIP-so400m geometry; the
 "336 px" of the metric name is not reachable with the shipped tower), 8 region masks, a
@@ -37,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="vila15_8b", choices=["vila15_8b", "llama2_7b", "sheared_3b", "tiny"])
+    ap.add_argument("--model", default="vila15_8b", choices=["vila15_8b", "vila15_8b_clip336", "llama2_7b", "sheared_3b", "tiny"])
     ap.add_argument("--regions", type=int, default=8)
     ap.add_argument("--prompt-len", type=int, default=64)
     ap.add_argument("--max-new-tokens", type=int, default=128)
@@ -46,7 +48,42 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="equal-length requests per generate() call per GPU")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8 = BASELINE configs[4]: weight-only OCP e4m3fn for the streamed LLM matrices (W8A16); NOT the headline")
-    return ap.parse_args()
+    ap.add_argument("--preset", default=None, choices=["config1", "config2", "config3", "config4"],
+                    help="BASELINE.json configs[i] per-GPU shape: config1 = bs 1 (default); config2 = bs 32 over 8 GPUs = 4 requests "
+                         "per GPU; config3 = llama2_7b, 16 regions, 512-id prompt; config4 = fp8 weights, bs 64 over 8 GPUs = 8 per GPU")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="no model, no GPU: the N ranks only rendezvous (gloo), exchange fake ids through the same gather and print "
+                         "the rank-0 line -- checks the self-launch / rendezvous / gather plumbing on a CPU box")
+    ap.add_argument("--cpu-decode-steps", type=int, default=12, help="decode steps the CPU baseline measures (full depth)")
+    a = ap.parse_args()
+    if a.preset == "config2":
+        a.batch = 4
+    elif a.preset == "config3":
+        a.model, a.regions, a.prompt_len = "llama2_7b", 16, 512
+    elif a.preset == "config4":
+        a.weights, a.batch = "fp8", 8
+    return a
+
+
+def workload_name(args, cfg, T):
+    geo = {"vila15_8b": "SpatialRGPT-VILA1.5-8B geometry (Llama-3-8B 32L/4096/GQA-8 + SigLIP-so400m 384px x2 passes + regiongpt "
+                        "extractor + mlp_downsample)",
+           "vila15_8b_clip336": "VILA1.5-8B LLM geometry behind the CLIP-L/14-336 tower (the only true 336-px tower: 577 tokens, "
+                                "select_feature=patch -> 576)",
+           "llama2_7b": "SpatialRGPT llama2_7b geometry (Llama-2-7B 32L/4096/MHA-32 + SigLIP-so400m 384px x2 passes)",
+           "sheared_3b": "SpatialRGPT sheared_3b geometry (Sheared-LLaMA-2.7B 32L/2560/MHA-20 + SigLIP-so400m)", "tiny": "tiny plumbing model"}
+    if args.model == "vila15_8b" and args.weights == "bf16" and args.batch == 1 and args.regions == 8:
+        tag = "BASELINE configs[1]"
+    elif args.model == "vila15_8b" and args.weights == "bf16" and args.batch == 4 and args.regions == 8:
+        tag = "BASELINE configs[2] per-GPU shape (bs 32 over 8 GPUs = 4 requests per GPU)"
+    elif args.model == "llama2_7b" and args.regions == 16 and args.prompt_len == 512:
+        tag = "BASELINE configs[3]"
+    elif args.model == "vila15_8b" and args.weights == "fp8" and args.batch == 8:
+        tag = "BASELINE configs[4] per-GPU shape (fp8 LLM weights, bs 64 over 8 GPUs = 8 requests per GPU)"
+    else:
+        tag = "non-BASELINE variant"
+    return (f"{tag}: {geo[args.model]}, {args.regions} region masks, bs={args.batch} per GPU, prompt {args.prompt_len} ids -> "
+            f"T={T}, greedy {args.max_new_tokens} new tokens")
 
 
 def make_cfg(name):
@@ -55,6 +92,8 @@ def make_cfg(name):
     if name == "tiny":
         return SrgptConfig(vit_hidden=64, vit_inter=176, vit_layers=3, vit_heads=4, image_size=378, hidden=64, inter=160,
                            layers=2, heads=4, kv_heads=2, vocab=128, mask_token_id=120, depth_token_id=121)
+    if name == "vila15_8b_clip336":
+        return SrgptConfig.clip_l14_336()
     return getattr(SrgptConfig, name)()
 
 
@@ -86,16 +125,15 @@ def synth_request(cfg, regions, prompt_len, seed, device, dtype):
     return torch.tensor([seq], device=device), images, depths, masks
 
 
-def cpu_baseline(cfg, sd_cpu, regions, prompt_len, n_llm, n_vit):
-    """The oracle (CPU restatement of the reference's path, oracle/srgpt_oracle.py) on the host cores, bounded:
-    true widths, n_llm of cfg.layers decoder layers + lm_head, n_vit of the tower layers, G = 4 decode steps;
-    per-layer times are scaled to full depth.  Checker/baseline only -- never part of the measured GPU path."""
+def cpu_baseline(cfg, sd_cpu, regions, prompt_len, g_cpu):
+    """The oracle (CPU restatement of the reference's path, oracle/srgpt_oracle.py) on the host cores at FULL depth and true
+    widths: both tower passes, refinement / pooling / projector / splice, the T-position prefill with lm_head on every row (as the
+    reference computes it) and `g_cpu` greedy decode steps -- every stage of the request is measured, only the decode-step count
+    is bounded (the per-step cost is flat over 128 steps: the context grows from T to T+128).  Checker/baseline only."""
     from oracle import srgpt_oracle as so
 
     names = so.SrgptConfig.__dataclass_fields__
-    d = {k: v for k, v in cfg.to_dict().items() if k in names}
-    d.update(layers=n_llm, vit_layers=n_vit + 1)  # select_layer=-2 -> runs n_vit layers
-    ocfg = so.SrgptConfig(**d)
+    ocfg = so.SrgptConfig(**{k: v for k, v in cfg.to_dict().items() if k in names})
     # thread count: probed on the 256-core bench host (scripts/cpu_probe.py) -- torch's CPU bf16 path is fastest
     # at 16 threads (22.9 ms / 2-layer decode step) and collapses beyond 64 (5.1 s at 256 threads)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -104,7 +142,7 @@ def cpu_baseline(cfg, sd_cpu, regions, prompt_len, n_llm, n_vit):
     with torch.no_grad():
         t0 = time.perf_counter()
         tower = so.vit_forward(sd_cpu, ocfg, torch.cat([images, depths], 0))
-        t["vit"] = time.perf_counter() - t0
+        t["vit_x2"] = time.perf_counter() - t0
         t0 = time.perf_counter()
         hres, lres = so.feature_refinement(sd_cpu, tower[:1])
         me, de = so.region_extractor(sd_cpu, hres, tower[1:], masks)
@@ -116,40 +154,79 @@ def cpu_baseline(cfg, sd_cpu, regions, prompt_len, n_llm, n_vit):
         t0 = time.perf_counter()
         logits = so.llama_forward(sd_cpu, ocfg, emb, torch.arange(T)[None], kv)
         t["prefill"] = time.perf_counter() - t0
-        # lm_head-only cost (all rows, as the reference computes it) to separate depth-dependent from fixed cost
-        x = torch.randn((1, T, ocfg.hidden)).to(torch.bfloat16)
-        t0 = time.perf_counter()
-        torch.nn.functional.linear(x, sd_cpu["llm.lm_head.weight"])
-        t["lm_head_prefill"] = time.perf_counter() - t0
         nxt = logits[:, -1].argmax(-1)
-        G = 4
         t0 = time.perf_counter()
-        for s in range(G):
+        for s in range(g_cpu):
             e = torch.nn.functional.embedding(nxt[:, None], sd_cpu["llm.model.embed_tokens.weight"])
             logits = so.llama_forward(sd_cpu, ocfg, e, torch.tensor([[T + s]]), kv, last_only=True)
             nxt = logits[:, -1].argmax(-1)
-        t["decode_step"] = (time.perf_counter() - t0) / G
-        x1 = torch.randn((1, 1, ocfg.hidden)).to(torch.bfloat16)
-        t0 = time.perf_counter()
-        for _ in range(3):
-            torch.nn.functional.linear(x1, sd_cpu["llm.lm_head.weight"])
-        t["lm_head_decode"] = (time.perf_counter() - t0) / 3
-    Lf, Vf = cfg.layers, cfg.vit_layers  # the reference executes all tower layers
-    vit_full = t["vit"] * Vf / n_vit
-    prefill_full = (t["prefill"] - t["lm_head_prefill"]) * Lf / n_llm + t["lm_head_prefill"]
-    dec_full = (t["decode_step"] - t["lm_head_decode"]) * Lf / n_llm + t["lm_head_decode"]
-    return t, vit_full, prefill_full, dec_full, t["region_proj_splice"]
+        t["decode_step"] = (time.perf_counter() - t0) / max(1, g_cpu)
+    return t
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: fork N ranks of this script (one process per GPU, the reference's
+    srgpt_bench.sh pattern), rendezvous on 127.0.0.1, pass rank 0's JSON line through.  Exit code = worst rank's."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so_:
+        so_.bind(("127.0.0.1", 0))
+        port = so_.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SRGPT_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def launcher_selftest(args):
+    """plumbing check of the N>1 leg without a model: rendezvous, barrier, ragged-safe id gather, one rank-0 JSON line."""
+    import torch.distributed as dist
+
+    from spatialrgpt_amd.dist import gather_ids, init_distributed
+
+    rank, world, _ = init_distributed(backend="gloo")
+    assert world == args.gpus
+    G = args.max_new_tokens
+    ids = torch.full((args.batch, G), rank, dtype=torch.int64)
+    out = gather_ids(ids)
+    if world > 1:
+        dist.barrier()
+    assert out.shape == (world * args.batch, G) and all(int(out[r * args.batch, 0]) == r for r in range(world))
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "world_size_seen": world, "gathered_rows": int(out.shape[0]),
+                          "launcher": "self" if os.environ.get("SRGPT_BENCH_SELF_LAUNCHED") else "external"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.selftest_launcher:
+        return launcher_selftest(args)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
     from spatialrgpt_amd.dist import gather_ids, init_distributed
 
-    rank, world, local = init_distributed()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
-    device = torch.device("cuda", local if torch.cuda.device_count() > local else 0)
+    ndev = torch.cuda.device_count()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    local_env = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    # fewer devices than ranks (a 1-GPU box asked for --gpus 2): ranks share devices round-robin; RCCL refuses two ranks on one
+    # device, so that case rendezvous over gloo (the exchange is 1 KB of ids per rank) -- said so in the JSON line
+    shared = world_env > ndev
+    device = torch.device("cuda", local_env % ndev)
     torch.cuda.set_device(device)
+    rank, world, local = init_distributed(backend="gloo" if shared else None)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import torch.distributed as dist
 
     from spatialrgpt_amd import _lib as L
@@ -162,18 +239,10 @@ def main():
     G = args.max_new_tokens
     t_build = time.perf_counter()
     sd = synth_state_dict(cfg, seed=0, dtype=dtype, device=device)
-    # bounded CPU-baseline sample: copy the first layers' weights to the host before the engine consumes them
-    n_llm_s, n_vit_s = min(2, cfg.layers), min(2, cfg.vit_layers_run)
+    # CPU baseline runs the SAME weights at full depth: copy them to the host before the engine consumes them
     sd_cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        keep = []
-        for k in sd:
-            if k.startswith("llm.model.layers.") or ".encoder.layers." in k:
-                idx = int(k.split(".layers.")[1].split(".")[0])
-                if idx >= (n_llm_s if k.startswith("llm.") else n_vit_s):
-                    continue
-            keep.append(k)
-        sd_cpu = {k: sd[k].cpu() for k in keep}
+        sd_cpu = {k: v.cpu() for k, v in sd.items()}
     model = LlavaLlamaModel(cfg, sd, device=device, dtype=dtype, rope_positions=1024, consume_state_dict=True,
                             llm_weight_format="fp8" if args.weights == "fp8" else "native")
     del sd
@@ -204,13 +273,24 @@ def main():
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert out.shape[-1] == G
+    assert out.shape[-1] == G and out.shape[0] == world * args.batch, out.shape
     tokens = world * args.steps * G * args.batch
     value = tokens / dt
+    dist_info = {"launcher": "self (bench.py forked its ranks)" if os.environ.get("SRGPT_BENCH_SELF_LAUNCHED") else
+                 ("torch.distributed.run" if world > 1 else "single process"), "world_size_seen": world}
+    if world > 1:
+        mine = torch.tensor([args.steps * G * args.batch / dt_local, float(device.index)], dtype=torch.float64,
+                            device=device if dist.get_backend() == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dist_info.update(backend=("rccl (torch backend 'nccl')" if dist.get_backend() == "nccl" else dist.get_backend()),
+                         per_rank_tokens_per_s=[round(float(t[0]), 2) for t in allr], rank_devices=[int(t[1]) for t in allr],
+                         devices_visible=ndev, ranks_share_devices=bool(shared))
 
     # ---------------- roofline of the dominant kernel: decode weight-streaming GEMV (gate/up + SwiGLU) --------
     # measured live with events on the launch stream, cycling over all layers' matrices (7.5 GB >> 256 MB L3)
@@ -255,14 +335,19 @@ def main():
         torch.cuda.synchronize()
         dec_ms = e0.elapsed_time(e1) / G
         wbytes = eng.w.llm_weight_bytes()
-        traffic = None  # HBM bytes per launch from the PMC pass (separate rocprofv3 --pmc run, 2x FETCH_SIZE correction)
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")
+        # HBM bytes per launch: PMC counters cannot be read from inside this process -- the figure comes from the tracked
+        # summary of a separate `rocprofv3 --pmc FETCH_SIZE` pass over this same command (x2 gfx950 correction), and says so
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemv.json")
+        if not os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")
         if args.model == "vila15_8b" and os.path.exists(pmc) and not fp8:
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+            traffic_src = f"static: {os.path.relpath(pmc, ROOT)} (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction; not measured in this run)"
         roof = {"bound": "hbm", "kernel": ("skinny_kernel<swiglu, W8> (decode gate/up projection, fp8 weights)" if fp8 else
                                            "gemv_kernel<bf16,1,swiglu> (decode gate/up projection, 54% of streamed bytes)"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5),
+                "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5),
                 "how": "hip events around each launch on the launch stream, 3 sweeps over the 32 layers' matrices (cold in L3)",
                 "decode_ms_per_token": round(dec_ms, 4), "decode_weight_bytes_per_token": wbytes,
                 "decode_hbm_gbs_whole_step": round(wbytes / (dec_ms * 1e-3) / 1e9, 1),
@@ -270,27 +355,28 @@ def main():
 
     cpu = None
     if sd_cpu is not None:
-        t, vit_full, prefill_full, dec_full, misc = cpu_baseline(cfg, sd_cpu, args.regions, args.prompt_len, n_llm_s, n_vit_s)
-        total = vit_full + misc + prefill_full + (G - 1) * dec_full
+        g_cpu = max(1, args.cpu_decode_steps)
+        t = cpu_baseline(cfg, sd_cpu, args.regions, args.prompt_len, g_cpu)
+        del sd_cpu
+        total = t["vit_x2"] + t["region_proj_splice"] + t["prefill"] + (G - 1) * t["decode_step"]
         cpu = {"value": round(G / total, 4), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": (f"oracle (CPU restatement of the reference path, bf16) at true widths on {n_llm_s}/{cfg.layers} LLM layers + "
-                          f"lm_head and {n_vit_s}/{cfg.vit_layers} ViT layers x2 images, prefill T=259 + 4 decode steps; per-layer "
-                          f"times scaled to full depth (est. per request: vision {vit_full:.1f}s, prefill {prefill_full:.1f}s, "
-                          f"decode {dec_full * 1e3:.0f} ms/token)"),
+               "sample": (f"oracle (CPU restatement of the reference path, bf16, same weights) at FULL depth ({cfg.layers} LLM layers, "
+                          f"{cfg.vit_layers_run} ViT layers x2 images) on one request: vision {t['vit_x2']:.2f}s + region/projector/splice "
+                          f"{t['region_proj_splice']:.2f}s + prefill(T={args.prompt_len - 1 + 196}, lm_head on all rows) {t['prefill']:.2f}s "
+                          f"measured once, {g_cpu} of the {G} decode steps measured ({t['decode_step'] * 1e3:.0f} ms/token) and scaled "
+                          f"to {G - 1}"),
                "measured_s": {k: round(v, 4) for k, v in t.items()}}
 
     if rank == 0:
         line = {
-            "metric": "region-grounded output tokens/sec @ VILA1.5-8B, 8 regions, greedy",
+            "metric": f"region-grounded output tokens/sec @ {'VILA1.5-8B' if args.model.startswith('vila15_8b') else args.model}, {args.regions} regions, greedy",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.weights == "bf16" else "bf16 activations / fp8-e4m3fn LLM weights (W8A16)", "data": "synthetic (seeded random weights of the named architecture; random images/depth/box masks/ids)",
-            "config": {"workload": ("BASELINE configs[1]: SpatialRGPT-VILA1.5-8B geometry (Llama-3-8B 32L/4096/GQA-8 + SigLIP-so400m "
-                                    "384px x2 passes + regiongpt extractor + mlp_downsample), 8 region masks, bs=1 per GPU, "
-                                    f"prompt {args.prompt_len} ids -> T=259, greedy {G} new tokens") if args.model == "vila15_8b" else args.model,
+            "config": {"workload": workload_name(args, cfg, args.prompt_len - 1 + 196),
                        "requests_per_step_per_gpu": args.batch, "new_tokens_per_request": G, "parallelism": f"dp{world}",
                        "decode": "hipGraph" if not args.no_graph else "eager", "build_s": round(t_build, 1),
-                       "llm_weights": args.weights},
+                       "llm_weights": args.weights, "dist": dist_info},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

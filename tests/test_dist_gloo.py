@@ -69,3 +69,23 @@ def test_shard_and_gather_world2():
         p.join(100)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_bench_self_launch_plumbing():
+    """`python bench.py --gpus 2` must fork its own ranks when no launcher set WORLD_SIZE (the driver's command shape;
+    reference pattern: scripts/srgpt/eval/srgpt_bench.sh:23-34) -- checked without a model through --selftest-launcher:
+    rendezvous on 127.0.0.1, the ragged-safe id gather, exactly one rank-0 JSON line, exit code 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launcher", "--batch", "3"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["world_size_seen"] == 2 and j["gathered_rows"] == 6 and j["launcher"] == "self"
