@@ -10,47 +10,11 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_epilogue.h"
+
+int srgpt_gemm256_launch(const void* A, const void* W, int K, int lda, const Epilogue& e, hipStream_t s);  // gemm256.hip
 
 namespace {
-
-struct Epilogue {
-  const void* bias;
-  const void* residual;
-  void* C;
-  int M, N, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw;
-  float* partial;  // split-K: fp32 slabs [splits][M][N] (deterministic: reduced in slab order by splitk_reduce_kernel)
-  int splits, tiles_per_split;
-};
-
-template <typename T>
-__device__ __forceinline__ void epilogue_store(const Epilogue& e, int m, int n, float acc) {
-  if (m >= e.M || n >= e.N) return;
-  float v = acc;
-  if (e.bias) {
-    const int bi = e.bias_mod > 0 ? n % e.bias_mod : n;
-    v += to_f(reinterpret_cast<const T*>(e.bias)[bi]);
-  }
-  v = rnd<T>(v);  // nn.Linear / conv output is materialised in T
-  if (e.act != SRGPT_ACT_NONE) v = rnd<T>(apply_act<T>(v, e.act));
-  if (e.residual) {
-    const int rm = e.res_mod > 0 ? m % e.res_mod : m;
-    v = rnd<T>(v + to_f(reinterpret_cast<const T*>(e.residual)[(size_t)rm * e.N + n]));
-  }
-  size_t off;
-  if (e.out_mode == SRGPT_OUT_DECONV2X) {
-    const int cout = e.N >> 2, gg = e.gw * e.gw;
-    const int img = m / gg, rem = m - img * gg, i = rem / e.gw, j = rem - i * e.gw;
-    const int tap = n / cout, co = n - tap * cout, a = tap >> 1, b = tap & 1;
-    const int ow = 2 * e.gw;
-    off = ((size_t)img * ow * ow + (size_t)(2 * i + a) * ow + (2 * j + b)) * cout + co;
-  } else {
-    off = (size_t)m * e.ldc + n;
-  }
-  if (e.out_f32)
-    reinterpret_cast<float*>(e.C)[off] = v;
-  else
-    reinterpret_cast<T*>(e.C)[off] = from_f<T>(v);
-}
 
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
@@ -173,8 +137,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__
           if (m < e.M && n < e.N) slab[(size_t)m * e.N + n] = a[r];
         }
       } else {
-#pragma clang loop unroll(full)
-        for (int r = 0; r < 16; ++r) epilogue_store<bf16_t>(e, mb + (r & 3) + 8 * (r >> 2), n, a[r]);
+        epilogue_tile32<bf16_t>(e, mb, n, a);
       }
     }
 }
@@ -312,8 +275,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_bf16_glds(const b
           if (m < e.M && n < e.N) slab[(size_t)m * e.N + n] = a[r];
         }
       } else {
-#pragma clang loop unroll(full)
-        for (int r = 0; r < 16; ++r) epilogue_store<bf16_t>(e, mb + (r & 3) + 8 * (r >> 2), n, a[r]);
+        epilogue_tile32<bf16_t>(e, mb, n, a);
       }
     }
 }
@@ -404,6 +366,38 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
     hipLaunchKernelGGL(gemm_f32_simple, grid, dim3(256), 0, s, (const float*)A, (const float*)W, K, lda, e);
     SRGPT_LAUNCH_CHECK();
     return SRGPT_OK;
+  }
+  // ---- 256 x 256 eight-wave kernel (gemm256.hip) when its tiles fill the chip: batched ViT / prefill, large squares ----
+  {
+    const int cus = srgpt_device_cus();
+    const int nk256 = K / 64;
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    const double padded = (double)cdiv(M, 256) * 256.0 * (double)cdiv(N, 256) * 256.0 / ((double)M * (double)N);
+    bool use256 = K % 64 == 0 && K >= 256 && M >= 384 && padded <= 1.35;
+    int sp = 1;
+    if (use256 && t256 * 10 < (long)cus * 7) {  // under-filled: split K (deterministic slabs) if that fills it, else small tiles
+      while (sp < 4 && t256 * sp * 10 < (long)cus * 7) ++sp;
+      if (t256 * sp * 10 < (long)cus * 7 || nk256 / sp < 8 || !ws || (int64_t)sp * M * N * 4 > ws_bytes) use256 = false;
+    }
+    const int f256 = SRGPT_KNOB("SRGPT_GEMM_FORCE_256", 0);  // tuning build: 1 = whenever legal, -1 = never
+    if (f256 > 0) use256 = K % 64 == 0 && K >= 128, sp = 1;
+    if (f256 < 0) use256 = false;
+    if (use256) {
+      if (sp > 1) {
+        e.partial = reinterpret_cast<float*>(ws);
+        e.tiles_per_split = cdiv(nk256, sp);
+        e.splits = cdiv(nk256, e.tiles_per_split);
+      }
+      SRGPT_TRY(srgpt_gemm256_launch(A, W, K, lda, e, s));
+      if (e.splits > 1) {
+        const size_t total = (size_t)M * N;
+        int rgrid = (int)((total + 255) / 256);
+        if (rgrid > 2048) rgrid = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(rgrid), dim3(256), 0, s, e);
+        SRGPT_LAUNCH_CHECK();
+      }
+      return SRGPT_OK;
+    }
   }
   // ---- tile / split-K selection: fill the 256 CUs with >= ~2 blocks each ----
   const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);

@@ -12,10 +12,16 @@ under TEACHER FORCING (the oracle's ids are fed, every step is compared, nothing
 
 Stated tolerances (bf16 arithmetic end to end, fp32 accumulation; the two sides differ in accumulation order and in where
 attention rounds P -- flash keeps fp32 scores and a bf16 P, HF-eager rounds the probabilities to bf16 after an fp32 softmax):
-  stage tensors      max|d| <= 3e-2 of the tensor's max (27-layer tower: 5e-2, it sums 26 residual updates)
-  logits             max|d| <= 6e-2 and rms <= 1.5e-2 of the logit range, over ALL positions / ALL steps
-  greedy ids         argmax equal wherever the oracle's top-1/top-2 margin exceeds 2x the max tolerance
-The measured numbers are printed and written to gpurun_out/fulldepth_parity_<config>.json."""
+  stage tensors      max|d| <= 2.5e-2 of the tensor's max (the 26-layer tower outputs: 4e-2, they sum 26 residual updates)
+  logits             calibrated against the NOISE FLOOR of bf16 arithmetic itself: the oracle is run a second time in fp32 on
+                     the same (bf16-valued) weights and inputs, teacher-forced with the same ids; floor = oracle_bf16 - oracle_fp32.
+                       (a) engine vs bf16 oracle:  max|d| <= 2 x floor max,  rms <= 2 x floor rms   (two independent bf16 paths
+                           differ by ~sqrt(2) x one path's rounding noise), with absolute caps max <= 0.15, rms <= 2.5e-2 of the range
+                       (b) engine vs fp32 oracle:  rms <= 1.25 x floor rms -- the HIP path is as close to exact arithmetic as the
+                           reference's own bf16 path is
+                     over ALL T prompt positions x the whole vocabulary and ALL decode steps
+  greedy ids         argmax equal wherever the bf16 oracle's top-1/top-2 margin exceeds 2 x the measured max error bound
+The measured numbers are printed and written to gpurun_out/fulldepth_parity_<config>.json (committed under profiles/)."""
 import json
 import os
 import sys
@@ -31,7 +37,7 @@ DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-LOGIT_MAX, LOGIT_RMS = 6e-2, 1.5e-2
+LOGIT_MAX_CAP, LOGIT_RMS_CAP = 0.15, 2.5e-2
 
 
 def _run(geom, regions, prompt_len, G):
@@ -55,24 +61,40 @@ def _run(geom, regions, prompt_len, G):
     t0 = time.perf_counter()
     ref_ids, st = so.generate(w_cpu, ocfg, ids, images, depths, masks, max_new_tokens=G, return_stages=True, model_dtype=dtype)
     t_oracle = time.perf_counter() - t0
+    # noise floor: the same request through the oracle in fp32 (weights = the bf16 values, exactly representable), teacher
+    # forced with the bf16 oracle's ids so that every position / step is comparable
+    t0 = time.perf_counter()
+    w32 = {k: v.float() for k, v in w_cpu.items()}
     del w_cpu
+    emb32, _, _, _ = so.prepare_inputs(w32, ocfg, ids, images.float(), depths.float(), [m.float() for m in masks])
+    kv = so.KVCache(ocfg.layers)
+    T32 = emb32.shape[1]
+    pre32 = so.llama_forward(w32, ocfg, emb32, torch.arange(T32)[None], kv)
+    steps32 = [pre32[:, -1]]
+    for t_ in range(G - 1):
+        e = torch.nn.functional.embedding(ref_ids[:, t_:t_ + 1], w32["llm.model.embed_tokens.weight"])
+        steps32.append(so.llama_forward(w32, ocfg, e, torch.tensor([[T32 + t_]]), kv, last_only=True)[:, -1])
+    steps32 = torch.stack(steps32, dim=1)
+    del w32, kv
+    t_oracle32 = time.perf_counter() - t0
 
     got = {}
     emb, _, lens = eng.prepare_inputs(ids.to(DEV), images.to(DEV), depths.to(DEV), [m.to(DEV) for m in masks], None, stages=got)
     T = prompt_len - 1 + 196
     assert emb.shape == (1, T, cfg.hidden) and lens == [T]
     report = {"config": geom, "regions": regions, "prompt_len": prompt_len, "T": T, "G": G, "oracle_s": round(t_oracle, 1),
+              "oracle_fp32_s": round(t_oracle32, 1),
               "build_s": round(t_build, 1), "oracle_threads": torch.get_num_threads(), "stages": {}}
 
-    def chk(a, b, what, rel=3e-2):
+    def chk(a, b, what, rel=2.5e-2):
         a, b = a.detach().float().cpu(), b.detach().float().cpu()
         scale = float(b.abs().max()) + 1e-6
         report["stages"][what] = {"max_abs_over_max": float((a - b).abs().max()) / scale,
                                   "rms_over_max": float((a - b).pow(2).mean().sqrt()) / scale, "tol": rel}
         assert_close(a, b, rel * scale, 0, what)
 
-    chk(got["tower_features"], st["tower_features"], "tower_features (26 ViT layers, RGB)", 5e-2)
-    chk(got["depth_features"], st["depth_features"], "depth_features (26 ViT layers, depth)", 5e-2)
+    chk(got["tower_features"], st["tower_features"], "tower_features (26 ViT layers, RGB)", 4e-2)
+    chk(got["depth_features"], st["depth_features"], "depth_features (26 ViT layers, depth)", 4e-2)
     chk(got["hres"], st["hres"], "hres")
     chk(got["lres"], st["lres"], "lres")
     chk(torch.stack(got["mask_embeds"]), torch.stack(st["mask_embeds"]), "mask_embeds")
@@ -82,21 +104,28 @@ def _run(geom, regions, prompt_len, G):
 
     # prefill over the ENGINE's own embeddings (end to end), logits at every position vs the oracle's
     stt, logits, _ = eng.prefill(emb, max_new=G + 1, all_logits=True)
-    rp = logit_parity_report(logits, st["prefill_logits"], LOGIT_MAX, "prefill logits, all positions")
-    del logits
     # decode path, teacher forced with the oracle's ids: every step compared
     dec = teacher_forced_decode_logits(eng, stt, ref_ids)
-    rd = logit_parity_report(dec, st["step_logits"], LOGIT_MAX, "decode logits, teacher forced")
-    rd["own_argmax_equals_oracle_ids"] = int((dec.argmax(-1).cpu() == ref_ids).sum())
-    report["prefill"], report["decode"] = rp, rd
+    ok = True
+    for name, got_l, ref16, ref32 in (("prefill", logits, st["prefill_logits"], pre32), ("decode", dec, st["step_logits"], steps32)):
+        floor = logit_parity_report(ref16, ref32, 1.0, f"{name}: NOISE FLOOR oracle_bf16 vs oracle_fp32")
+        tol_max = min(LOGIT_MAX_CAP, 2 * floor["max_abs_over_range"])
+        tol_rms = min(LOGIT_RMS_CAP, 2 * floor["rms_over_range"])
+        r16 = logit_parity_report(got_l, ref16, tol_max, f"{name}: engine vs oracle_bf16")
+        r32 = logit_parity_report(got_l, ref32, tol_max, f"{name}: engine vs oracle_fp32")
+        r16.update(tol_max=tol_max, tol_rms=tol_rms, own_argmax_equals_oracle_argmax=r16["argmax_agree"])
+        r32.update(tol_rms=1.25 * floor["rms_over_range"])
+        report[name] = {"noise_floor": floor, "vs_bf16_oracle": r16, "vs_fp32_oracle": r32}
+        ok &= r16["max_abs_over_range"] <= tol_max and r16["rms_over_range"] <= tol_rms
+        ok &= r16["argmax_disagree_out_of_margin"] == 0
+        ok &= r32["rms_over_range"] <= 1.25 * floor["rms_over_range"]
+    report["decode"]["engine_argmax_equals_oracle_ids"] = int((dec.argmax(-1).cpu() == ref_ids).sum())
+    del logits
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"fulldepth_parity_{geom}.json"), "w") as f:
         json.dump(report, f, indent=1)
     print("\nFULLDEPTH", json.dumps(report))
-    for r in (rp, rd):
-        assert r["max_abs_over_range"] <= LOGIT_MAX, r
-        assert r["rms_over_range"] <= LOGIT_RMS, r
-        assert r["argmax_disagree_out_of_margin"] == 0, r
+    assert ok, {k: report[k] for k in ("prefill", "decode")}
     del model
     torch.cuda.empty_cache()
 

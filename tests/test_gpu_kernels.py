@@ -79,6 +79,51 @@ def test_gemm_deconv2x(dtype, n_img, g, C):
     assert_close(out.reshape(n_img, 4 * g * g, C), ref, _tol(ref, dtype), 0, "deconv2x")
 
 
+@pytest.mark.parametrize("M,N,K,what", [
+    (3000, 4304, 1152, "ragged M and N, 204 tiles, no split (ViT fc1 shape at ~2 images x 2)"),
+    (2048, 4096, 1024, "128 tiles -> split-K 2 (deterministic slabs)"),
+    (4096, 4096, 512, "exact tiles, 8 K tiles"),
+    (2072, 28672, 4096, "batched prefill gate/up (8 requests x 259 rows)"),
+    (11664, 1152, 4352, "batched ViT fc2 with K padded to a multiple of 64"),
+    (2305, 3456, 256, "minimum K (4 tiles): prologue/tail paths only")])
+def test_gemm_256_tile_kernel(M, N, K, what):
+    """gemm256.hip (256 x 256 x 64 tiles, 8 waves, counted LDS-DMA waits): every shape here takes that kernel.  Checked
+    against fp32 torch on the device with an ASYMMETRIC epilogue (bias + tanh-GELU + residual) and a plain one, twice (the
+    second run must be bit-identical: a DMA / barrier race would show as run-to-run differences)."""
+    ops, L = _ops()
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = torch.randn((M, K), generator=g, device=DEV).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+    b = torch.randn((N,), generator=g, device=DEV).to(torch.bfloat16)
+    r = torch.randn((M, N), generator=g, device=DEV).to(torch.bfloat16)
+    ref = a.float() @ w.float().T
+    out = ops.gemm(a, w)
+    assert_close(out, ref, _tol(ref, torch.bfloat16), 0, f"gemm256 plain: {what}")
+    ref2 = F.gelu((ref + b.float()).to(torch.bfloat16).float(), approximate="tanh").to(torch.bfloat16).float() + r.float()
+    out2 = ops.gemm(a, w, b, r, act=L.ACT_GELU_TANH)
+    assert_close(out2, ref2, _tol(ref2, torch.bfloat16), 0, f"gemm256 bias+gelu+res: {what}")
+    for _ in range(3):
+        assert torch.equal(ops.gemm(a, w, b, r, act=L.ACT_GELU_TANH), out2), "run-to-run difference"
+    # rows of A with a stride (lda > K), as the ViT workspace hands them over
+    big = torch.randn((M, K + 64), generator=g, device=DEV).to(torch.bfloat16)
+    out4 = ops.gemm(big[:, :K], w)
+    assert_close(out4, big[:, :K].float() @ w.float().T, _tol(ref, torch.bfloat16), 0, f"gemm256 strided A: {what}")
+
+
+def test_gemm_256_deconv_epilogue():
+    """the second deconv of the refinement module at 4 images: [4*54*54, 1152] x [4608, 1152] with the pixel-shuffle epilogue"""
+    ops, L = _ops()
+    n_img, g, C = 4, 54, 1152
+    x = _rand((n_img, g * g, C), torch.bfloat16, 8).to(DEV)
+    wt, b = _rand((C, C, 2, 2), torch.bfloat16, 9, 0.03).to(DEV), _rand((C,), torch.bfloat16, 10).to(DEV)
+    ref = F.conv_transpose2d(x.float().reshape(n_img, g, g, C).permute(0, 3, 1, 2), wt.float(), b.float(), stride=2)
+    ref = F.gelu(ref.to(torch.bfloat16).float()).flatten(2).transpose(1, 2)
+    w2 = wt.permute(2, 3, 1, 0).reshape(4 * C, C).contiguous()
+    out = ops.gemm(x.reshape(-1, C), w2, b, act=L.ACT_GELU_ERF, bias_mod=C, out_mode=L.OUT_DECONV2X, gw=g,
+                   out_shape=(n_img * 4 * g * g, C))
+    assert_close(out.reshape(n_img, 4 * g * g, C), ref, _tol(ref, torch.bfloat16), 0, "gemm256 deconv2x")
+
+
 # ------------------------------------------------------------------------------------------------ GEMV
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("B,N,K", [(1, 1000, 4096), (1, 1001, 4096), (2, 512, 11008), (4, 300, 1024), (1, 128, 64),
