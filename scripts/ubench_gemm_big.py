@@ -14,7 +14,12 @@ shapes = [("sq4096", 4096, 4096, 4096), ("sq8192", 8192, 8192, 8192),
           ("prefill b8 qkv", 2072, 6144, 4096), ("prefill b8 o", 2072, 4096, 4096), ("prefill b8 gate/up", 2072, 28672, 4096),
           ("prefill b8 down", 2072, 4096, 14336), ("prefill b4 gate/up", 1036, 28672, 4096), ("prefill b4 down", 1036, 4096, 14336),
           ("deconv2 b8", 23328, 4608, 1152)]
+only = None
+if "--only" in sys.argv:
+    only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
 for name, M, N, K in shapes:
+    if only is not None and name not in only:
+        continue
     Ws = [torch.randn((N, K), device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(2)]
     a = torch.randn((M, K), device=dev, dtype=torch.bfloat16)
     out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)

@@ -367,17 +367,28 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
     SRGPT_LAUNCH_CHECK();
     return SRGPT_OK;
   }
-  // ---- 256 x 256 eight-wave kernel (gemm256.hip) when its tiles fill the chip: batched ViT / prefill, large squares ----
+  // ---- 256 x 256 eight-wave kernel (gemm256.hip) when a cost model calibrated on MI355X measurements says it wins ----
+  // (profiles/r02_gemm256_*.txt: one block per CU; a round of tiles costs ~15.5 us of launch + prologue + epilogue plus 1.7 us per
+  //  K tile; the small-tile kernels below sustain ~730 TF/s at K <= 1536 and ~600 TF/s beyond (780 on very wide N) on shapes
+  //  that fill the chip)
   {
     const int cus = srgpt_device_cus();
     const int nk256 = K / 64;
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    const double padded = (double)cdiv(M, 256) * 256.0 * (double)cdiv(N, 256) * 256.0 / ((double)M * (double)N);
-    bool use256 = K % 64 == 0 && K >= 256 && M >= 384 && padded <= 1.35;
+    bool use256 = K % 64 == 0 && K >= 256 && M >= 384;
     int sp = 1;
-    if (use256 && t256 * 10 < (long)cus * 7) {  // under-filled: split K (deterministic slabs) if that fills it, else small tiles
-      while (sp < 4 && t256 * sp * 10 < (long)cus * 7) ++sp;
-      if (t256 * sp * 10 < (long)cus * 7 || nk256 / sp < 8 || !ws || (int64_t)sp * M * N * 4 > ws_bytes) use256 = false;
+    if (use256) {
+      if (t256 < cus && ws) {  // under-filled: split K (deterministic slabs) while the blocks still fit one round
+        sp = (int)(cus / t256);
+        if (sp > 4) sp = 4;
+        while (sp > 1 && (nk256 / sp < 8 || (int64_t)sp * M * N * 4 > ws_bytes)) --sp;
+      }
+      const long blocks = t256 * sp;
+      const double rounds = (double)((blocks + cus - 1) / cus);
+      double t_new = rounds * (15.5 + 1.7 * (double)cdiv(nk256, sp));
+      if (sp > 1) t_new += 2.0 + (double)M * N * 4.0 * (sp + 1) / 4.0e6;  // slab write + reduce pass (bytes / 4 TB/s, in us)
+      const double t_old = 2.0 * M * N * (double)K / ((K <= 1536 ? 730.0 : (N >= 16384 ? 780.0 : 600.0)) * 1e6);
+      use256 = t_new < 0.95 * t_old;
     }
     const int f256 = SRGPT_KNOB("SRGPT_GEMM_FORCE_256", 0);  // tuning build: 1 = whenever legal, -1 = never
     if (f256 > 0) use256 = K % 64 == 0 && K >= 128, sp = 1;

@@ -6,19 +6,22 @@
 //   * LDS: two K-tile buffers x (A 256x64 + W 256x64) bf16, rows of 128 B in 16-byte slots, slot ^ ((row >> 1) & 7)
 //     (the conflict-free ds_read_b128 fragment layout of gemm.hip), filled by LDS-DMA (global_load_lds_dwordx4: one
 //     wave-instruction = 8 rows x 128 B = 1 KiB, full cache lines; the swizzle permutes which 16-byte chunk a lane fetches)
-//   * a K tile is consumed in 4 PHASES, phase p = m-tile p of the wave (32 rows) x both n-tiles x K = 64 -> 8 MFMAs
-//     (256 matrix-pipe cycles); the W fragments of the whole K tile are read in phase 0 and kept in 32 VGPRs, the A fragments
-//     of m-tile p (16 VGPRs) in phase p.  So every LDS region has ONE reading phase: W after phase 0 and the A rows of m-tile
-//     p after phase p are free, and the next-but-one K tile is DMA'd into the buffer that is still being multiplied:
-//         phase 0: A rows of m-tiles 0,1 of tile t+1     phase 2: W rows   0..127 of tile t+2
-//         phase 1: A rows of m-tiles 2,3 of tile t+1     phase 3: W rows 128..255 of tile t+2
-//     (each "slot" = 16 KiB = 2 DMA instructions per thread, restaged >= 2 phases after its last ds_read)
-//   * the two waves of a SIMD run ONE PHASE APART (waves 4-7 start one barrier late): while one wave issues its 8 MFMAs the
-//     other reads fragments and issues DMA, so the matrix pipe always has a wave on it (s_setprio 1 around the MFMA cluster)
-//   * DMA is never drained in the main loop: two counted waits per K tile -- vmcnt(6) in phase 0 (A rows of m-tiles 2,3 of
-//     THIS tile have landed, 3 slots stay in flight) and vmcnt(4) in phase 2 (W + A rows 0,1 of the NEXT tile, 2 slots in
-//     flight) -- each placed one full phase (a workgroup barrier both wave groups have passed) before the first ds_read of
-//     that data; raw s_barrier only (a __syncthreads() would carry vmcnt(0)).
+//   * a K tile is consumed in 2 PHASES, phase P = m-tiles 2P, 2P+1 of the wave (64 rows) x both n-tiles x K = 64 -> 16 MFMAs
+//     on four accumulators (512 matrix-pipe cycles).  Measured (scripts/ubench_gemm256_ablate.sh): with 8-MFMA clusters on TWO
+//     accumulators the MFMAs alone ran at 44 instead of 32 cycles each -- a dependent 32x32x16 MFMA two issue slots behind its
+//     producer stalls.  The W fragments of the whole K tile are read in phase 0 and kept in 32 VGPRs, the A fragments of the
+//     phase's two m-tiles in 32 more.  Every LDS region therefore has ONE reading phase (W and A rows 0,1: phase 0; A rows 2,3:
+//     phase 1) and the next-but-one K tile is DMA'd into the buffer that is still being multiplied:
+//         phase 0 of tile t: A rows of m-tiles 2,3 of tile t+1 (2 DMA instructions per thread)
+//         phase 1 of tile t: W (lo, hi) and A rows of m-tiles 0,1 of tile t+2 (6 instructions)
+//   * the two waves of a SIMD run ONE PHASE APART (waves 4-7 start one barrier late): while one wave issues its 16 MFMAs the
+//     other reads fragments, so the matrix pipe always has a wave on it; the DMA instructions are issued BETWEEN the MFMAs of
+//     the multiply part (in the matrix pipe's shadow), s_setprio 1 around the cluster
+//   * DMA is never drained in the main loop: two counted waits per K tile -- vmcnt(6) in phase 0 (A rows 2,3 of THIS tile have
+//     landed; the 6 of the previous phase 1 stay in flight) and vmcnt(2) in phase 1 (W + A rows 0,1 of the NEXT tile) -- each
+//     placed one full phase (a workgroup barrier both wave groups have passed) before the first ds_read of that data; fragment
+//     reads retire (lgkmcnt 0) BEFORE the barrier of their load part, so a region is free once both halves passed it; raw
+//     s_barrier only (a __syncthreads() would carry vmcnt(0)).
 //   * blocks are renumbered so that each XCD (private 4 MiB L2) owns a contiguous run of tiles, walked in 8-row bands.
 // Requirements (checked by the launcher; everything else stays on gemm.hip's kernels): K % 64 == 0, K >= 256.
 #include <type_traits>
@@ -36,7 +39,7 @@ constexpr int G_LDS = 2 * G_BUF;          // 128 KiB
 #define G_BARRIER()                          \
   do {                                       \
     __builtin_amdgcn_sched_barrier(0);       \
-    __builtin_amdgcn_s_barrier();            \
+    if (ablate != 9) __builtin_amdgcn_s_barrier(); \
     __builtin_amdgcn_sched_barrier(0);       \
   } while (0)
 #define G_VMCNT(N)                                                   \
@@ -46,6 +49,9 @@ constexpr int G_LDS = 2 * G_BUF;          // 128 KiB
     __builtin_amdgcn_sched_barrier(0);                               \
   } while (0)
 
+template <int ablate>  // 0 = the kernel; 1..4 = timing-only ablations, instantiated in the tuning build only (wrong results):
+                       // 1 no DMA in the loop, 2 no DMA waits, 3 no fragment reads after the first tile, 4 no MFMA,
+                       // 7 no stagger (lockstep), 9 MFMAs only, 10 MFMAs + barriers only
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                int K, int lda, Epilogue e, int gx, int gy) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -89,22 +95,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
                                      (__attribute__((address_space(3))) void*)(lds + lds_off), 16, 0, 0);
   };
   // stage slot `sl` (compile-time) of K tile kt into buffer kt & 1
-  auto stage = [&](auto sl_c, int kt) {
+  // which = 0 / 1: the first / second DMA instruction of the slot, 2: both
+  auto stage = [&](auto sl_c, int kt, int which = 2) {
     constexpr int sl = decltype(sl_c)::value;
     const int k0 = kt * G_BK;
     const int boff = (kt & 1) * G_BUF;
     if constexpr (sl == 0) {
-      dma(pw[0] + k0, boff + G_OPER + (wave + 0) * 1024);
-      dma(pw[1] + k0, boff + G_OPER + (wave + 8) * 1024);
+      if (which != 1) dma(pw[0] + k0, boff + G_OPER + (wave + 0) * 1024);
+      if (which != 0) dma(pw[1] + k0, boff + G_OPER + (wave + 8) * 1024);
     } else if constexpr (sl == 1) {
-      dma(pw[2] + k0, boff + G_OPER + (wave + 16) * 1024);
-      dma(pw[3] + k0, boff + G_OPER + (wave + 24) * 1024);
+      if (which != 1) dma(pw[2] + k0, boff + G_OPER + (wave + 16) * 1024);
+      if (which != 0) dma(pw[3] + k0, boff + G_OPER + (wave + 24) * 1024);
     } else if constexpr (sl == 2) {
-      dma(pa[0] + k0, boff + (wave + 0) * 1024);
-      dma(pa[1] + k0, boff + (wave + 16) * 1024);
+      if (which != 1) dma(pa[0] + k0, boff + (wave + 0) * 1024);
+      if (which != 0) dma(pa[1] + k0, boff + (wave + 16) * 1024);
     } else {
-      dma(pa[2] + k0, boff + (wave + 8) * 1024);
-      dma(pa[3] + k0, boff + (wave + 24) * 1024);
+      if (which != 1) dma(pa[2] + k0, boff + (wave + 8) * 1024);
+      if (which != 0) dma(pa[3] + k0, boff + (wave + 24) * 1024);
     }
   };
   using S0 = std::integral_constant<int, 0>;
@@ -131,9 +138,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
       acc[i][1] = z;
     }
   }
-  bf16x8 fw[2][4], fa[4];
+  bf16x8 fw[2][4], fa[2][4];
 
-  // ---- prologue: tile kt0 complete, W of tile kt0+1 (its A rows are staged in phases 0 and 1 of tile kt0) ----
+  // ---- prologue: tile kt0 complete, W + A rows 0,1 of tile kt0+1 (its A rows 2,3 are staged in phase 0 of tile kt0) ----
   stage(S0{}, kt0);
   stage(S1{}, kt0);
   stage(S2{}, kt0);
@@ -141,71 +148,101 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
   if (kt0 + 1 < nk) {
     stage(S0{}, kt0 + 1);
     stage(S1{}, kt0 + 1);
-    G_VMCNT(4);
+    stage(S2{}, kt0 + 1);
+    G_VMCNT(6);
   } else {
     G_VMCNT(0);
   }
   G_BARRIER();
-  if (wr == 1) G_BARRIER();  // waves 4-7 run one phase behind waves 0-3
+  // the late half runs one phase behind the early half; the two waves of a SIMD must be in different halves
+  const bool late = ablate == 7 ? false : wr == 1;
+  if (late) G_BARRIER();
 
+  // Phase P (0 / 1) of K tile kt = m-tiles 2P, 2P+1 of the wave x both n-tiles x K = 64: 16 MFMAs on FOUR accumulators (the same
+  // accumulator comes round every 4th MFMA: back-to-back dependent 32x32x16 MFMAs at distance 2 stall ~8 cycles each).
+  //   load part:     fragment reads (P0: W of the tile + A m-tiles 0,1; P1: A m-tiles 2,3), counted DMA wait, lgkmcnt(0), barrier
+  //   multiply part: 16 MFMAs with this phase's DMA instructions issued in their shadow, barrier
+  // DMA plan (issue order per thread): P0 of tile t: A rows 2,3 of tile t+1 (2 instr) | P1 of tile t: W lo, W hi, A rows 0,1 of
+  // tile t+2 (6 instr) into the buffer tile t occupies -- all of its readers retired their reads (lgkmcnt(0) BEFORE the
+  // barrier of their P0 load part) at least one workgroup barrier earlier.  Waits: P0 needs A rows 2,3 of THIS tile one
+  // phase later -> vmcnt(6) (the 6 of the previous P1 may fly); P1 needs W + A rows 0,1 of the NEXT tile one phase later
+  // -> vmcnt(2) (the 2 of this tile's P0 may fly).
   auto phase = [&](auto p_c, int kt, bool more1, bool more2) {
-    constexpr int p = decltype(p_c)::value;
+#define G_WAIT(N)                                                                  \
+  do {                                                                             \
+    if (ablate != 2 && ablate != 1 && ablate != 9 && ablate != 10) G_VMCNT(N);     \
+  } while (0)
+    constexpr int P = decltype(p_c)::value;
     const char* buf = lds + (kt & 1) * G_BUF;
-    // -------- load part: fragments of this phase, then the DMA slot of this phase --------
-    if constexpr (p == 0) {
+    if ((ablate != 3 && ablate != 9 && ablate != 10) || kt == kt0) {
+      if constexpr (P == 0) {
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn)
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            fw[jn][ks] = *reinterpret_cast<const bf16x8*>(buf + w_base + jn * 32 * 128 + koff[ks]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-          fw[jn][ks] = *reinterpret_cast<const bf16x8*>(buf + w_base + jn * 32 * 128 + koff[ks]);
-      __builtin_amdgcn_sched_barrier(0);
+          fa[mi][ks] = *reinterpret_cast<const bf16x8*>(buf + a_base + (2 * P + mi) * 32 * 128 + koff[ks]);
     }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fa[ks] = *reinterpret_cast<const bf16x8*>(buf + a_base + p * 32 * 128 + koff[ks]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (p == 0) {
-      if (more1) {
-        stage(S2{}, kt + 1);
-        G_VMCNT(6);
-      } else {
-        G_VMCNT(0);
-      }
-    } else if constexpr (p == 1) {
-      if (more1) stage(S3{}, kt + 1);
-    } else if constexpr (p == 2) {
-      if (more2) {
-        stage(S0{}, kt + 2);
-        G_VMCNT(4);
-      } else {
-        G_VMCNT(0);
-      }
+    if (ablate == 1 || ablate == 9 || ablate == 10) more1 = more2 = false;
+    if constexpr (P == 0) {
+      if (more1) G_WAIT(6); else G_WAIT(0);
     } else {
-      if (more2) stage(S1{}, kt + 2);
+      if (more2) G_WAIT(2); else G_WAIT(0);
     }
+    // fragments land before the barrier: whoever passes it may overwrite what this phase read
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     G_BARRIER();
     // -------- multiply part --------
     __builtin_amdgcn_s_setprio(1);
+    if (ablate != 4) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn)
-        acc[p][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fw[jn][ks], acc[p][jn], 0, 0, 0);
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int jn = 0; jn < 2; ++jn)
+            acc[2 * P + mi][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fw[jn][ks], acc[2 * P + mi][jn], 0, 0, 0);
+        // DMA in the matrix pipe's shadow: P0 one instruction after MFMA 4 and 12; P1 two after MFMA 4, 8, 12
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P == 0) {
+          if (more1 && (ks == 0 || ks == 2)) stage(S3{}, kt + 1, ks >> 1);
+        } else {
+          if (more2) {
+            if (ks == 0) stage(S0{}, kt + 2, 2);
+            if (ks == 1) stage(S1{}, kt + 2, 2);
+            if (ks == 2) stage(S2{}, kt + 2, 2);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      asm volatile("" ::"v"(fa[0][0]), "v"(fa[0][3]), "v"(fa[1][0]), "v"(fa[1][3]), "v"(fw[0][0]), "v"(fw[1][3]));
+      if constexpr (P == 0) {
+        if (more1) stage(S3{}, kt + 1, 2);
+      } else if (more2) {
+        stage(S0{}, kt + 2, 2);
+        stage(S1{}, kt + 2, 2);
+        stage(S2{}, kt + 2, 2);
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
     G_BARRIER();
   };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
-  using P2 = std::integral_constant<int, 2>;
-  using P3 = std::integral_constant<int, 3>;
 
   for (int kt = kt0; kt < nk; ++kt) {
     const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
     phase(P0{}, kt, more1, more2);
     phase(P1{}, kt, more1, more2);
-    phase(P2{}, kt, more1, more2);
-    phase(P3{}, kt, more1, more2);
   }
-  if (wr == 0) G_BARRIER();  // pairs with the last barrier of the late half
+  if (!late && ablate != 7) G_BARRIER();  // pairs with the last barrier of the late half
 
   // ---- epilogue.  D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
 #pragma clang loop unroll(full)
@@ -233,11 +270,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
 // e.splits / e.tiles_per_split / e.partial are set by the caller (srgpt_gemm) when it wants split-K; the deterministic
 // slab reduction (splitk_reduce_kernel in gemm.hip) follows there.
 int srgpt_gemm256_launch(const void* A, const void* W, int K, int lda, const Epilogue& e, hipStream_t s) {
-  static std::atomic<uint64_t> attr_done{0};
-  SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)gemm_bf16_256_kernel, G_LDS));
   const int gx = cdiv(e.N, G_BN), gy = cdiv(e.M, G_BM);
-  hipLaunchKernelGGL(gemm_bf16_256_kernel, dim3(gx * gy, e.splits > 1 ? e.splits : 1), dim3(512), G_LDS, s, (const bf16_t*)A,
-                     (const bf16_t*)W, K, lda, e, gx, gy);
+#define G_LAUNCH(AB)                                                                                                        \
+  do {                                                                                                                    \
+    static std::atomic<uint64_t> attr_done{0};                                                                            \
+    SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)gemm_bf16_256_kernel<AB>, G_LDS));                         \
+    hipLaunchKernelGGL(gemm_bf16_256_kernel<AB>, dim3(gx * gy, e.splits > 1 ? e.splits : 1), dim3(512), G_LDS, s,   \
+                       (const bf16_t*)A, (const bf16_t*)W, K, lda, e, gx, gy);                                            \
+  } while (0)
+#ifdef SRGPT_TUNING_KNOBS
+  switch (SRGPT_KNOB("SRGPT_GEMM256_ABLATE", 0)) {
+    case 1: G_LAUNCH(1); break;
+    case 2: G_LAUNCH(2); break;
+    case 3: G_LAUNCH(3); break;
+    case 4: G_LAUNCH(4); break;
+    case 7: G_LAUNCH(7); break;
+    case 9: G_LAUNCH(9); break;    // MFMAs only: no fragment reads, no DMA, no barriers
+    case 10: G_LAUNCH(10); break;  // MFMAs + barriers only
+    default: G_LAUNCH(0); break;
+  }
+#else
+  G_LAUNCH(0);
+#endif
+#undef G_LAUNCH
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }
