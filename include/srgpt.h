@@ -127,7 +127,9 @@ int srgpt_rope_kv_append(void* qkv, void* kcache, void* vcache, const int* pos0,
 /* Decode attention for one new token per sequence against the static cache, fused with RoPE of the new
  * q/k and the cache append (same reference lines as above + flash-attn decode, modeling_llama.py:540-566).
  *   qkv [B, (Hq+2Hkv)*D] raw projections of the new token; pos (device int[B]) = tokens already cached.
- *   ws: fp32 workspace of srgpt_decode_attn_ws_floats(B,Hq,D) floats.  out [B, Hq*D]. */
+ *   ws: fp32 workspace of srgpt_decode_attn_ws_floats(B,Hq,D) floats: per-split partials followed by one arrival ticket per
+ *   (sequence, kv head).  The tickets must be ZERO before the first launch (zero the workspace once when it is allocated);
+ *   every launch leaves them zero again.  One kernel: the split that arrives last merges the partials.  out [B, Hq*D]. */
 int64_t srgpt_decode_attn_ws_floats(int B, int Hq, int D);
 int srgpt_decode_attention(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
                            const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D,
@@ -187,6 +189,8 @@ int srgpt_cross_entropy(const float* logits, const int64_t* labels, float* row_l
  * --------------------------------------------------------------------------------------------- */
 typedef struct {
   int dtype, hidden, inter, heads, n_layers_run, image_size, patch, kp; /* kp: padded 3*p*p */
+  int inter_pad;        /* row length of w2 and of the MLP activation buffer: inter rounded up to a multiple of 64, zero filled
+                           (4304 -> 4352 for SigLIP-so400m) so that fc2's K dimension tiles exactly */
   int act;              /* MLP activation: SRGPT_ACT_GELU_TANH (SigLIP) or SRGPT_ACT_QUICK_GELU (CLIP) */
   float eps;
   const void* patch_w;  /* [hidden, kp] (conv weight flattened (c,ky,kx), zero padded) */
@@ -200,7 +204,7 @@ typedef struct {
   const void* const* wo;    const void* const* bo;
   const void* const* ln2_w; const void* const* ln2_b;
   const void* const* w1;    const void* const* b1;     /* [inter, hidden] */
-  const void* const* w2;    const void* const* b2;     /* [hidden, inter] */
+  const void* const* w2;    const void* const* b2;     /* [hidden, inter_pad], columns >= inter are zero */
 } srgpt_vit_weights;
 
 /* workspace bytes for n_img images */

@@ -24,7 +24,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 class VitWeights(C.Structure):
     _fields_ = [
         ("dtype", i32), ("hidden", i32), ("inter", i32), ("heads", i32), ("n_layers_run", i32),
-        ("image_size", i32), ("patch", i32), ("kp", i32), ("act", i32), ("eps", f32),
+        ("image_size", i32), ("patch", i32), ("kp", i32), ("inter_pad", i32), ("act", i32), ("eps", f32),
         ("patch_w", vp), ("patch_b", vp), ("pos_emb", vp), ("cls_emb", vp), ("pre_ln_w", vp), ("pre_ln_b", vp),
         ("ln1_w", C.POINTER(vp)), ("ln1_b", C.POINTER(vp)),
         ("wqkv", C.POINTER(vp)), ("bqkv", C.POINTER(vp)),
@@ -125,7 +125,7 @@ def load() -> C.CDLL:
             raise SrgptNativeError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.srgpt_abi_version() != 1:
+    if lib.srgpt_abi_version() != 2:
         raise SrgptNativeError("libsrgpt_hip.so ABI version mismatch; rebuild the extension")
     _lib = lib
     return lib

@@ -255,7 +255,8 @@ template <typename T, int D, int G>
 __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__ qkv, T* __restrict__ kcache,
                                                            T* __restrict__ vcache, const int* __restrict__ pos,
                                                            const T* __restrict__ cos_tab, const T* __restrict__ sin_tab,
-                                                           float* __restrict__ ws, int Hq, int Hkv, int max_pos,
+                                                           float* __restrict__ ws, int* __restrict__ tickets,
+                                                           T* __restrict__ out, int Hq, int Hkv, int max_pos,
                                                            int nsplit, float scale) {
   constexpr int VEC = Vec16<T>::N;
   constexpr int LPK = D / VEC;   // lanes per key
@@ -336,13 +337,21 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   }
 
   float* wbase = ws + (((size_t)b * Hkv + hk) * G) * (size_t)DEC_SPLIT_MAX * (D + 2);
-  if (kbeg >= kend) {  // empty split: neutral partial (zeros, m = -inf, l = 0)
+  // Partials are published WRITE-THROUGH (agent-scope relaxed atomic stores = global_store ... sc1) and read back with
+  // agent-scope relaxed loads by whichever block of this (sequence, kv head) arrives last: no second launch for the merge.
+  auto publish = [&](float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto publish2 = [&](float* p, float a, float b2) {
+    const unsigned long long u = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b2) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  const bool empty = kbeg >= kend;
+  if (empty) {  // empty split: neutral partial (zeros, m = -inf, l = 0)
     for (int w = tid; w < G * (D + 2); w += 256) {
       const int gq = w / (D + 2), d = w - gq * (D + 2);
-      wbase[((size_t)gq * DEC_SPLIT_MAX + split) * (D + 2) + d] = (d == D) ? -INFINITY : 0.f;
+      publish(wbase + ((size_t)gq * DEC_SPLIT_MAX + split) * (D + 2) + d, (d == D) ? -INFINITY : 0.f);
     }
-    return;
   }
+  if (!empty) {
 
   // ---- pass 1: scores ----
   auto score = [&](int key, const float* kv) {
@@ -444,67 +453,85 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
       if (sub == 0) red[wave][gq][dl + i] = x;
     }
   __syncthreads();
-  for (int w = tid; w < G * D; w += 256) {
-    const int gq = w / D, d = w - gq * D;
+  // 8-byte write-through stores (pairs of floats; rows of D + 2 floats are 8-byte aligned because D is even)
+  for (int w = tid; w < G * (D / 2); w += 256) {
+    const int gq = w / (D / 2), d = 2 * (w - gq * (D / 2));
     float* wp = wbase + ((size_t)gq * DEC_SPLIT_MAX + split) * (D + 2);
-    wp[d] = red[0][gq][d] + red[1][gq][d] + red[2][gq][d] + red[3][gq][d];
-    if (d == 0) {
-      wp[D] = stat_m[gq];
-      wp[D + 1] = stat_l[gq];
-    }
+    publish2(wp + d, red[0][gq][d] + red[1][gq][d] + red[2][gq][d] + red[3][gq][d],
+             red[0][gq][d + 1] + red[1][gq][d + 1] + red[2][gq][d + 1] + red[3][gq][d + 1]);
+    if (d == 0) publish2(wp + D, stat_m[gq], stat_l[gq]);
   }
-}
+  }  // !empty
 
-// merge the per-split partials of one (head, batch row).  All loads (the first 16 splits' O rows and the
-// per-split statistics) are issued before anything depends on them: one memory latency for the whole kernel.
-template <typename T>
-__global__ __launch_bounds__(128) void decode_combine_kernel(const float* __restrict__ ws, T* __restrict__ out, int Hq,
-                                                             int D, int nsplit) {
-  constexpr int PRE = 16;
-  __shared__ float wgt[DEC_SPLIT_MAX];
-  __shared__ float inv_s;
-  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const float* wp = ws + ((size_t)b * Hq + h) * (size_t)DEC_SPLIT_MAX * (D + 2);
-  const int d0 = min(tid, D - 1);
-  float v[PRE];
-#pragma unroll
-  for (int j = 0; j < PRE; ++j) v[j] = wp[(size_t)min(j, nsplit - 1) * (D + 2) + d0];
-  if (tid < 64) {  // wave 0: one split per lane (nsplit <= 64)
-    const int sidx = min(tid, nsplit - 1);
-    const float ms_raw = wp[(size_t)sidx * (D + 2) + D];
-    const float ls_raw = wp[(size_t)sidx * (D + 2) + D + 1];
-    const bool ok = tid < nsplit;
+  // ---- arrival ticket: every storing wave drains its write-through stores, one lane takes the ticket; the block that draws
+  //      the last one merges the nsplit partials of its G query heads (fixed split order: the result does not depend on
+  //      which block came last) and re-arms the ticket for the next launch on this stream ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(tickets + (size_t)b * Hkv + hk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stat_l[0] = (t == nsplit - 1) ? 1.f : 0.f;  // stat_l is free again: broadcast "I am last" through the existing LDS
+  }
+  __syncthreads();
+  if (stat_l[0] == 0.f) return;
+  __syncthreads();
+  auto fetch = [&](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // per-head merge weights: wave gq handles head gq (G <= 8 heads over 4 waves), one split per lane (nsplit <= 64)
+  float* wgt = &sc[0][0];  // [G][DEC_SPLIT_MAX] weights, reusing the score buffer (DEC_CHUNK_MAX >= DEC_SPLIT_MAX)
+  for (int gq = wave; gq < G; gq += 4) {
+    const float* wp = wbase + (size_t)gq * DEC_SPLIT_MAX * (D + 2);
+    const bool ok = lane < nsplit;
+    const int sidx = ok ? lane : nsplit - 1;
+    const unsigned long long ml = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)sidx * (D + 2) + D),
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float ms_raw = __uint_as_float((unsigned)ml), ls_raw = __uint_as_float((unsigned)(ml >> 32));
     const float ms = ok ? ms_raw : -INFINITY;
     const float ls = ok ? ls_raw : 0.f;
     const float M = wave_max(ms);
-    const float w = (ms > -INFINITY) ? __expf(ms - M) : 0.f;
-    const float den = wave_sum(w * ls);
-    wgt[tid] = w;
-    if (tid == 0) inv_s = den > 0.f ? 1.f / den : 0.f;
+    const float wv = (ms > -INFINITY) ? __expf(ms - M) : 0.f;
+    const float den = wave_sum(wv * ls);
+    sc[gq][lane] = wv;
+    if (lane == 0) stat_m[gq] = den > 0.f ? 1.f / den : 0.f;
   }
   __syncthreads();
-  if (tid < D) {
-    float num = 0.f;
+  // every thread merges a pair of output dims: the first 16 splits' partials are requested back to back (one memory latency)
+  constexpr int PRE = 16;
+  for (int w = tid; w < G * (D / 2); w += 256) {
+    const int gq = w / (D / 2), d = 2 * (w - gq * (D / 2));
+    const float* wp = wbase + (size_t)gq * DEC_SPLIT_MAX * (D + 2) + d;
+    unsigned long long v[PRE];
 #pragma unroll
     for (int j = 0; j < PRE; ++j)
-      if (j < nsplit) num = fmaf(wgt[j], v[j], num);
-    for (int s = PRE; s < nsplit; ++s) num = fmaf(wgt[s], wp[(size_t)s * (D + 2) + tid], num);
-    out[((size_t)b * Hq + h) * D + tid] = from_f<T>(num * inv_s);
+      v[j] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)min(j, nsplit - 1) * (D + 2)),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float n0 = 0.f, n1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < PRE; ++j)
+      if (j < nsplit) {
+        n0 = fmaf(sc[gq][j], __uint_as_float((unsigned)v[j]), n0);
+        n1 = fmaf(sc[gq][j], __uint_as_float((unsigned)(v[j] >> 32)), n1);
+      }
+    for (int sp = PRE; sp < nsplit; ++sp) {
+      const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)sp * (D + 2)),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      n0 = fmaf(sc[gq][sp], __uint_as_float((unsigned)u), n0);
+      n1 = fmaf(sc[gq][sp], __uint_as_float((unsigned)(u >> 32)), n1);
+    }
+    T* op = out + ((size_t)b * Hq + (size_t)hk * G + gq) * D + d;
+    op[0] = from_f<T>(n0 * stat_m[gq]);
+    op[1] = from_f<T>(n1 * stat_m[gq]);
   }
-  for (int d = tid + 128; d < D; d += 128) {  // head_dim > 128
-    float num = 0.f;
-    for (int s = 0; s < nsplit; ++s) num = fmaf(wgt[s], wp[(size_t)s * (D + 2) + d], num);
-    out[((size_t)b * Hq + h) * D + d] = from_f<T>(num * inv_s);
-  }
+  if (tid == 0) __hip_atomic_store(tickets + (size_t)b * Hkv + hk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <typename T, int D>
 int launch_decode_d(int G, const void* qkv, void* kc, void* vc, const int* pos, const void* ct, const void* st,
-                    float* ws, int B, int Hq, int Hkv, int max_pos, int nsplit, float scale, hipStream_t s) {
+                    float* ws, int* tickets, void* out, int B, int Hq, int Hkv, int max_pos, int nsplit, float scale,
+                    hipStream_t s) {
   dim3 grid(Hkv, nsplit, B);
 #define LD(GG)                                                                                                     \
   hipLaunchKernelGGL((decode_split_kernel<T, D, GG>), grid, dim3(256), 0, s, (const T*)qkv, (T*)kc, (T*)vc, pos, \
-                     (const T*)ct, (const T*)st, ws, Hq, Hkv, max_pos, nsplit, scale)
+                     (const T*)ct, (const T*)st, ws, tickets, (T*)out, Hq, Hkv, max_pos, nsplit, scale)
   switch (G) {
     case 1: LD(1); break;
     case 2: LD(2); break;
@@ -527,19 +554,18 @@ int launch_decode(const void* qkv, void* kc, void* vc, const int* pos, const voi
   SRGPT_CHECK(cdiv(max_pos, nsplit) <= DEC_CHUNK_MAX, SRGPT_ERR_UNSUPPORTED,
               "srgpt_decode_attention: max_pos %d exceeds %d cached positions", max_pos, DEC_SPLIT_MAX * DEC_CHUNK_MAX);
   const float scale = 1.0f / sqrtf((float)D);
+  int* tickets = reinterpret_cast<int*>(ws + (size_t)B * Hq * DEC_SPLIT_MAX * (D + 2));  // int[B * Hkv] behind the partials
   int rc;
   switch (D) {
-    case 16: rc = launch_decode_d<T, 16>(G, qkv, kc, vc, pos, ct, st, ws, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
-    case 32: rc = launch_decode_d<T, 32>(G, qkv, kc, vc, pos, ct, st, ws, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
-    case 64: rc = launch_decode_d<T, 64>(G, qkv, kc, vc, pos, ct, st, ws, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
-    case 128: rc = launch_decode_d<T, 128>(G, qkv, kc, vc, pos, ct, st, ws, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
+    case 16: rc = launch_decode_d<T, 16>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
+    case 32: rc = launch_decode_d<T, 32>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
+    case 64: rc = launch_decode_d<T, 64>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
+    case 128: rc = launch_decode_d<T, 128>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
     default:
       srgpt_set_error("srgpt_decode_attention: head_dim %d not supported (16,32,64,128)", D);
       return SRGPT_ERR_UNSUPPORTED;
   }
   if (rc) return rc;
-  SRGPT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(decode_combine_kernel<T>, dim3(Hq, B), dim3(128), 0, s, ws, (T*)out, Hq, D, nsplit);
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }
@@ -547,7 +573,7 @@ int launch_decode(const void* qkv, void* kc, void* vc, const int* pos, const voi
 }  // namespace
 
 extern "C" int64_t srgpt_decode_attn_ws_floats(int B, int Hq, int D) {
-  return (int64_t)B * Hq * DEC_SPLIT_MAX * (D + 2);
+  return (int64_t)B * Hq * DEC_SPLIT_MAX * (D + 2) + (int64_t)B * Hq;  // partials + arrival tickets (<= B * Hkv ints)
 }
 
 extern "C" int srgpt_decode_attention(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,

@@ -34,7 +34,7 @@ VitWs carve_vit(const srgpt_vit_weights* w, int n_img, void* ws) {
   v.col = c.take(rows * w->kp * es);
   v.h = c.take(rows * w->hidden * es);
   v.qkv = c.take(rows * 3 * w->hidden * es);
-  v.mlp = c.take(rows * w->inter * es);
+  v.mlp = c.take(rows * w->inter_pad * es);
   v.gws_bytes = (size_t)srgpt_gemm_ws_bytes((int)rows, w->hidden);  // split-K only pays on the narrow (N = hidden) GEMMs
   v.gws = c.take(v.gws_bytes);
   v.total = c.off;
@@ -192,7 +192,9 @@ extern "C" int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images,
   SRGPT_CHECK(w && images && out && ws && n_img > 0, SRGPT_ERR_ARG, "srgpt_vit_forward: bad args");
   // image_size need not be a multiple of patch: a 'valid' conv drops the remainder (384 px / 14 -> 27 patches)
   SRGPT_CHECK(w->hidden % w->heads == 0 && w->image_size >= w->patch, SRGPT_ERR_ARG, "srgpt_vit_forward: bad config");
-  const int dt = w->dtype, C = w->hidden, I = w->inter, H = w->heads, hd = C / H;
+  SRGPT_CHECK(w->inter_pad >= w->inter && w->inter_pad % 8 == 0, SRGPT_ERR_ARG, "srgpt_vit_forward: inter_pad %d < inter %d",
+              w->inter_pad, w->inter);
+  const int dt = w->dtype, C = w->hidden, I = w->inter, IP = w->inter_pad, H = w->heads, hd = C / H;
   const int g = w->image_size / w->patch, gg = g * g, L = gg + (w->cls_emb ? 1 : 0), rows = n_img * L;
   const VitWs v = carve_vit(w, n_img, ws);
   void* x = out;  // residual stream lives in the output buffer
@@ -211,6 +213,10 @@ extern "C" int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images,
   const float scale = 1.0f / sqrtf((float)hd);
   const char* qkv = reinterpret_cast<const char*>(v.qkv);
   const size_t es = dtype_size(dt);
+  if (IP > I)  // the pad columns of the MLP activation buffer: zero once per forward (fc1 never writes them, w2 is zero there)
+    SRGPT_HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(v.mlp) + (size_t)I * es, (size_t)IP * es, 0, (size_t)(IP - I) * es,
+                                   (size_t)rows, as_stream(stream)),
+                  "srgpt_vit_forward: zeroing the activation pad");
   for (int l = 0; l < w->n_layers_run; ++l) {
     SRGPT_TRY(srgpt_layernorm(x, w->ln1_w[l], w->ln1_b[l], v.h, rows, C, w->eps, SRGPT_ACT_NONE, dt, stream));
     SRGPT_TRY(srgpt_gemm(v.h, w->wqkv[l], w->bqkv[l], nullptr, v.qkv, rows, 3 * C, C, C, 3 * C, SRGPT_ACT_NONE, 0, 0, 0,
@@ -221,9 +227,9 @@ extern "C" int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images,
     SRGPT_TRY(srgpt_gemm(v.h, w->wo[l], w->bo[l], x, x, rows, C, C, C, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt,
                          stream));
     SRGPT_TRY(srgpt_layernorm(x, w->ln2_w[l], w->ln2_b[l], v.h, rows, C, w->eps, SRGPT_ACT_NONE, dt, stream));
-    SRGPT_TRY(srgpt_gemm(v.h, w->w1[l], w->b1[l], nullptr, v.mlp, rows, I, C, C, I, w->act, 0, 0, 0,
+    SRGPT_TRY(srgpt_gemm(v.h, w->w1[l], w->b1[l], nullptr, v.mlp, rows, I, C, C, IP, w->act, 0, 0, 0,
                          SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt, stream));
-    SRGPT_TRY(srgpt_gemm(v.mlp, w->w2[l], w->b2[l], x, x, rows, C, I, I, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt,
+    SRGPT_TRY(srgpt_gemm(v.mlp, w->w2[l], w->b2[l], x, x, rows, C, IP, IP, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt,
                          stream));
   }
   return SRGPT_OK;

@@ -42,7 +42,7 @@ class DecodeState:
         nbytes = lib.srgpt_llm_ws_bytes(C.byref(eng.w.llm), batch, ws_tokens)
         if nbytes < 0:
             raise RuntimeError("srgpt_llm_ws_bytes failed")
-        self.ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+        self.ws = torch.zeros((nbytes,), device=dev, dtype=torch.uint8)  # zeroed once: holds the decode-attention arrival tickets
         st = L.LlmState()
         st.batch, st.max_pos, st.max_new, st.ws_tokens = batch, max_pos, max_new, ws_tokens
         st.kcache, st.vcache = self.kcache.data_ptr(), self.vcache.data_ptr()

@@ -173,7 +173,7 @@ def decode_attention(qkv, kcache, vcache, pos, cos_tab, sin_tab, Hq, Hkv, D):
     B = qkv.shape[0]
     max_pos = kcache.shape[-2]
     out = torch.empty((B, Hq * D), device=qkv.device, dtype=qkv.dtype)
-    ws = torch.empty((L.load().srgpt_decode_attn_ws_floats(B, Hq, D),), device=qkv.device, dtype=torch.float32)
+    ws = torch.zeros((L.load().srgpt_decode_attn_ws_floats(B, Hq, D),), device=qkv.device, dtype=torch.float32)  # tickets start at 0
     L.check(L.load().srgpt_decode_attention(_p(qkv), _p(kcache), _p(vcache), _p(pos), _p(cos_tab), _p(sin_tab), _p(out),
                                             _p(ws), B, Hq, Hkv, D, max_pos, dt_code(qkv), _stream()))
     return out

@@ -80,6 +80,7 @@ class PreparedWeights:
         self.pre_ln_w = get(VT + "pre_layrnorm.weight") if clip else None
         self.pre_ln_b = get(VT + "pre_layrnorm.bias") if clip else None
         n_run = cfg.vit_layers_run
+        self.inter_pad = (cfg.vit_inter + 63) // 64 * 64
         v = {k: [] for k in ("ln1_w", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")}
         for i in range(n_run):
             q = f"{VT}encoder.layers.{i}."
@@ -93,12 +94,18 @@ class PreparedWeights:
             v["ln2_b"].append(get(q + "layer_norm2.bias"))
             v["w1"].append(get(q + "mlp.fc1.weight"))
             v["b1"].append(get(q + "mlp.fc1.bias"))
-            v["w2"].append(get(q + "mlp.fc2.weight"))
+            w2 = get(q + "mlp.fc2.weight")  # [hidden, inter] -> [hidden, inter_pad], zero columns (fc2's K tiles exactly by 64)
+            if self.inter_pad != cfg.vit_inter:
+                w2p = torch.zeros((C_, self.inter_pad), device=self.device, dtype=dtype)
+                w2p[:, :cfg.vit_inter] = w2
+                w2 = w2p
+            v["w2"].append(w2)
             v["b2"].append(get(q + "mlp.fc2.bias"))
         self.vit_t = v
         vw = L.VitWeights()
         vw.dtype, vw.hidden, vw.inter, vw.heads = code, C_, cfg.vit_inter, cfg.vit_heads
         vw.n_layers_run, vw.image_size, vw.patch, vw.kp, vw.eps = n_run, cfg.image_size, p, self.kp, cfg.vit_eps
+        vw.inter_pad = self.inter_pad
         vw.act = L.ACT_QUICK_GELU if clip else L.ACT_GELU_TANH
         vw.patch_w, vw.pos_emb = self.patch_w.data_ptr(), self.pos_emb.data_ptr()
         vw.patch_b = None if self.patch_b is None else self.patch_b.data_ptr()
