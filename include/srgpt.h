@@ -72,6 +72,16 @@ int srgpt_gemm(const void* A, const void* W, const void* bias, const void* resid
                int M, int N, int K, int lda, int ldc, int act, int bias_mod, int res_mod,
                int out_f32, int out_mode, int gw, void* ws, int64_t ws_bytes, int dtype, srgpt_stream_t stream);
 
+/* GEMM with weight-only fp8 quantisation (the prefill-side companion of srgpt_gemv_w8, BASELINE config 5):
+ *   C[M,N] = act( (A[M,K] @ fp8(W8[N,K])^T) * wscale[n] + bias[n] ) + residual[M,N]
+ * A / bias / residual / C bf16 (C fp32 if out_f32), W8 = OCP e4m3fn bytes, wscale = one fp32 scale per weight row, fp32
+ * accumulation over the fp8 values widened exactly to bf16; with power-of-two scales this equals srgpt_gemm on the dequantised
+ * bf16 weights bit for bit.  K % 64 == 0 takes the 256 x 256 MFMA kernel, any other K a scalar fallback.  ws: optional fp32
+ * split-K workspace (srgpt_gemm_ws_bytes). */
+int srgpt_gemm_w8(const void* A, const void* W8, const float* wscale, const void* bias, const void* residual, void* C,
+                  int M, int N, int K, int lda, int ldc, int act, int out_f32, void* ws, int64_t ws_bytes,
+                  srgpt_stream_t stream);
+
 /* Decode-only fused GEMVs (any batch; 1-2 rows: VALU kernel, 3+ rows: MFMA kernel, 16 rows per weight pass), weights
  * streamed once from HBM:
  *   norm_w != NULL : x <- RMSNorm(x) * norm_w first (modeling_llama.py:61-75) (rounded to dtype like torch)
@@ -253,8 +263,9 @@ typedef struct {
   const void* const* wgu;       /* per layer [2*inter, hidden]  rows gate;up */
   const void* const* wdown;     /* per layer [hidden, inter] */
   /* Optional fp8 (OCP e4m3fn) copies + per-row fp32 scales of the five streamed matrices.  When wqkv8 != NULL the DECODE
-   * step streams these through srgpt_gemv_w8 (half the bytes per token); prefill keeps using the dtype matrices above,
-   * which the loader fills with the dequantised values so both phases see the same weights. */
+   * step streams these through srgpt_gemv_w8 (half the bytes per token) and prefill multiplies them with srgpt_gemm_w8; the
+   * dtype matrices above (wqkv / wo / wgu / wdown / lm_head) are then never read and may be NULL (per-layer arrays of NULLs):
+   * the fp8 bytes are the only copy of those weights in HBM. */
   const void* lm_head8;
   const float* lm_head_scale;
   const void* const* wqkv8;

@@ -339,6 +339,54 @@ __global__ __launch_bounds__(256) void gemm_f32_simple(const float* __restrict__
     for (int j = 0; j < 4; ++j) epilogue_store<float>(e, m0 + ty * 4 + i, n0 + tx * 4 + j, acc[i][j]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp8-weight fallback for K that is not a multiple of 64 (tiny test geometries): 64x64 tile, BK 16, scalar loads, fp32 FMA
+// on the exactly widened operands -- correctness first, any K
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_w8_simple(const bf16_t* __restrict__ A, const unsigned char* __restrict__ W8,
+                                                      int K, int lda, Epilogue e) {
+  constexpr int BM = 64, BN = 64, BKF = 16;
+  __shared__ float As[BKF][BM + 4];
+  __shared__ float Ws[BKF][BN + 4];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  float acc[4][4] = {};
+  const int lr = tid >> 2, lc = (tid & 3) * 4;  // 64 rows x 4 groups of 4 k per tile
+  for (int k0 = 0; k0 < K; k0 += BKF) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + lc + i;
+      const int m = m0 + lr, n = n0 + lr;
+      As[lc + i][lr] = (m < e.M && k < K) ? to_f(A[(size_t)m * lda + k]) : 0.f;
+      float wv = 0.f;
+      if (n < e.N && k < K) {
+        const int code = W8[(size_t)n * K + k];
+        wv = __builtin_amdgcn_cvt_pk_f32_fp8(code, false)[0];
+      }
+      Ws[lc + i][lr] = wv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BKF; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Ws[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) epilogue_store<bf16_t>(e, m0 + ty * 4 + i, n0 + tx * 4 + j, acc[i][j]);
+}
+
 }  // namespace
 
 extern "C" int64_t srgpt_gemm_ws_bytes(int M, int N) { return (int64_t)8 * M * N * 4; }
@@ -359,7 +407,7 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
     SRGPT_CHECK(out_mode == SRGPT_OUT_PLAIN, SRGPT_ERR_ARG, "srgpt_gemm: unknown out_mode %d", out_mode);
     SRGPT_CHECK(ldc >= N, SRGPT_ERR_ARG, "srgpt_gemm: ldc < N");
   }
-  Epilogue e{bias, residual, C, M, N, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw, nullptr, 1, 0};
+  Epilogue e{bias, residual, C, M, N, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw, nullptr, 1, 0, nullptr};
   hipStream_t s = as_stream(stream);
   if (dtype == SRGPT_F32) {
     dim3 grid(cdiv(N, 64), cdiv(M, 64));
@@ -473,6 +521,49 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
       hipLaunchKernelGGL((gemm_bf16_glds<64, 128, 1>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
   }
   SRGPT_LAUNCH_CHECK();
+  if (e.splits > 1) {
+    const size_t total = (size_t)M * N;
+    int rgrid = (int)((total + 255) / 256);
+    if (rgrid > 2048) rgrid = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(rgrid), dim3(256), 0, s, e);
+    SRGPT_LAUNCH_CHECK();
+  }
+  return SRGPT_OK;
+}
+
+// C = epilogue((A @ fp8(W8)^T) * wscale): bf16 activations, OCP e4m3fn weight bytes, one fp32 scale per weight row -- the
+// prefill-side companion of srgpt_gemv_w8 (BASELINE config 5).  Always the 256 x 256 kernel (W tile staged as bytes, widened
+// to bf16 between LDS and the MFMA operands); K splits (deterministic slabs) when the tiles do not fill the chip.
+extern "C" int srgpt_gemm_w8(const void* A, const void* W8, const float* wscale, const void* bias, const void* residual,
+                             void* C, int M, int N, int K, int lda, int ldc, int act, int out_f32, void* ws,
+                             int64_t ws_bytes, srgpt_stream_t stream) {
+  SRGPT_CHECK(A && W8 && wscale && C, SRGPT_ERR_ARG, "srgpt_gemm_w8: null pointer");
+  SRGPT_CHECK(M > 0 && N > 0 && K > 0, SRGPT_ERR_ARG, "srgpt_gemm_w8: bad shape M=%d N=%d K=%d", M, N, K);
+  SRGPT_CHECK(lda >= K, SRGPT_ERR_ARG, "srgpt_gemm_w8: lda < K");
+  SRGPT_CHECK(ldc >= N, SRGPT_ERR_ARG, "srgpt_gemm_w8: ldc < N");
+  Epilogue e{bias, residual, C, M, N, ldc, act, 0, 0, out_f32, SRGPT_OUT_PLAIN, 0, nullptr, 1, 0, wscale};
+  hipStream_t s = as_stream(stream);
+  if (K % 64 != 0 || lda % 8 != 0 || ((uintptr_t)A % 16) || ((uintptr_t)W8 % 16)) {  // odd geometries: the scalar kernel
+    hipLaunchKernelGGL(gemm_w8_simple, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, s, (const bf16_t*)A,
+                       (const unsigned char*)W8, K, lda, e);
+    SRGPT_LAUNCH_CHECK();
+    return SRGPT_OK;
+  }
+  const int cus = srgpt_device_cus();
+  const int nk = K / 64;
+  const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
+  int sp = 1;
+  if (tiles < cus && ws) {
+    sp = (int)(cus / tiles);
+    if (sp > 4) sp = 4;
+    while (sp > 1 && (nk / sp < 8 || (int64_t)sp * M * N * 4 > ws_bytes)) --sp;
+  }
+  if (sp > 1) {
+    e.partial = reinterpret_cast<float*>(ws);
+    e.tiles_per_split = cdiv(nk, sp);
+    e.splits = cdiv(nk, e.tiles_per_split);
+  }
+  SRGPT_TRY(srgpt_gemm256_launch(A, W8, K, lda, e, s));
   if (e.splits > 1) {
     const size_t total = (size_t)M * N;
     int rgrid = (int)((total + 255) / 256);

@@ -49,11 +49,19 @@ constexpr int G_LDS = 2 * G_BUF;          // 128 KiB
     __builtin_amdgcn_sched_barrier(0);                               \
   } while (0)
 
-template <int ablate>  // 0 = the kernel; 1..4 = timing-only ablations, instantiated in the tuning build only (wrong results):
+// W8: the weight operand is OCP e4m3fn bytes [N, K] with one fp32 (power-of-two) scale per row (BASELINE config 5): the W tile is
+// DMA'd as bytes (16 KiB per K tile, 16 rows x 64 B per wave-instruction, 16-byte chunk ^ ((row >> 2) & 3) -> conflict-free
+// ds_read_b128), one 16-byte read = 16 consecutive k of a row = the B operands of TWO MFMAs after v_cvt_pk_f32_fp8 /
+// v_cvt_pk_bf16_f32, so the A operand takes its 16-byte chunks in the matching order (chunk 4j + 2 hi + e for MFMA 2j + e);
+// the row scale multiplies the accumulator in the epilogue (exact: the bf16 value of code * 2^k is code * 2^k).
+template <int ablate, bool W8>  // ablate 0 = the kernel; 1..4 = timing-only ablations, instantiated in the tuning build only (wrong results):
                        // 1 no DMA in the loop, 2 no DMA waits, 3 no fragment reads after the first tile, 4 no MFMA,
                        // 7 no stagger (lockstep), 9 MFMAs only, 10 MFMAs + barriers only
-__global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __restrict__ A, const void* __restrict__ Wv,
                                                                int K, int lda, Epilogue e, int gx, int gy) {
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(Wv);
+  const unsigned char* W8p = reinterpret_cast<const unsigned char*>(Wv);
+  constexpr int NW = W8 ? 1 : 2;  // DMA instructions per thread for one half (128 rows) of the W tile
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,6 +91,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
   // slot 0: W groups w, w+8 | slot 1: W groups 16+w, 24+w | slot 2: A groups w, 16+w | slot 3: A groups 8+w, 24+w
   const bf16_t* pw[4];
   const bf16_t* pa[4];
+  const unsigned char* pw8[2];  // fp8 W: group g = rows 16g .. 16g+15 (64 B each); this wave stages groups w and 8 + w
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int gw_ = wave + 8 * i;                                  // W: 0..7, 8..15, 16..23, 24..31
@@ -90,7 +99,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
     pw[i] = W + (size_t)min(n0 + gw_ * 8 + lr, e.N - 1) * K + lc * 8;
     pa[i] = A + (size_t)min(m0 + ga_ * 8 + lr, e.M - 1) * lda + lc * 8;
   }
-  auto dma = [&](const bf16_t* src, int lds_off) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)  // lane -> row lane >> 2 of the group, physical chunk lane & 3; (row >> 2) & 3 = (lane >> 4) & 3
+    pw8[i] = W8p + (size_t)min(n0 + (wave + 8 * i) * 16 + (lane >> 2), e.N - 1) * K + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+  auto dma = [&](const void* src, int lds_off) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lds + lds_off), 16, 0, 0);
   };
@@ -100,7 +112,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
     constexpr int sl = decltype(sl_c)::value;
     const int k0 = kt * G_BK;
     const int boff = (kt & 1) * G_BUF;
-    if constexpr (sl == 0) {
+    if constexpr (sl == 0 && W8) {
+      if (which != 1) dma(pw8[0] + k0, boff + G_OPER + (wave + 0) * 1024);
+    } else if constexpr (sl == 1 && W8) {
+      if (which != 1) dma(pw8[1] + k0, boff + G_OPER + (wave + 8) * 1024);
+    } else if constexpr (sl == 0) {
       if (which != 1) dma(pw[0] + k0, boff + G_OPER + (wave + 0) * 1024);
       if (which != 0) dma(pw[1] + k0, boff + G_OPER + (wave + 8) * 1024);
     } else if constexpr (sl == 1) {
@@ -123,11 +139,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
   //      tile rows are multiples of 32, so the swizzle depends on the lane only ----
   const int l31 = lane & 31, hi = lane >> 5, sw = (l31 >> 1) & 7;
   const int frag0 = l31 * 128 + ((hi ^ (sw & 1)) << 4);   // + ((ks ^ (sw >> 1)) << 5) per k-step
-  int koff[4];
+  int koff[4];  // A (and bf16 W) fragment offset of MFMA ks within its 32-row tile
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) koff[ks] = frag0 + ((ks ^ (sw >> 1)) << 5);
+  for (int ks = 0; ks < 4; ++ks) {
+    if constexpr (W8) {  // chunk 4j + 2 hi + e for MFMA ks = 2j + e: the k order of one 16-byte fp8 read of the W row
+      const int slot = 4 * (ks >> 1) + 2 * hi + (ks & 1);
+      koff[ks] = l31 * 128 + ((slot ^ sw) << 4);
+    } else {
+      koff[ks] = frag0 + ((ks ^ (sw >> 1)) << 5);
+    }
+  }
   const int a_base = wr * 128 * 128;                       // + p * 32 * 128 per m-tile
-  const int w_base = G_OPER + wc * 64 * 128;               // + jn * 32 * 128 per n-tile
+  const int w_base = G_OPER + wc * 64 * (W8 ? 64 : 128);   // + jn * 32 rows per n-tile
+  int koff8[2];  // fp8 W: 16-byte chunk (2j + hi) ^ ((row >> 2) & 3) of the 64-byte row
+#pragma unroll
+  for (int j = 0; j < 2; ++j) koff8[j] = l31 * 64 + (((2 * j + hi) ^ ((l31 >> 2) & 3)) << 4);
 
   f32x16 acc[4][2];
   {
@@ -139,6 +165,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
     }
   }
   bf16x8 fw[2][4], fa[2][4];
+  u32x4 raw8[2][2];  // W8: the tile's fp8 W fragments as read from LDS
 
   // ---- prologue: tile kt0 complete, W + A rows 0,1 of tile kt0+1 (its A rows 2,3 are staged in phase 0 of tile kt0) ----
   stage(S0{}, kt0);
@@ -149,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
     stage(S0{}, kt0 + 1);
     stage(S1{}, kt0 + 1);
     stage(S2{}, kt0 + 1);
-    G_VMCNT(6);
+    if constexpr (W8) G_VMCNT(4); else G_VMCNT(6);
   } else {
     G_VMCNT(0);
   }
@@ -175,12 +202,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
     constexpr int P = decltype(p_c)::value;
     const char* buf = lds + (kt & 1) * G_BUF;
     if ((ablate != 3 && ablate != 9 && ablate != 10) || kt == kt0) {
-      if constexpr (P == 0) {
+      if constexpr (P == 0 && !W8) {
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks)
             fw[jn][ks] = *reinterpret_cast<const bf16x8*>(buf + w_base + jn * 32 * 128 + koff[ks]);
+      }
+      if constexpr (P == 0 && W8) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) raw8[jn][j] = *reinterpret_cast<const u32x4*>(buf + w_base + jn * 32 * 64 + koff8[j]);
       }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -191,12 +224,33 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
     __builtin_amdgcn_sched_barrier(0);
     if (ablate == 1 || ablate == 9 || ablate == 10) more1 = more2 = false;
     if constexpr (P == 0) {
-      if (more1) G_WAIT(6); else G_WAIT(0);
+      if (more1) {
+        if constexpr (W8) G_WAIT(4); else G_WAIT(6);
+      } else {
+        G_WAIT(0);
+      }
     } else {
       if (more2) G_WAIT(2); else G_WAIT(0);
     }
     // fragments land before the barrier: whoever passes it may overwrite what this phase read
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (P == 0 && W8) {  // 16 fp8 -> two bf16x8 MFMA operands (k ascending: byte 0 of word 0 is the lowest k)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw8[jn][j][q], false);
+            const f32x2 hh = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw8[jn][j][q], true);
+            bf16x8& dst = fw[jn][2 * j + (q >> 1)];
+            dst[4 * (q & 1) + 0] = (bf16_t)lo[0];
+            dst[4 * (q & 1) + 1] = (bf16_t)lo[1];
+            dst[4 * (q & 1) + 2] = (bf16_t)hh[0];
+            dst[4 * (q & 1) + 3] = (bf16_t)hh[1];
+          }
+    }
     G_BARRIER();
     // -------- multiply part --------
     __builtin_amdgcn_s_setprio(1);
@@ -271,26 +325,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
 // slab reduction (splitk_reduce_kernel in gemm.hip) follows there.
 int srgpt_gemm256_launch(const void* A, const void* W, int K, int lda, const Epilogue& e, hipStream_t s) {
   const int gx = cdiv(e.N, G_BN), gy = cdiv(e.M, G_BM);
-#define G_LAUNCH(AB)                                                                                                        \
+  const bool w8 = e.wscale != nullptr;  // fp8 weight bytes + per-row scales
+#define G_LAUNCH(AB, W8V)                                                                                                    \
   do {                                                                                                                    \
     static std::atomic<uint64_t> attr_done{0};                                                                            \
-    SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)gemm_bf16_256_kernel<AB>, G_LDS));                         \
-    hipLaunchKernelGGL(gemm_bf16_256_kernel<AB>, dim3(gx * gy, e.splits > 1 ? e.splits : 1), dim3(512), G_LDS, s,   \
-                       (const bf16_t*)A, (const bf16_t*)W, K, lda, e, gx, gy);                                            \
+    SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)gemm_bf16_256_kernel<AB, W8V>, G_LDS));                        \
+    hipLaunchKernelGGL((gemm_bf16_256_kernel<AB, W8V>), dim3(gx * gy, e.splits > 1 ? e.splits : 1), dim3(512), G_LDS, s,  \
+                       (const bf16_t*)A, W, K, lda, e, gx, gy);                                                           \
   } while (0)
 #ifdef SRGPT_TUNING_KNOBS
   switch (SRGPT_KNOB("SRGPT_GEMM256_ABLATE", 0)) {
-    case 1: G_LAUNCH(1); break;
-    case 2: G_LAUNCH(2); break;
-    case 3: G_LAUNCH(3); break;
-    case 4: G_LAUNCH(4); break;
-    case 7: G_LAUNCH(7); break;
-    case 9: G_LAUNCH(9); break;    // MFMAs only: no fragment reads, no DMA, no barriers
-    case 10: G_LAUNCH(10); break;  // MFMAs + barriers only
-    default: G_LAUNCH(0); break;
+    case 1: G_LAUNCH(1, false); break;
+    case 2: G_LAUNCH(2, false); break;
+    case 3: G_LAUNCH(3, false); break;
+    case 4: G_LAUNCH(4, false); break;
+    case 7: G_LAUNCH(7, false); break;
+    case 9: G_LAUNCH(9, false); break;    // MFMAs only: no fragment reads, no DMA, no barriers
+    case 10: G_LAUNCH(10, false); break;  // MFMAs + barriers only
+    default:
+      if (w8) G_LAUNCH(0, true); else G_LAUNCH(0, false);
+      break;
   }
 #else
-  G_LAUNCH(0);
+  if (w8) G_LAUNCH(0, true); else G_LAUNCH(0, false);
 #endif
 #undef G_LAUNCH
   SRGPT_LAUNCH_CHECK();

@@ -11,6 +11,7 @@ struct SrgptGemmEpilogue {
   int M, N, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw;
   float* partial;  // split-K: fp32 slabs [splits][M][N] (deterministic: reduced in slab order by splitk_reduce_kernel)
   int splits, tiles_per_split;
+  const float* wscale;  // fp8 weights (srgpt_gemm_w8): one fp32 scale per output column, applied to the accumulator; else NULL
 };
 typedef SrgptGemmEpilogue Epilogue;
 
@@ -19,7 +20,7 @@ namespace {
 template <typename T>
 __device__ __forceinline__ void epilogue_store(const Epilogue& e, int m, int n, float acc) {
   if (m >= e.M || n >= e.N) return;
-  float v = acc;
+  float v = e.wscale ? acc * e.wscale[n] : acc;
   if (e.bias) {
     const int bi = e.bias_mod > 0 ? n % e.bias_mod : n;
     v += to_f(reinterpret_cast<const T*>(e.bias)[bi]);
@@ -58,6 +59,7 @@ __device__ __forceinline__ void epilogue_tile32(const Epilogue& e, int mb, int n
   const T* resid = reinterpret_cast<const T*>(e.residual);
   float b = 0.f;
   if (bias) b = to_f(bias[e.bias_mod > 0 ? n % e.bias_mod : n]);
+  const float sc = e.wscale ? e.wscale[n] : 1.f;
   float res[16];
   if (resid) {
 #pragma unroll
@@ -69,7 +71,7 @@ __device__ __forceinline__ void epilogue_tile32(const Epilogue& e, int mb, int n
   }
   float v[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = rnd<T>(a[r] + b);  // nn.Linear / conv output is materialised in T
+  for (int r = 0; r < 16; ++r) v[r] = rnd<T>(a[r] * sc + b);  // nn.Linear / conv output is materialised in T
   switch (e.act) {
     case SRGPT_ACT_GELU_ERF:
 #pragma unroll

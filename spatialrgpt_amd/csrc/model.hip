@@ -284,25 +284,37 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
   }
   if (hidden_out) SRGPT_HIP_TRY(hipMemcpyAsync(hidden_out, l.x, hid_bytes, hipMemcpyDeviceToDevice, s), "srgpt_llm_prefill: hidden-state copy");
   const float scale = 1.0f / sqrtf((float)D);
+  // fp8 copies present -> they are the weights (srgpt_gemm_w8 / srgpt_gemv_w8); the dtype matrices are not touched
+  const bool w8 = w->wqkv8 != nullptr;
+  if (w8)
+    SRGPT_CHECK(dt == SRGPT_BF16 && w->wo8 && w->wgu8 && w->wdown8 && w->lm_head8 && w->wqkv_scale && w->wo_scale &&
+                    w->wgu_scale && w->wdown_scale && w->lm_head_scale,
+                SRGPT_ERR_ARG, "srgpt_llm_prefill: fp8 weights need bf16 activations and all five matrices + scales");
+  auto mm = [&](const void* a, const void* Wd, const void* W8p, const float* sc, const void* res, void* out, int N, int K,
+                int f32, void* gws, int64_t gws_bytes) -> int {
+    if (w8) return srgpt_gemm_w8(a, W8p, sc, nullptr, res, out, rows, N, K, K, N, SRGPT_ACT_NONE, f32, gws, gws_bytes, stream);
+    return srgpt_gemm(a, Wd, nullptr, res, out, rows, N, K, K, N, SRGPT_ACT_NONE, 0, 0, f32, SRGPT_OUT_PLAIN, 0, gws, gws_bytes, dt,
+                      stream);
+  };
   for (int i = 0; i < w->layers; ++i) {
     char* kc = reinterpret_cast<char*>(st->kcache) + (size_t)i * layer_kv;
     char* vc = reinterpret_cast<char*>(st->vcache) + (size_t)i * layer_kv;
     SRGPT_TRY(srgpt_rmsnorm(l.x, w->attn_norm[i], l.h, rows, Hd, w->rms_eps, dt, stream));
-    SRGPT_TRY(srgpt_gemm(l.h, w->wqkv[i], nullptr, nullptr, l.qkv, rows, QW, Hd, Hd, QW, SRGPT_ACT_NONE, 0, 0, 0,
-                         SRGPT_OUT_PLAIN, 0, l.gws, (int64_t)l.gws_bytes, dt, stream));
+    SRGPT_TRY(mm(l.h, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, nullptr, l.qkv, QW, Hd, 0, l.gws,
+                 (int64_t)l.gws_bytes));
     SRGPT_TRY(srgpt_rope_kv_append(l.qkv, kc, vc, nullptr, w->rope_cos, w->rope_sin, B, T, Hq, Hkv, D, st->max_pos, dt,
                                    stream));
     SRGPT_TRY(srgpt_attention(l.qkv, kc, vc, l.attn, B, T, T, Hq, Hkv, D, (int64_t)T * QW, QW, D,
                               (int64_t)Hkv * st->max_pos * D, D, (int64_t)st->max_pos * D,
                               (int64_t)Hkv * st->max_pos * D, D, (int64_t)st->max_pos * D, scale, 1, nullptr, dt, stream));
-    SRGPT_TRY(srgpt_gemm(l.attn, w->wo[i], nullptr, l.x, l.x, rows, Hd, Hq * D, Hq * D, Hd, SRGPT_ACT_NONE, 0, 0, 0,
-                         SRGPT_OUT_PLAIN, 0, l.gws, (int64_t)l.gws_bytes, dt, stream));
+    SRGPT_TRY(mm(l.attn, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, l.x, l.x, Hd, Hq * D, 0, l.gws,
+                 (int64_t)l.gws_bytes));
     SRGPT_TRY(srgpt_rmsnorm(l.x, w->mlp_norm[i], l.h, rows, Hd, w->rms_eps, dt, stream));
-    SRGPT_TRY(srgpt_gemm(l.h, w->wgu[i], nullptr, nullptr, l.gu, rows, 2 * I, Hd, Hd, 2 * I, SRGPT_ACT_NONE, 0, 0, 0,
-                         SRGPT_OUT_PLAIN, 0, l.gws, (int64_t)l.gws_bytes, dt, stream));
+    SRGPT_TRY(mm(l.h, w->wgu[i], w8 ? w->wgu8[i] : nullptr, w8 ? w->wgu_scale[i] : nullptr, nullptr, l.gu, 2 * I, Hd, 0, l.gws,
+                 (int64_t)l.gws_bytes));
     SRGPT_TRY(srgpt_silu_mul(l.gu, l.act, rows, I, dt, stream));
-    SRGPT_TRY(srgpt_gemm(l.act, w->wdown[i], nullptr, l.x, l.x, rows, Hd, I, I, Hd, SRGPT_ACT_NONE, 0, 0, 0,
-                         SRGPT_OUT_PLAIN, 0, l.gws, (int64_t)l.gws_bytes, dt, stream));
+    SRGPT_TRY(mm(l.act, w->wdown[i], w8 ? w->wdown8[i] : nullptr, w8 ? w->wdown_scale[i] : nullptr, l.x, l.x, Hd, I, 0, l.gws,
+                 (int64_t)l.gws_bytes));
     if (hidden_out)
       SRGPT_HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(hidden_out) + (size_t)(i + 1) * hid_bytes, l.x, hid_bytes,
                                    hipMemcpyDeviceToDevice, s),
@@ -310,8 +322,7 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
   }
   if (all_logits) {
     SRGPT_TRY(srgpt_rmsnorm(l.x, w->final_norm, l.h, rows, Hd, w->rms_eps, dt, stream));
-    SRGPT_TRY(srgpt_gemm(l.h, w->lm_head, nullptr, nullptr, all_logits, rows, w->vocab, Hd, Hd, w->vocab, SRGPT_ACT_NONE,
-                         0, 0, 1, SRGPT_OUT_PLAIN, 0, nullptr, 0, dt, stream));
+    SRGPT_TRY(mm(l.h, w->lm_head, w->lm_head8, w->lm_head_scale, nullptr, all_logits, w->vocab, Hd, 1, nullptr, 0));
   }
   // last position of every sequence -> logits (final norm fused into the GEMV prologue)
   if (lens) {  // right-padded ragged batch: row b ends at lens[b] - 1 and decoding continues from position lens[b]
@@ -332,8 +343,11 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
     hipLaunchKernelGGL(set_int_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, st->pos, B, T);
     SRGPT_LAUNCH_CHECK();
   }
-  SRGPT_TRY(srgpt_gemv(l.last, w->lm_head, w->final_norm, w->rms_eps, nullptr, st->logits, B, w->vocab, Hd, 0, 1, dt,
-                       stream));
+  if (w8)
+    SRGPT_TRY(srgpt_gemv_w8(l.last, w->lm_head8, w->lm_head_scale, w->final_norm, w->rms_eps, nullptr, st->logits, B, w->vocab, Hd,
+                            0, 1, stream));
+  else
+    SRGPT_TRY(srgpt_gemv(l.last, w->lm_head, w->final_norm, w->rms_eps, nullptr, st->logits, B, w->vocab, Hd, 0, 1, dt, stream));
   return SRGPT_OK;
 }
 

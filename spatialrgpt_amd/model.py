@@ -231,7 +231,8 @@ class LlavaLlamaModel:
         return self.llm
 
     def get_lm_head(self):
-        return self.engine.w.lm_head
+        w = self.engine.w
+        return w.lm_head if w.lm_head is not None else w.dequantised("lm_head")
 
     def get_vision_tower(self):
         return self.vision_tower

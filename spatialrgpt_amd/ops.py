@@ -121,6 +121,24 @@ def gemv_w8(x, w8, wscale, norm_w=None, eps=0.0, residual=None, swiglu=False, ou
     return out
 
 
+def gemm_w8(a, w8, wscale, bias=None, residual=None, act=L.ACT_NONE, out=None, out_f32=False):
+    """act((a @ fp8(w8).T) * wscale + bias) + residual: a [M,K] bf16 (row stride may exceed K), w8 uint8 [N,K] (OCP e4m3fn),
+    wscale fp32 [N]."""
+    _dev(a, w8, wscale, bias, residual)
+    _same_dtype("gemm_w8", a, bias=bias, residual=residual)
+    if a.dtype != torch.bfloat16 or w8.dtype != torch.uint8 or wscale.dtype != torch.float32:
+        raise ValueError("gemm_w8: a must be bf16, w8 uint8, wscale fp32")
+    M, K = a.shape
+    N = w8.shape[0]
+    assert w8.shape[1] == K and a.stride(1) == 1 and w8.is_contiguous() and wscale.numel() == N
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    ws = _splitk_ws(a.device, M, N) if M * N <= (1 << 24) else None
+    L.check(L.load().srgpt_gemm_w8(_p(a), _p(w8), _p(wscale), _p(bias), _p(residual), _p(out), M, N, K, a.stride(0), out.stride(0),
+                                   act, int(out_f32), _p(ws), 0 if ws is None else ws.numel(), _stream()))
+    return out
+
+
 def layernorm(x, w, b, eps, act=L.ACT_NONE, out=None):
     _dev(x, w, b)
     _same_dtype("layernorm", x, weight=w, bias=b, out=out)

@@ -28,7 +28,7 @@ LM = "llm."
 def _ptr_array(tensors: List[torch.Tensor]):
     arr = (L.vp * len(tensors))()
     for i, t in enumerate(tensors):
-        arr[i] = t.data_ptr()
+        arr[i] = None if t is None else t.data_ptr()
     return arr
 
 
@@ -48,8 +48,9 @@ class PreparedWeights:
     def __init__(self, cfg: SrgptConfig, sd: Dict[str, torch.Tensor], device, dtype, rope_positions: int = 0,
                  consume: bool = False, llm_weight_format: str = "native"):
         """llm_weight_format: "native" (the engine dtype) or "fp8" -- weight-only OCP e4m3fn quantisation of the five
-        streamed LLM matrices with one fp32 scale per output row (BASELINE config 5; bf16 engines only): the decode step
-        streams the fp8 bytes, prefill uses the dequantised bf16 values of the SAME quantised weights."""
+        streamed LLM matrices with one fp32 (power-of-two) scale per output row (BASELINE config 5; bf16 engines only).  The
+        fp8 bytes are the ONLY copy of those matrices in HBM: decode streams them (srgpt_gemv_w8), prefill multiplies them
+        (srgpt_gemm_w8); `dequantised(name, layer)` rebuilds the bf16 values for checks."""
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         if llm_weight_format not in ("native", "fp8"):
             raise ValueError(f"unknown llm_weight_format {llm_weight_format!r}")
@@ -159,11 +160,12 @@ class PreparedWeights:
             qd = {k: ([], []) for k in ("wqkv", "wo", "wgu", "wdown")}
             for k in qd:
                 for i in range(cfg.layers):
-                    q8, sc, deq = ops.quantize_fp8_rows(lt[k][i])
-                    lt[k][i] = deq
+                    q8, sc, _ = ops.quantize_fp8_rows(lt[k][i])
+                    lt[k][i] = None  # the bf16 matrix is dropped: nothing reads it
                     qd[k][0].append(q8)
                     qd[k][1].append(sc)
-            self.lm_head8, self.lm_head_scale, self.lm_head = ops.quantize_fp8_rows(self.lm_head)
+            self.lm_head8, self.lm_head_scale, _ = ops.quantize_fp8_rows(self.lm_head)
+            self.lm_head = None
             self.llm_q = qd
         n_pos = rope_positions or cfg.max_position_embeddings
         self.rope_len = n_pos
@@ -172,7 +174,8 @@ class PreparedWeights:
         lw.dtype, lw.hidden, lw.inter, lw.layers = code, cfg.hidden, cfg.inter, cfg.layers
         lw.heads, lw.kv_heads, lw.head_dim, lw.vocab, lw.rms_eps = cfg.heads, cfg.kv_heads, cfg.head_dim, self.embed.shape[0], cfg.rms_eps
         lw.rope_cos, lw.rope_sin = self.rope_cos.data_ptr(), self.rope_sin.data_ptr()
-        lw.embed, lw.final_norm, lw.lm_head = self.embed.data_ptr(), self.final_norm.data_ptr(), self.lm_head.data_ptr()
+        lw.embed, lw.final_norm = self.embed.data_ptr(), self.final_norm.data_ptr()
+        lw.lm_head = None if self.lm_head is None else self.lm_head.data_ptr()
         for k, ts in lt.items():
             arr = _ptr_array(ts)
             self._keep.append(arr)
@@ -186,6 +189,13 @@ class PreparedWeights:
                 setattr(lw, k + "_scale", asc)
         self.llm = lw
         self.vocab = self.embed.shape[0]
+
+    def dequantised(self, name: str, layer: int = 0) -> torch.Tensor:
+        """bf16 values of an fp8-held matrix ("wqkv" | "wo" | "wgu" | "wdown" | "lm_head"): code * scale, exact in bf16."""
+        if self.llm_q is None:
+            raise ValueError("weights are not fp8")
+        q8, sc = (self.lm_head8, self.lm_head_scale) if name == "lm_head" else (self.llm_q[name][0][layer], self.llm_q[name][1][layer])
+        return (q8.view(torch.float8_e4m3fn).float() * sc[:, None]).to(self.dtype)
 
     def llm_weight_bytes(self) -> int:
         """bytes streamed from HBM per decoded token at batch 1 (everything but embed_tokens)."""

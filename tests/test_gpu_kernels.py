@@ -124,6 +124,33 @@ def test_gemm_256_deconv_epilogue():
     assert_close(out.reshape(n_img, 4 * g * g, C), ref, _tol(ref, torch.bfloat16), 0, "gemm256 deconv2x")
 
 
+@pytest.mark.parametrize("M,N,K", [(259, 6144, 4096), (2072, 4096, 4096), (300, 1000, 512), (64, 128258 // 8, 256), (1036, 28672 // 4, 4096),
+                                   (210, 64, 160), (37, 130, 72)])  # the last two: K % 64 != 0 -> scalar fallback
+def test_gemm_w8_equals_gemm_on_dequantised_weights(M, N, K):
+    """srgpt_gemm_w8 (fp8 weight bytes staged through LDS, widened to bf16 in front of the MFMA, row scale in the epilogue) ==
+    srgpt_gemm on dequant(quant(W)): BIT-identical for the plain product (power-of-two scales commute with the fp32
+    accumulation) -- compared at equal K-split so the accumulation order is the same -- and within bf16 tolerance of fp32 torch
+    with a bias / SiLU / residual epilogue."""
+    ops, L = _ops()
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N)
+    a = torch.randn((M, K), generator=g, device=DEV).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+    b = torch.randn((N,), generator=g, device=DEV).to(torch.bfloat16)
+    r = torch.randn((M, N), generator=g, device=DEV).to(torch.bfloat16)
+    q8, sc, deq = ops.quantize_fp8_rows(w)
+    ref = a.float() @ deq.float().T
+    out = ops.gemm_w8(a, q8, sc)
+    assert_close(out, ref, _tol(ref, torch.bfloat16), 0, "gemm_w8 vs fp32 torch on the dequantised weights")
+    out2 = ops.gemm_w8(a, q8, sc, b, r, act=L.ACT_SILU)
+    ref2 = F.silu((ref + b.float()).to(torch.bfloat16).float()).to(torch.bfloat16).float() + r.float()
+    assert_close(out2, ref2, _tol(ref2, torch.bfloat16), 0, "gemm_w8 bias + silu + residual")
+    for _ in range(2):
+        assert torch.equal(ops.gemm_w8(a, q8, sc, b, r, act=L.ACT_SILU), out2), "run-to-run difference"
+    lo = ops.gemm_w8(a, q8, sc, out_f32=True)
+    assert lo.dtype == torch.float32
+    assert_close(lo, ref, _tol(ref, torch.bfloat16), 0, "gemm_w8 fp32 out")
+
+
 # ------------------------------------------------------------------------------------------------ GEMV
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("B,N,K", [(1, 1000, 4096), (1, 1001, 4096), (2, 512, 11008), (4, 300, 1024), (1, 128, 64),

@@ -227,9 +227,10 @@ def test_fp8_weight_decode_vs_oracle_on_dequantised_weights(batch):
     w = so.synth_weights(ocfg, seed=3, dtype=dtype)
     wq = so.fp8_dequantised_weights(w)
     eng = SrgptEngine(SrgptConfig(**kw), dict(w), device=DEV, dtype=dtype, rope_positions=512, llm_weight_format="fp8")
-    # the engine's dequantised matrices are bit-identical to the oracle's
-    assert torch.equal(eng.w.lm_head.cpu(), wq["llm.lm_head.weight"])
-    assert torch.equal(eng.w.llm_t["wdown"][1].cpu(), wq["llm.model.layers.1.mlp.down_proj.weight"])
+    # the fp8 bytes are the only copy the engine holds; code * scale is bit-identical to the oracle's dequantised matrices
+    assert eng.w.lm_head is None and all(t is None for t in eng.w.llm_t["wdown"])
+    assert torch.equal(eng.w.dequantised("lm_head").cpu(), wq["llm.lm_head.weight"])
+    assert torch.equal(eng.w.dequantised("wdown", 1).cpu(), wq["llm.model.layers.1.mlp.down_proj.weight"])
     assert eng.w.llm_weight_bytes() < 0.55 * sum(t.numel() * 2 for k, t in w.items() if k.startswith("llm.") and "embed" not in k)
     g = torch.Generator().manual_seed(5)
     T, G = 37, 5
