@@ -243,6 +243,20 @@ __global__ __launch_bounds__(64) void simple_attn_kernel(const T* __restrict__ q
 constexpr int DEC_CHUNK_MAX = 256;
 constexpr int DEC_SPLIT_MAX = 64;
 
+// L2 prefetch riding on the decode-attention launch: the attention blocks leave HBM idle (they move ~1 MB), and the kernel
+// that follows (o_proj, a weight-streaming GEMV) pays a full memory latency before its first FMA.  Extra blocks of THIS launch
+// pull the rows the GEMV's blocks will read into the L2 of the XCD those blocks will run on (block j of a launch runs on XCD
+// j % 8; a wrong guess costs speed, never correctness): prefetch block p loads the rows of GEMV block p.
+struct DecodePrefetch {
+  const char* base;      // weight matrix the next GEMV streams (NULL: no prefetch blocks)
+  long long row_bytes;   // bytes per weight row
+  int unit_rows;         // rows per GEMV work unit (1: bf16 row per wave; 2: fp8 column pair)
+  int n_units;           // units of the GEMV
+  int gemv_grid;         // blocks the GEMV will launch (a wave's units are unit0 + k * gemv_grid * 4)
+  int rounds;            // how many of a wave's units to prefetch (L2 capacity: 4 MiB per XCD)
+  int nblocks;           // prefetch blocks appended to the attention grid
+};
+
 static inline int decode_nsplit(int max_pos) {
   const int env_min = SRGPT_KNOB("SRGPT_DECODE_MIN_SPLITS", 16);  // tuning knob
   int n = cdiv(max_pos, DEC_CHUNK_MAX);
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
                                                            const T* __restrict__ cos_tab, const T* __restrict__ sin_tab,
                                                            float* __restrict__ ws, int* __restrict__ tickets,
                                                            T* __restrict__ out, int Hq, int Hkv, int max_pos,
-                                                           int nsplit, float scale) {
+                                                           int nsplit, float scale, int n_attn, DecodePrefetch pf) {
   constexpr int VEC = Vec16<T>::N;
   constexpr int LPK = D / VEC;   // lanes per key
   constexpr int KPW = 64 / LPK;  // keys per wave-instruction
@@ -270,8 +284,22 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   __shared__ float red[4][G][D];
   __shared__ float stat_m[G], stat_l[G];
 
-  const int hk = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= n_attn) {  // ---- prefetch block (see DecodePrefetch) ----
+    const int p = (int)blockIdx.x - n_attn;
+    const int per_row = (int)(pf.row_bytes >> 10);  // 1 KiB wave-loads per row
+    int done = 0;
+    for (int u = p * 4 + wave; u < pf.n_units && done < pf.rounds; u += pf.gemv_grid * 4, ++done)
+      for (int r = 0; r < pf.unit_rows; ++r) {
+        const char* row = pf.base + (size_t)(u * pf.unit_rows + r) * pf.row_bytes + lane * 16;
+        for (int c = 0; c < per_row; ++c) {
+          u32x4 v = *reinterpret_cast<const u32x4*>(row + ((size_t)c << 10));
+          asm volatile("" ::"v"(v));  // keep the load; the data is dropped
+        }
+      }
+    return;
+  }
+  const int hk = (int)blockIdx.x % Hkv, split = ((int)blockIdx.x / Hkv) % nsplit, b = (int)blockIdx.x / (Hkv * nsplit);
   const int P = pos[b];
   const int total = P + 1;
   const int chunk = (total + nsplit - 1) / nsplit;
@@ -527,11 +555,12 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
 template <typename T, int D>
 int launch_decode_d(int G, const void* qkv, void* kc, void* vc, const int* pos, const void* ct, const void* st,
                     float* ws, int* tickets, void* out, int B, int Hq, int Hkv, int max_pos, int nsplit, float scale,
-                    hipStream_t s) {
-  dim3 grid(Hkv, nsplit, B);
+                    const DecodePrefetch& pf, hipStream_t s) {
+  const int n_attn = Hkv * nsplit * B;
+  dim3 grid(n_attn + (pf.base ? pf.nblocks : 0));
 #define LD(GG)                                                                                                     \
   hipLaunchKernelGGL((decode_split_kernel<T, D, GG>), grid, dim3(256), 0, s, (const T*)qkv, (T*)kc, (T*)vc, pos, \
-                     (const T*)ct, (const T*)st, ws, tickets, (T*)out, Hq, Hkv, max_pos, nsplit, scale)
+                     (const T*)ct, (const T*)st, ws, tickets, (T*)out, Hq, Hkv, max_pos, nsplit, scale, n_attn, pf)
   switch (G) {
     case 1: LD(1); break;
     case 2: LD(2); break;
@@ -547,7 +576,7 @@ int launch_decode_d(int G, const void* qkv, void* kc, void* vc, const int* pos, 
 
 template <typename T>
 int launch_decode(const void* qkv, void* kc, void* vc, const int* pos, const void* ct, const void* st, void* out,
-                  float* ws, int B, int Hq, int Hkv, int D, int max_pos, hipStream_t s) {
+                  float* ws, int B, int Hq, int Hkv, int D, int max_pos, const DecodePrefetch& pf, hipStream_t s) {
   const int G = Hq / Hkv;
   const int nsplit = decode_nsplit(max_pos);
   // a split's scores live in LDS (sc[G][DEC_CHUNK_MAX]): the longest chunk is ceil(max_pos / nsplit) keys
@@ -557,10 +586,10 @@ int launch_decode(const void* qkv, void* kc, void* vc, const int* pos, const voi
   int* tickets = reinterpret_cast<int*>(ws + (size_t)B * Hq * DEC_SPLIT_MAX * (D + 2));  // int[B * Hkv] behind the partials
   int rc;
   switch (D) {
-    case 16: rc = launch_decode_d<T, 16>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
-    case 32: rc = launch_decode_d<T, 32>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
-    case 64: rc = launch_decode_d<T, 64>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
-    case 128: rc = launch_decode_d<T, 128>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, s); break;
+    case 16: rc = launch_decode_d<T, 16>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, pf, s); break;
+    case 32: rc = launch_decode_d<T, 32>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, pf, s); break;
+    case 64: rc = launch_decode_d<T, 64>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, pf, s); break;
+    case 128: rc = launch_decode_d<T, 128>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, pf, s); break;
     default:
       srgpt_set_error("srgpt_decode_attention: head_dim %d not supported (16,32,64,128)", D);
       return SRGPT_ERR_UNSUPPORTED;
@@ -576,20 +605,46 @@ extern "C" int64_t srgpt_decode_attn_ws_floats(int B, int Hq, int D) {
   return (int64_t)B * Hq * DEC_SPLIT_MAX * (D + 2) + (int64_t)B * Hq;  // partials + arrival tickets (<= B * Hkv ints)
 }
 
-extern "C" int srgpt_decode_attention(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
-                                      const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D,
-                                      int max_pos, int dtype, srgpt_stream_t stream) {
+// internal entry (model.hip): decode attention + L2 prefetch of the weight matrix the next GEMV streams.
+// next_w = NULL -> no prefetch.  batch > 2 goes through the skinny kernel, whose row mapping differs: no prefetch there.
+int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
+                              const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D, int max_pos, int dtype,
+                              const void* next_w, int next_n, int next_k, int next_fp8, srgpt_stream_t stream) {
   SRGPT_CHECK(qkv && kcache && vcache && pos && cos_tab && sin_tab && out && ws, SRGPT_ERR_ARG,
               "srgpt_decode_attention: null pointer");
   SRGPT_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, SRGPT_ERR_ARG, "srgpt_decode_attention: bad heads");
+  DecodePrefetch pf{nullptr, 0, 1, 0, 1, 0, 0};
+  const int pf_rounds = SRGPT_KNOB("SRGPT_DECODE_PREFETCH_ROUNDS", 2);  // 0 = off; 2 = all of o_proj (measured 3.189 / 3.169 / 3.138 ms per token at 0 / 1 / 2)
+  if (next_w && B <= 2 && pf_rounds > 0 && dtype == SRGPT_BF16) {
+    const int cus = srgpt_device_cus();
+    const long long row_bytes = next_fp8 ? (long long)next_k : 2LL * next_k;
+    if (row_bytes % 1024 == 0) {
+      pf.base = reinterpret_cast<const char*>(next_w);
+      pf.row_bytes = row_bytes;
+      pf.unit_rows = next_fp8 ? 2 : 1;
+      pf.n_units = next_fp8 ? (next_n + 1) / 2 : next_n;
+      int grid = (pf.n_units + 3) / 4;  // the GEMV launchers' grid (gemv.hip launch_gemv / gemv_w8.hip): 2 blocks per CU
+      if (grid > cus * 2) grid = cus * 2;
+      pf.gemv_grid = grid;
+      pf.rounds = pf_rounds;
+      pf.nblocks = grid;
+    }
+  }
   if (dtype == SRGPT_BF16)
-    return launch_decode<bf16_t>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos,
+    return launch_decode<bf16_t>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos, pf,
                                  as_stream(stream));
   if (dtype == SRGPT_F32)
-    return launch_decode<float>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos,
+    return launch_decode<float>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos, pf,
                                 as_stream(stream));
   srgpt_set_error("srgpt_decode_attention: bad dtype %d", dtype);
   return SRGPT_ERR_ARG;
+}
+
+extern "C" int srgpt_decode_attention(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
+                                      const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D,
+                                      int max_pos, int dtype, srgpt_stream_t stream) {
+  return srgpt_decode_attention_pf(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos, dtype, nullptr, 0,
+                                   0, 0, stream);
 }
 
 extern "C" int srgpt_attention(const void* q, const void* k, const void* v, void* o, int B, int Tq, int Tk, int Hq,

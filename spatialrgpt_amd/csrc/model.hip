@@ -5,6 +5,10 @@
 
 #include "common.h"
 
+int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
+                              const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D, int max_pos, int dtype,
+                              const void* next_w, int next_n, int next_k, int next_fp8, srgpt_stream_t stream);  // attn.hip
+
 namespace {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -395,8 +399,9 @@ extern "C" int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state
     char* vc = reinterpret_cast<char*>(st->vcache) + (size_t)i * layer_kv;
     SRGPT_TRY(mv(d.xd, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, w->attn_norm[i], nullptr,
                  d.qkvd, QW, Hd, 0, 0));
-    SRGPT_TRY(srgpt_decode_attention(d.qkvd, kc, vc, st->pos, w->rope_cos, w->rope_sin, d.attnd, d.dws, B, Hq, Hkv, D,
-                                     st->max_pos, dt, stream));
+    // the attention launch also pulls o_proj's weights into L2 (HBM is idle while it runs)
+    SRGPT_TRY(srgpt_decode_attention_pf(d.qkvd, kc, vc, st->pos, w->rope_cos, w->rope_sin, d.attnd, d.dws, B, Hq, Hkv, D,
+                                        st->max_pos, dt, w8 ? w->wo8[i] : w->wo[i], Hd, Hq * D, w8 ? 1 : 0, stream));
     SRGPT_TRY(mv(d.attnd, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, nullptr, d.xd, d.xd, Hd,
                  Hq * D, 0, 0));
     SRGPT_TRY(mv(d.xd, w->wgu[i], w8 ? w->wgu8[i] : nullptr, w8 ? w->wgu_scale[i] : nullptr, w->mlp_norm[i], nullptr,
