@@ -243,19 +243,7 @@ __global__ __launch_bounds__(64) void simple_attn_kernel(const T* __restrict__ q
 constexpr int DEC_CHUNK_MAX = 256;
 constexpr int DEC_SPLIT_MAX = 64;
 
-// L2 prefetch riding on the decode-attention launch: the attention blocks leave HBM idle (they move ~1 MB), and the kernel
-// that follows (o_proj, a weight-streaming GEMV) pays a full memory latency before its first FMA.  Extra blocks of THIS launch
-// pull the rows the GEMV's blocks will read into the L2 of the XCD those blocks will run on (block j of a launch runs on XCD
-// j % 8; a wrong guess costs speed, never correctness): prefetch block p loads the rows of GEMV block p.
-struct DecodePrefetch {
-  const char* base;      // weight matrix the next GEMV streams (NULL: no prefetch blocks)
-  long long row_bytes;   // bytes per weight row
-  int unit_rows;         // rows per GEMV work unit (1: bf16 row per wave; 2: fp8 column pair)
-  int n_units;           // units of the GEMV
-  int gemv_grid;         // blocks the GEMV will launch (a wave's units are unit0 + k * gemv_grid * 4)
-  int rounds;            // how many of a wave's units to prefetch (L2 capacity: 4 MiB per XCD)
-  int nblocks;           // prefetch blocks appended to the attention grid
-};
+typedef SrgptPrefetch DecodePrefetch;  // common.h: L2 prefetch blocks appended to the launch (here: o_proj's weights)
 
 static inline int decode_nsplit(int max_pos) {
   const int env_min = SRGPT_KNOB("SRGPT_DECODE_MIN_SPLITS", 16);  // tuning knob
@@ -285,18 +273,8 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   __shared__ float stat_m[G], stat_l[G];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((int)blockIdx.x >= n_attn) {  // ---- prefetch block (see DecodePrefetch) ----
-    const int p = (int)blockIdx.x - n_attn;
-    const int per_row = (int)(pf.row_bytes >> 10);  // 1 KiB wave-loads per row
-    int done = 0;
-    for (int u = p * 4 + wave; u < pf.n_units && done < pf.rounds; u += pf.gemv_grid * 4, ++done)
-      for (int r = 0; r < pf.unit_rows; ++r) {
-        const char* row = pf.base + (size_t)(u * pf.unit_rows + r) * pf.row_bytes + lane * 16;
-        for (int c = 0; c < per_row; ++c) {
-          u32x4 v = *reinterpret_cast<const u32x4*>(row + ((size_t)c << 10));
-          asm volatile("" ::"v"(v));  // keep the load; the data is dropped
-        }
-      }
+  if ((int)blockIdx.x >= n_attn) {  // ---- prefetch block (common.h) ----
+    srgpt_prefetch_block(pf, (int)blockIdx.x - n_attn, wave, lane);
     return;
   }
   const int hk = (int)blockIdx.x % Hkv, split = ((int)blockIdx.x / Hkv) % nsplit, b = (int)blockIdx.x / (Hkv * nsplit);
@@ -613,23 +591,10 @@ int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const
   SRGPT_CHECK(qkv && kcache && vcache && pos && cos_tab && sin_tab && out && ws, SRGPT_ERR_ARG,
               "srgpt_decode_attention: null pointer");
   SRGPT_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, SRGPT_ERR_ARG, "srgpt_decode_attention: bad heads");
-  DecodePrefetch pf{nullptr, 0, 1, 0, 1, 0, 0};
-  const int pf_rounds = SRGPT_KNOB("SRGPT_DECODE_PREFETCH_ROUNDS", 2);  // 0 = off; 2 = all of o_proj (measured 3.189 / 3.169 / 3.138 ms per token at 0 / 1 / 2)
-  if (next_w && B <= 2 && pf_rounds > 0 && dtype == SRGPT_BF16) {
-    const int cus = srgpt_device_cus();
-    const long long row_bytes = next_fp8 ? (long long)next_k : 2LL * next_k;
-    if (row_bytes % 1024 == 0) {
-      pf.base = reinterpret_cast<const char*>(next_w);
-      pf.row_bytes = row_bytes;
-      pf.unit_rows = next_fp8 ? 2 : 1;
-      pf.n_units = next_fp8 ? (next_n + 1) / 2 : next_n;
-      int grid = (pf.n_units + 3) / 4;  // the GEMV launchers' grid (gemv.hip launch_gemv / gemv_w8.hip): 2 blocks per CU
-      if (grid > cus * 2) grid = cus * 2;
-      pf.gemv_grid = grid;
-      pf.rounds = pf_rounds;
-      pf.nblocks = grid;
-    }
-  }
+  // 0 = off; 2 = all of o_proj (measured 3.189 / 3.169 / 3.138 ms per token at 0 / 1 / 2 rounds)
+  const int pf_rounds = SRGPT_KNOB("SRGPT_DECODE_PREFETCH_ROUNDS", 2);
+  const DecodePrefetch pf = dtype == SRGPT_BF16 ? srgpt_prefetch_for_gemv(next_w, next_n, next_k, 0, next_fp8, B, pf_rounds, 0)
+                                                : srgpt_prefetch_for_gemv(nullptr, 0, 0, 0, 0, B, 0, 0);
   if (dtype == SRGPT_BF16)
     return launch_decode<bf16_t>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos, pf,
                                  as_stream(stream));

@@ -166,3 +166,62 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     default: return x;
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// L2 prefetch blocks riding on a decode-step launch.  A batch-1 decode step is a chain of weight-streaming GEMVs separated by
+// kernel boundaries: every GEMV pays a full memory latency before its first FMA, and the launch in front of it leaves HBM
+// idle while it drains (or, for the attention kernel, for its whole duration).  Extra blocks appended to launch N pull the
+// first rows launch N+1 will read into the L2 of the XCD its blocks will run on (block j of a launch runs on XCD j % 8 -- a
+// wrong guess costs speed, never correctness): prefetch block p loads what GEMV block p will read first.  Being the LAST
+// blocks of the grid they are dispatched as the compute blocks retire, i.e. into the drain.
+// ------------------------------------------------------------------------------------------------
+struct SrgptPrefetch {
+  const char* base;      // weight matrix of the next GEMV (NULL: no prefetch blocks)
+  long long row_bytes;   // stride between weight rows
+  int prefix_bytes;      // leading bytes of each row to pull (multiple of 1024; the whole row if >= row_bytes)
+  int n_units;           // work units of the next GEMV (a wave owns units unit0 + k * gemv_grid * 4)
+  int unit_rows;         // rows per unit
+  int umul, rstride;     // row of (unit u, r) = u * umul + r * rstride  (plain: 1, -; SwiGLU gate/up: 1, N; fp8 column pair: 2, 1)
+  int gemv_grid;         // compute blocks the next GEMV launches
+  int rounds;            // how many of a wave's units to pull
+  int nblocks;           // prefetch blocks appended to this launch (= gemv_grid)
+};
+
+__device__ __forceinline__ void srgpt_prefetch_block(const SrgptPrefetch& pf, int p, int wave, int lane) {
+  const int per_row = (int)((pf.prefix_bytes < pf.row_bytes ? (long long)pf.prefix_bytes : pf.row_bytes) >> 10);
+  int done = 0;
+  for (int u = p * 4 + wave; u < pf.n_units && done < pf.rounds; u += pf.gemv_grid * 4, ++done)
+    for (int r = 0; r < pf.unit_rows; ++r) {
+      const char* row = pf.base + (size_t)((long long)u * pf.umul + (long long)r * pf.rstride) * pf.row_bytes + lane * 16;
+      for (int c = 0; c < per_row; ++c) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(row + ((size_t)c << 10));
+        asm volatile("" ::"v"(v));  // keep the load; the data is dropped
+      }
+    }
+}
+
+extern "C" int srgpt_device_cus(void);
+// descriptor for "the next launch is the batch-`batch` decode GEMV over W [N (2N if swiglu), K]" (bf16 rows, or fp8 bytes).
+// Mirrors the grid / unit mapping of gemv.hip's and gemv_w8.hip's launchers for batch <= 2 (the VALU kernels); anything else
+// (3+ rows: the skinny kernel, fp8 SwiGLU units of four rows) gets no prefetch.
+static inline SrgptPrefetch srgpt_prefetch_for_gemv(const void* W, int N, int K, int swiglu, int fp8, int batch, int rounds,
+                                                    int prefix_bytes) {
+  SrgptPrefetch pf{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0};
+  const long long row_bytes = fp8 ? (long long)K : 2LL * K;
+  if (!W || batch > 2 || rounds <= 0 || row_bytes % 1024 != 0 || (fp8 && swiglu)) return pf;
+  const int cus = srgpt_device_cus();
+  const int per_cu = (size_t)batch * K * 2 > 70 * 1024 ? 1 : 2;
+  pf.base = reinterpret_cast<const char*>(W);
+  pf.row_bytes = row_bytes;
+  pf.prefix_bytes = prefix_bytes > 0 ? prefix_bytes : (int)row_bytes;
+  pf.n_units = fp8 ? (N + 1) / 2 : N;
+  pf.unit_rows = (fp8 || swiglu) ? 2 : 1;
+  pf.umul = fp8 ? 2 : 1;
+  pf.rstride = fp8 ? 1 : N;
+  int grid = (pf.n_units + 3) / 4;
+  if (grid > cus * per_cu) grid = cus * per_cu;
+  pf.gemv_grid = grid;
+  pf.rounds = rounds;
+  pf.nblocks = grid;
+  return pf;
+}
