@@ -3,7 +3,7 @@ import json
 import re
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
 g, p = "gpurun_out/" + tag, "profiles/" + tag
 d = json.loads(open(g + "_bench_default.json").read().strip().splitlines()[-1])
 open(p + "_bench.json", "w").write(json.dumps(d, indent=1) + "\n")
@@ -31,8 +31,8 @@ for l in open(g + "_pmc_mfma.txt").read().splitlines():
     nd, mf, gui, name = int(mm.group(1)), float(mm.group(2)), float(mm.group(4)), mm.group(5)
     if mf > 0:
         out.append(f"{nd:10d} {mf:16.0f} {gui:14.0f} {100 * mf / ((gui / 8) * 1024):12.1f}  {name[:100]}")
-out += ["# the GEMMs of this workload are small (M = 259 prefill, M = 1458 ViT: 20-140 us each) and latency-bound; the same kernel reaches",
-        "# 779 TF/s = 31 % of the 2.5 PF dense bf16 peak at 4096^3 (scripts/ubench_gemm.py); the prefix they dominate is ~16 ms of the ~426 ms request."]
+out += ["# the GEMMs of the bs=1 workload are small (M = 259 prefill, M = 1458 ViT: 20-140 us each) and latency-bound; shapes that fill the chip",
+        "# go through gemm256 (profiles/r02_gemm256_*.txt: 1.10 PF/s at 4096^3 = 80 % of the same kernel's MFMA-only rate at the sustained clock)."]
 open(p + "_pmc_mfma.txt", "w").write("\n".join(out) + "\n")
 out = [f"# {tag}: rocprofv3 --pmc FETCH_SIZE -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --max-new-tokens 8   (own pass)",
        "# FETCH_SIZE: KiB per dispatch, summed here over dispatches; gfx950 counts a 128-B streaming request as 64 B -> corrected bytes = 2 x (MI355X_MICROARCH.md, HBM section)",
@@ -49,6 +49,13 @@ for l in open(g + "_pmc_fetch.txt").read().splitlines():
 if gu:
     out.append(f"# gate/up GEMV (gemv_kernel<..., true, 2>): {2 * gu / 1024:.1f} MiB per dispatch vs 224.0 MiB of weights (2*14336*4096*2 B): ratio {2 * gu * 1024 / (2 * 14336 * 4096 * 2):.4f} -> every weight byte read once.")
     json.dump({"kernel": "gemv_kernel<bf16,1,swiglu>", "fetch_size_kib": round(gu, 1), "correction": 2.0,
-               "traffic_bytes_per_launch": int(round(gu * 2048, -3)), "source": p + "_pmc_fetch.txt"}, open("profiles/r01_pmc_gemv.json", "w"))
+               "traffic_bytes_per_launch": int(round(gu * 2048, -3)), "source": p + "_pmc_fetch.txt"}, open("profiles/" + tag.split("_")[0] + "_pmc_gemv.json", "w"))
 open(p + "_pmc_fetch.txt", "w").write("\n".join(out) + "\n")
 print("composed", p, "| gate/up trace avg", trace_us, "us | bench", d["value"], "tok/s")
+import os
+for extra in ("_pmc_lds.txt", "_kernel_stats_b4.txt", "_kernel_stats_fp8b8.txt"):
+    if os.path.exists(g + extra):
+        hdr2 = {"_pmc_lds.txt": "# rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --max-new-tokens 4 --batch 8 (own pass)\n# conflict share of a kernel = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE\n",
+                "_kernel_stats_b4.txt": "# rocprofv3 --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 4   (BASELINE configs[2] per-GPU shape)\n",
+                "_kernel_stats_fp8b8.txt": "# rocprofv3 --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --weights fp8 --batch 8   (BASELINE configs[4] per-GPU shape)\n"}[extra]
+        open(p + extra, "w").write(hdr2 + open(g + extra).read())

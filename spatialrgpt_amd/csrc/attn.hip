@@ -245,10 +245,17 @@ constexpr int DEC_SPLIT_MAX = 64;
 
 typedef SrgptPrefetch DecodePrefetch;  // common.h: L2 prefetch blocks appended to the launch (here: o_proj's weights)
 
-static inline int decode_nsplit(int max_pos) {
-  const int env_min = SRGPT_KNOB("SRGPT_DECODE_MIN_SPLITS", 16);  // tuning knob
+// splits per (sequence, kv head): enough blocks for ~2 per CU (a single sequence needs 16 splits to spread its K/V rows over
+// the chip; at 8 sequences the batch already does that and 16 splits only multiply the merge work), never fewer than the
+// score buffer requires (DEC_CHUNK_MAX keys per split)
+static inline int decode_nsplit(int max_pos, int B, int Hkv) {
+  const int force = SRGPT_KNOB("SRGPT_DECODE_MIN_SPLITS", 0);  // tuning build: fixed split count
+  int want = cdiv(2 * srgpt_device_cus(), Hkv * B);
+  if (want > 16) want = 16;
+  if (want < 1) want = 1;
+  if (force > 0) want = force;
   int n = cdiv(max_pos, DEC_CHUNK_MAX);
-  if (n < env_min) n = env_min;
+  if (n < want) n = want;
   if (n > DEC_SPLIT_MAX) n = DEC_SPLIT_MAX;
   return n;
 }
@@ -556,7 +563,7 @@ template <typename T>
 int launch_decode(const void* qkv, void* kc, void* vc, const int* pos, const void* ct, const void* st, void* out,
                   float* ws, int B, int Hq, int Hkv, int D, int max_pos, const DecodePrefetch& pf, hipStream_t s) {
   const int G = Hq / Hkv;
-  const int nsplit = decode_nsplit(max_pos);
+  const int nsplit = decode_nsplit(max_pos, B, Hkv);
   // a split's scores live in LDS (sc[G][DEC_CHUNK_MAX]): the longest chunk is ceil(max_pos / nsplit) keys
   SRGPT_CHECK(cdiv(max_pos, nsplit) <= DEC_CHUNK_MAX, SRGPT_ERR_UNSUPPORTED,
               "srgpt_decode_attention: max_pos %d exceeds %d cached positions", max_pos, DEC_SPLIT_MAX * DEC_CHUNK_MAX);

@@ -415,28 +415,31 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
     SRGPT_LAUNCH_CHECK();
     return SRGPT_OK;
   }
-  // ---- 256 x 256 eight-wave kernel (gemm256.hip) when a cost model calibrated on MI355X measurements says it wins ----
-  // (profiles/r02_gemm256_*.txt: one block per CU; a round of tiles costs ~15.5 us of launch + prologue + epilogue plus 1.7 us per
-  //  K tile; the small-tile kernels below sustain ~730 TF/s at K <= 1536 and ~600 TF/s beyond (780 on very wide N) on shapes
-  //  that fill the chip)
+  // ---- 256 x 256 eight-wave kernel (gemm256.hip); rule calibrated on MI355X measurements (profiles/r02_gemm256_*.txt,
+  //      profiles/r02_gemm_final.txt: one block per CU, ~15 us of launch + prologue + epilogue per round of tiles) ----
+  //   K >= 2048: it wins or ties on every shape with M >= 384 (prefill b8 qkv 111 vs 172 us, down 334 vs 455, b4 down 140 vs 212);
+  //              an under-filled grid splits K (deterministic slabs) up to ~1.1 rounds of blocks
+  //   K <  2048: the fixed cost per round is a quarter of the tile time, so only when the last round is nearly full
+  //              (>= 88 %: ViT out-proj 50 vs 62 us; ViT qkv / fc1 at 84 / 76 % stay on the small-tile kernel: 131 vs 143 us)
   {
     const int cus = srgpt_device_cus();
     const int nk256 = K / 64;
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    bool use256 = K % 64 == 0 && K >= 256 && M >= 384;
+    // M >= 384 and at most 25 % of padded rows (M = 518 would fill 3 row tiles to 67 %)
+    bool use256 = K % 64 == 0 && K >= 256 && M >= 384 && (long)M * 4 >= (long)cdiv(M, 256) * 256 * 3;
     int sp = 1;
     if (use256) {
-      if (t256 < cus && ws) {  // under-filled: split K (deterministic slabs) while the blocks still fit one round
-        sp = (int)(cus / t256);
-        if (sp > 4) sp = 4;
-        while (sp > 1 && (nk256 / sp < 8 || (int64_t)sp * M * N * 4 > ws_bytes)) --sp;
+      if (K >= 2048) {
+        if (t256 < cus && ws) {
+          sp = (int)((cus * 11 / 10 + t256 / 2) / t256);
+          if (sp < 1) sp = 1;
+          if (sp > 4) sp = 4;
+          while (sp > 1 && (nk256 / sp < 8 || (int64_t)sp * M * N * 4 > ws_bytes)) --sp;
+        }
+      } else {
+        const long rounds = (t256 + cus - 1) / cus;
+        use256 = t256 * 100 >= rounds * cus * 88;
       }
-      const long blocks = t256 * sp;
-      const double rounds = (double)((blocks + cus - 1) / cus);
-      double t_new = rounds * (15.5 + 1.7 * (double)cdiv(nk256, sp));
-      if (sp > 1) t_new += 2.0 + (double)M * N * 4.0 * (sp + 1) / 4.0e6;  // slab write + reduce pass (bytes / 4 TB/s, in us)
-      const double t_old = 2.0 * M * N * (double)K / ((K <= 1536 ? 730.0 : (N >= 16384 ? 780.0 : 600.0)) * 1e6);
-      use256 = t_new < 0.95 * t_old;
     }
     const int f256 = SRGPT_KNOB("SRGPT_GEMM_FORCE_256", 0);  // tuning build: 1 = whenever legal, -1 = never
     if (f256 > 0) use256 = K % 64 == 0 && K >= 128, sp = 1;
