@@ -287,6 +287,8 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   const int hk = (int)blockIdx.x % Hkv, split = ((int)blockIdx.x / Hkv) % nsplit, b = (int)blockIdx.x / (Hkv * nsplit);
   const int P = pos[b];
   const int total = P + 1;
+  // the key ranges depend on the sequence length only (NOT on the cache capacity: fixed capacity-based ranges were measured --
+  // no faster -- and make the summation order, hence the bits, depend on how large a cache the caller happened to allocate)
   const int chunk = (total + nsplit - 1) / nsplit;
   const int kbeg = split * chunk, kend = min(kbeg + chunk, total);
   const T* row = qkv + (size_t)b * (Hq + 2 * Hkv) * D;
@@ -488,9 +490,22 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   __syncthreads();
   if (stat_l[0] == 0.f) return;
   __syncthreads();
-  auto fetch = [&](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // The first 16 splits' partials of this thread's pair of output dims AND the per-split statistics are requested back to
+  // back: the merge pays one memory latency.  (G * D / 2 <= 256 * MAXW items; one or two per thread for the shipped shapes.)
+  constexpr int PRE = 16;
+  constexpr int MAXW = (G * (D / 2) + 255) / 256;
+  unsigned long long v[MAXW][PRE];
+#pragma unroll
+  for (int wi = 0; wi < MAXW; ++wi) {
+    const int w = min(tid + 256 * wi, G * (D / 2) - 1);
+    const int gq = w / (D / 2), d = 2 * (w - gq * (D / 2));
+    const float* wp = wbase + (size_t)gq * DEC_SPLIT_MAX * (D + 2) + d;
+#pragma unroll
+    for (int j = 0; j < PRE; ++j)
+      v[wi][j] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)min(j, nsplit - 1) * (D + 2)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // per-head merge weights: wave gq handles head gq (G <= 8 heads over 4 waves), one split per lane (nsplit <= 64)
-  float* wgt = &sc[0][0];  // [G][DEC_SPLIT_MAX] weights, reusing the score buffer (DEC_CHUNK_MAX >= DEC_SPLIT_MAX)
   for (int gq = wave; gq < G; gq += 4) {
     const float* wp = wbase + (size_t)gq * DEC_SPLIT_MAX * (D + 2);
     const bool ok = lane < nsplit;
@@ -507,32 +522,29 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
     if (lane == 0) stat_m[gq] = den > 0.f ? 1.f / den : 0.f;
   }
   __syncthreads();
-  // every thread merges a pair of output dims: the first 16 splits' partials are requested back to back (one memory latency)
-  constexpr int PRE = 16;
-  for (int w = tid; w < G * (D / 2); w += 256) {
-    const int gq = w / (D / 2), d = 2 * (w - gq * (D / 2));
-    const float* wp = wbase + (size_t)gq * DEC_SPLIT_MAX * (D + 2) + d;
-    unsigned long long v[PRE];
 #pragma unroll
-    for (int j = 0; j < PRE; ++j)
-      v[j] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)min(j, nsplit - 1) * (D + 2)),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float n0 = 0.f, n1 = 0.f;
+  for (int wi = 0; wi < MAXW; ++wi) {
+    const int w = tid + 256 * wi;
+    if (w < G * (D / 2)) {
+      const int gq = w / (D / 2), d = 2 * (w - gq * (D / 2));
+      const float* wp = wbase + (size_t)gq * DEC_SPLIT_MAX * (D + 2) + d;
+      float n0 = 0.f, n1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < PRE; ++j)
-      if (j < nsplit) {
-        n0 = fmaf(sc[gq][j], __uint_as_float((unsigned)v[j]), n0);
-        n1 = fmaf(sc[gq][j], __uint_as_float((unsigned)(v[j] >> 32)), n1);
+      for (int j = 0; j < PRE; ++j)
+        if (j < nsplit) {
+          n0 = fmaf(sc[gq][j], __uint_as_float((unsigned)v[wi][j]), n0);
+          n1 = fmaf(sc[gq][j], __uint_as_float((unsigned)(v[wi][j] >> 32)), n1);
+        }
+      for (int sp = PRE; sp < nsplit; ++sp) {
+        const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)sp * (D + 2)),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n0 = fmaf(sc[gq][sp], __uint_as_float((unsigned)u), n0);
+        n1 = fmaf(sc[gq][sp], __uint_as_float((unsigned)(u >> 32)), n1);
       }
-    for (int sp = PRE; sp < nsplit; ++sp) {
-      const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)sp * (D + 2)),
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      n0 = fmaf(sc[gq][sp], __uint_as_float((unsigned)u), n0);
-      n1 = fmaf(sc[gq][sp], __uint_as_float((unsigned)(u >> 32)), n1);
+      T* op = out + ((size_t)b * Hq + (size_t)hk * G + gq) * D + d;
+      op[0] = from_f<T>(n0 * stat_m[gq]);
+      op[1] = from_f<T>(n1 * stat_m[gq]);
     }
-    T* op = out + ((size_t)b * Hq + (size_t)hk * G + gq) * D + d;
-    op[0] = from_f<T>(n0 * stat_m[gq]);
-    op[1] = from_f<T>(n1 * stat_m[gq]);
   }
   if (tid == 0) __hip_atomic_store(tickets + (size_t)b * Hkv + hk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
