@@ -165,6 +165,13 @@ int64_t srgpt_region_pool_ws_floats(int M, int fw, int C);
 int srgpt_region_pool(const void* feat, const void* masks, void* out, float* ws, int M, int mh, int mw,
                       int fw, int C, float rscale_h, float rscale_w, int mask_dtype, int dtype,
                       srgpt_stream_t stream);
+/* The same pooling straight from the caller's RAW uint8 masks [M, rh, rw]: ys[mh] / xs[mw] (device int32) are the
+ * cv2.INTER_NEAREST source row / column of every row / column of the mh x mw processor-size mask the reference builds on the host
+ * (mm_utils.py:477-532); the kernel's bilinear taps read through them, so nearest resize, float(uint8) and the resample are one
+ * pass over the raw bytes.  Bit-identical to srgpt_mask_resize_nearest followed by srgpt_region_pool. */
+int srgpt_region_pool_u8(const void* feat, const void* masks_u8, const int* ys, const int* xs, void* out, float* ws, int M,
+                         int rh, int rw, int mh, int mw, int fw, int C, float rscale_h, float rscale_w, int dtype,
+                         srgpt_stream_t stream);
 int srgpt_avgpool(const void* x, void* y, int n_img, int in_w, int out_w, int C, int dtype,
                   srgpt_stream_t stream);
 int srgpt_s2d(const void* x, void* y, int n_img, int g, int C, int dtype, srgpt_stream_t stream);

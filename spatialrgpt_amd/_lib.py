@@ -73,6 +73,7 @@ _SIGNATURES = {
     "srgpt_decode_attention": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "srgpt_region_pool_ws_floats": (i64, [i32, i32, i32]),
     "srgpt_region_pool": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, i32, i32, vp]),
+    "srgpt_region_pool_u8": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, i32, vp]),
     "srgpt_avgpool": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "srgpt_s2d": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "srgpt_im2col": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -34,21 +34,36 @@ __device__ __forceinline__ Idx src_index(float rscale, int dst, int n_in) {
   return r;
 }
 
-template <typename T, typename MT>
+// RAW = true: `masks` are the caller's raw uint8 [M, rh, rw] masks and (ys, xs) the cv2.INTER_NEAREST source
+// index of every row / column of the mh x mw processor-size mask the reference would have built on the host
+// (mm_utils.py:477-532: cv2.resize(..., INTER_NEAREST), then the processor with rescale 1.0 -> float(uint8)); the bilinear taps
+// read THROUGH the tables, so the nearest resize, the float conversion and the resample are one pass over the raw bytes.
+template <typename T, typename MT, bool RAW>
 __global__ __launch_bounds__(1024) void region_weights_kernel(const MT* __restrict__ masks, float* __restrict__ w,
-                                                              int mh, int mw, int fw, float rscale_h, float rscale_w) {
+                                                              int mh, int mw, int fw, float rscale_h, float rscale_w,
+                                                              const int* __restrict__ ys, const int* __restrict__ xs, int rh,
+                                                              int rw) {
   __shared__ float red[16];
   const int m = blockIdx.x;
-  const MT* mk = masks + (size_t)m * mh * mw;
+  const MT* mk = masks + (size_t)m * (RAW ? (size_t)rh * rw : (size_t)mh * mw);
   float* wm = w + (size_t)m * fw * fw;
   const int L = fw * fw;
   float s = 0.f;
+  auto at = [&](int yy, int xx) -> float {
+    if constexpr (RAW)
+      return (float)mk[(size_t)ys[yy] * rw + xs[xx]];  // float(uint8), as the processor with rescale_factor 1.0 produces
+    else
+      return to_f(mk[(size_t)yy * mw + xx]);
+  };
   for (int l = threadIdx.x; l < L; l += blockDim.x) {
     const int oy = l / fw, ox = l - oy * fw;
     const Idx y = src_index(rscale_h, oy, mh), x = src_index(rscale_w, ox, mw);
-    const float v00 = to_f(mk[(size_t)y.i0 * mw + x.i0]), v01 = to_f(mk[(size_t)y.i0 * mw + x.i1]);
-    const float v10 = to_f(mk[(size_t)y.i1 * mw + x.i0]), v11 = to_f(mk[(size_t)y.i1 * mw + x.i1]);
-    const float v = rnd<T>(y.l0 * (x.l0 * v00 + x.l1 * v01) + y.l1 * (x.l0 * v10 + x.l1 * v11));  // .to(x.dtype)
+    const float v00 = at(y.i0, x.i0), v01 = at(y.i0, x.i1);
+    const float v10 = at(y.i1, x.i0), v11 = at(y.i1, x.i1);
+    // explicit fused steps: every instantiation (float / bf16 / raw uint8 masks) rounds the same way, whatever the
+    // compiler's contraction choices would have been
+    const float top = fmaf(x.l1, v01, x.l0 * v00), bot = fmaf(x.l1, v11, x.l0 * v10);
+    const float v = rnd<T>(fmaf(y.l1, bot, y.l0 * top));  // .to(x.dtype)
     wm[l] = v;
     s += v;
   }
@@ -209,10 +224,11 @@ extern "C" int64_t srgpt_region_pool_ws_floats(int M, int fw, int C) {
   return (int64_t)M * L + nslab * M * C;
 }
 
-extern "C" int srgpt_region_pool(const void* feat, const void* masks, void* out, float* ws, int M, int mh, int mw,
-                                 int fw, int C, float rscale_h, float rscale_w, int mask_dtype, int dtype,
-                                 srgpt_stream_t stream) {
-  SRGPT_CHECK(mask_dtype == SRGPT_BF16 || mask_dtype == SRGPT_F32, SRGPT_ERR_ARG, "srgpt_region_pool: bad mask dtype");
+static int region_pool_impl(const void* feat, const void* masks, void* out, float* ws, int M, int mh, int mw, int fw, int C,
+                            float rscale_h, float rscale_w, int mask_dtype, int dtype, const int* ys, const int* xs, int rh, int rw,
+                            srgpt_stream_t stream) {
+  const bool raw = ys != nullptr;
+  SRGPT_CHECK(raw || mask_dtype == SRGPT_BF16 || mask_dtype == SRGPT_F32, SRGPT_ERR_ARG, "srgpt_region_pool: bad mask dtype");
   SRGPT_CHECK(feat && masks && out && ws, SRGPT_ERR_ARG, "srgpt_region_pool: null pointer");
   SRGPT_CHECK(M > 0 && M <= RP_MAXM, SRGPT_ERR_ARG, "srgpt_region_pool: M=%d must be in 1..%d per call", M, RP_MAXM);
   SRGPT_CHECK(mh > 0 && mw > 0 && fw > 0 && C > 0, SRGPT_ERR_ARG, "srgpt_region_pool: bad shape");
@@ -224,33 +240,45 @@ extern "C" int srgpt_region_pool(const void* feat, const void* masks, void* out,
   float* w = ws;
   float* partial = ws + (size_t)M * L;
   dim3 pgrid(nslab, cdiv(C / vec, RP_CHUNKS));
+#define RW(TT, MT, RAWV)                                                                                                   \
+  hipLaunchKernelGGL((region_weights_kernel<TT, MT, RAWV>), dim3(M), dim3(1024), 0, s, (const MT*)masks, w, mh, mw, fw,    \
+                     rscale_h, rscale_w, ys, xs, rh, rw)
   if (dtype == SRGPT_BF16) {
-    if (mask_dtype == SRGPT_BF16)
-      hipLaunchKernelGGL((region_weights_kernel<bf16_t, bf16_t>), dim3(M), dim3(1024), 0, s, (const bf16_t*)masks, w, mh, mw,
-                         fw, rscale_h, rscale_w);
-    else
-      hipLaunchKernelGGL((region_weights_kernel<bf16_t, float>), dim3(M), dim3(1024), 0, s, (const float*)masks, w, mh, mw,
-                         fw, rscale_h, rscale_w);
+    if (raw) RW(bf16_t, unsigned char, true);
+    else if (mask_dtype == SRGPT_BF16) RW(bf16_t, bf16_t, false);
+    else RW(bf16_t, float, false);
     if (M <= 8)
       hipLaunchKernelGGL((region_partial_kernel<bf16_t, 8>), pgrid, dim3(256), 0, s, (const bf16_t*)feat, w, partial, M, L, C);
     else
       hipLaunchKernelGGL((region_partial_kernel<bf16_t, 16>), pgrid, dim3(256), 0, s, (const bf16_t*)feat, w, partial, M, L, C);
     hipLaunchKernelGGL(region_final_kernel<bf16_t>, dim3(cdiv(M * C, 256)), dim3(256), 0, s, partial, (bf16_t*)out, nslab, M * C);
   } else {
-    if (mask_dtype == SRGPT_BF16)
-      hipLaunchKernelGGL((region_weights_kernel<float, bf16_t>), dim3(M), dim3(1024), 0, s, (const bf16_t*)masks, w, mh, mw,
-                         fw, rscale_h, rscale_w);
-    else
-      hipLaunchKernelGGL((region_weights_kernel<float, float>), dim3(M), dim3(1024), 0, s, (const float*)masks, w, mh, mw,
-                         fw, rscale_h, rscale_w);
+    if (raw) RW(float, unsigned char, true);
+    else if (mask_dtype == SRGPT_BF16) RW(float, bf16_t, false);
+    else RW(float, float, false);
     if (M <= 8)
       hipLaunchKernelGGL((region_partial_kernel<float, 8>), pgrid, dim3(256), 0, s, (const float*)feat, w, partial, M, L, C);
     else
       hipLaunchKernelGGL((region_partial_kernel<float, 16>), pgrid, dim3(256), 0, s, (const float*)feat, w, partial, M, L, C);
     hipLaunchKernelGGL(region_final_kernel<float>, dim3(cdiv(M * C, 256)), dim3(256), 0, s, partial, (float*)out, nslab, M * C);
   }
+#undef RW
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
+}
+
+extern "C" int srgpt_region_pool(const void* feat, const void* masks, void* out, float* ws, int M, int mh, int mw,
+                                 int fw, int C, float rscale_h, float rscale_w, int mask_dtype, int dtype,
+                                 srgpt_stream_t stream) {
+  return region_pool_impl(feat, masks, out, ws, M, mh, mw, fw, C, rscale_h, rscale_w, mask_dtype, dtype, nullptr, nullptr, 0, 0,
+                          stream);
+}
+
+extern "C" int srgpt_region_pool_u8(const void* feat, const void* masks_u8, const int* ys, const int* xs, void* out, float* ws,
+                                    int M, int rh, int rw, int mh, int mw, int fw, int C, float rscale_h, float rscale_w,
+                                    int dtype, srgpt_stream_t stream) {
+  SRGPT_CHECK(ys && xs && rh > 0 && rw > 0, SRGPT_ERR_ARG, "srgpt_region_pool_u8: null index tables / bad raw size");
+  return region_pool_impl(feat, masks_u8, out, ws, M, mh, mw, fw, C, rscale_h, rscale_w, SRGPT_F32, dtype, ys, xs, rh, rw, stream);
 }
 
 #define RDISPATCH(dtype, ...)                      \

@@ -137,7 +137,15 @@ class SrgptEngine:
         out = []
         for i in range(n):
             m = masks[i]
-            out.append(None if m is None else ops.region_pool(feats[i].to(self.dtype), m.to(self.device)))
+            if m is None:
+                out.append(None)
+            elif m.dtype == torch.uint8:
+                # raw uint8 masks [K, H, W]: nearest resize to the processor size + float + resample in the kernel
+                if self.cfg.image_aspect_ratio != "resize":
+                    raise NotImplementedError("raw uint8 masks need image_aspect_ratio == 'resize' (process_regions otherwise)")
+                out.append(ops.region_pool_u8(feats[i].to(self.dtype), m.to(self.device), self.cfg.image_size))
+            else:
+                out.append(ops.region_pool(feats[i].to(self.dtype), m.to(self.device)))
         return out
 
     def region_extractor(self, hres, depth_features, masks):

@@ -222,6 +222,38 @@ def region_pool(feat, masks, fw: Optional[int] = None):
     return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
 
+def region_pool_u8(feat, masks_u8, size: int):
+    """MaskPooling straight from raw uint8 masks [M, H, W]: the cv2-nearest resize to the processor size
+    (`size` x `size`, image_aspect_ratio == "resize"), float(uint8) and the bilinear resample run inside the pooling kernel.
+    Bit-identical to region_pool(feat, process_regions_device(masks, ...))."""
+    from .mm_utils import cv2_nearest_index
+
+    _dev(feat, masks_u8)
+    if masks_u8.dtype != torch.uint8 or masks_u8.dim() != 3:
+        raise ValueError("region_pool_u8: masks must be a uint8 tensor [M, H, W]")
+    Lf, Cc = feat.shape
+    M, rh, rw = masks_u8.shape
+    mh = mw = int(size)
+    sf = (Lf / (mh * mw)) ** 0.5
+    oh, ow = int(math.floor(mh * sf)), int(math.floor(mw * sf))
+    if oh * ow != Lf or oh != ow:
+        raise RuntimeError(f"mask of size {mh}x{mw} resamples to {oh}x{ow}, which does not match {Lf} feature tokens")
+    ys = torch.from_numpy(cv2_nearest_index(rh, mh)).to(feat.device)
+    xs = torch.from_numpy(cv2_nearest_index(rw, mw)).to(feat.device)
+    masks_u8 = _c(masks_u8)
+    rs = 1.0 / sf
+    lib = L.load()
+    outs = []
+    for m0 in range(0, M, 16):
+        mm = min(16, M - m0)
+        out = torch.empty((mm, Cc), device=feat.device, dtype=feat.dtype)
+        ws = torch.empty((lib.srgpt_region_pool_ws_floats(mm, oh, Cc),), device=feat.device, dtype=torch.float32)
+        L.check(lib.srgpt_region_pool_u8(_p(_c(feat)), _p(masks_u8[m0:m0 + mm]), _p(ys), _p(xs), _p(out), _p(ws), mm, rh, rw, mh, mw,
+                                         oh, Cc, rs, rs, dt_code(feat), _stream()))
+        outs.append(out)
+    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+
 def avgpool(x, n_img, in_w, out_w):
     _dev(x)
     Cc = x.shape[-1]

@@ -217,3 +217,40 @@ def test_device_preprocessing_equals_host_path():
     assert gotm.shape == (5, 384, 384) and torch.equal(gotm.cpu(), refm)
     with pytest.raises(NotImplementedError):
         process_regions_device(masks, proc, SimpleNamespace(image_aspect_ratio="pad", image_processor=proc), device=DEV)
+
+
+def test_raw_uint8_masks_go_straight_into_region_pooling():
+    """SURVEY 8f-2, literal wording: raw uint8 [K, H, W] masks handed to generate() / the pooling kernel (nearest resize to the
+    processor size, float(uint8) and the bilinear resample fused in srgpt_region_pool_u8) == the host path
+    (process_regions -> float masks -> MaskPooling) bit for bit, for both feature grids (108^2 refined RGB, 27^2 depth)."""
+    import numpy as np
+    from types import SimpleNamespace
+
+    from spatialrgpt_amd import ops
+    from spatialrgpt_amd.mm_utils import SrgptImageProcessor, process_regions
+
+    rng = np.random.default_rng(5)
+    proc = SrgptImageProcessor(size=384)
+    cfgp = SimpleNamespace(image_aspect_ratio="resize", image_processor=proc)
+    raw = [(rng.random((480, 640)) > 0.6).astype(np.uint8) for _ in range(5)] + [np.zeros((480, 640), np.uint8)]
+    host = process_regions(raw, proc, cfgp)  # float [6, 384, 384] (cv2-nearest restatement + processor)
+    raw_t = torch.from_numpy(np.stack(raw, 0)).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for dtype in (torch.bfloat16, torch.float32):
+        for fw in (108, 27):
+            feat = torch.randn((fw * fw, 64), generator=g, device=DEV).to(dtype)
+            want = ops.region_pool(feat, host.to(DEV))
+            got = ops.region_pool_u8(feat, raw_t, 384)
+            assert torch.equal(got, want), f"{dtype} fw={fw}: max diff {float((got.float() - want.float()).abs().max())}"
+    # through the model surface: generate() with uint8 masks == generate() with the host-processed float masks
+    so, ocfg, model, w, inp = _both()
+    S = model.config.image_size
+    rawm = (rng.random((inp["masks"][0].shape[0], 200, 300)) > 0.5).astype(np.uint8)
+    proc2 = SrgptImageProcessor(size=S)
+    hostm = process_regions(list(rawm), proc2, SimpleNamespace(image_aspect_ratio="resize", image_processor=proc2))
+    d = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    a = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=[torch.from_numpy(rawm).to(DEV)],
+                       do_sample=False, max_new_tokens=5, eos_token_id=None)
+    b = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=[hostm.to(DEV)], do_sample=False,
+                       max_new_tokens=5, eos_token_id=None)
+    assert torch.equal(a, b)
