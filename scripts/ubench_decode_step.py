@@ -1,0 +1,39 @@
+"""decode ms/token of the whole graph-captured step for several (weights, batch) configurations in one process.
+  SRGPT_LIB=<path of a libsrgpt_hip*.so build> python scripts/ubench_decode_step.py fp8:8 fp8:4 bf16:4
+Knobs of the tuning builds (SRGPT_SKINNY_W8_MODE, SRGPT_DECODE_PREFETCH_ROUNDS, ...) are read from the environment once per
+process by the library itself; this script only reports them."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from spatialrgpt_amd import _lib
+if os.environ.get("SRGPT_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["SRGPT_LIB"])
+from spatialrgpt_amd.config import SrgptConfig
+from spatialrgpt_amd.engine import SrgptEngine
+from spatialrgpt_amd.weights import synth_state_dict
+
+cfg = SrgptConfig.vila15_8b()
+G, T = 128, 259
+knobs = {k: v for k, v in os.environ.items() if k.startswith("SRGPT_")}
+wanted = [a.split(":") for a in sys.argv[1:]] or [["bf16", "1"]]
+for fmt in sorted({w for w, _ in wanted}):
+    sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device="cuda")
+    eng = SrgptEngine(cfg, sd, device="cuda", dtype=torch.bfloat16, rope_positions=1024, consume_state_dict=True,
+                      llm_weight_format="fp8" if fmt == "fp8" else "native")
+    del sd
+    for w, b in wanted:
+        if w != fmt:
+            continue
+        B = int(b)
+        x = torch.randn((B, T, cfg.hidden), device="cuda").to(torch.bfloat16)
+        best = 1e9
+        for rep in range(3):
+            st, _, _ = eng.prefill(x, max_new=G)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record(); eng.greedy_decode(st, G); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / G)
+        wb = eng.w.llm_weight_bytes()
+        print(f"{os.path.basename(_lib.LIB_PATH)} {knobs} | {fmt} batch {B}: {best:.4f} ms/step = {B / best * 1e3:.0f} tok/s decode-only, "
+              f"{wb / best / 1e9:.2f} TB/s of weights = {wb / best / 1e9 / 8:.3f} of 8 TB/s", flush=True)
+    del eng
+    torch.cuda.empty_cache()

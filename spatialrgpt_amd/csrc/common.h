@@ -201,9 +201,11 @@ __device__ __forceinline__ void srgpt_prefetch_block(const SrgptPrefetch& pf, in
 }
 
 extern "C" int srgpt_device_cus(void);
+
 // descriptor for "the next launch is the batch-`batch` decode GEMV over W [N (2N if swiglu), K]" (bf16 rows, or fp8 bytes).
 // Mirrors the grid / unit mapping of gemv.hip's and gemv_w8.hip's launchers for batch <= 2 (the VALU kernels); anything else
-// (3+ rows: the skinny kernel, fp8 SwiGLU units of four rows) gets no prefetch.
+// gets no prefetch: fp8 SwiGLU units of four rows, and 3+ rows (the skinny kernel -- its mapping, 4-row groups of block p's
+// 16-row units, was measured: o_proj +1 % at 8 fp8 rows, -2 % at 4 bf16 rows per decode step, not kept).
 static inline SrgptPrefetch srgpt_prefetch_for_gemv(const void* W, int N, int K, int swiglu, int fp8, int batch, int rounds,
                                                     int prefix_bytes) {
   SrgptPrefetch pf{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0};

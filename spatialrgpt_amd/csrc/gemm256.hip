@@ -51,8 +51,8 @@ constexpr int G_LDS = 2 * G_BUF;          // 128 KiB
 
 // W8: the weight operand is OCP e4m3fn bytes [N, K] with one fp32 (power-of-two) scale per row (BASELINE config 5): the W tile is
 // DMA'd as bytes (16 KiB per K tile, 16 rows x 64 B per wave-instruction, 16-byte chunk ^ ((row >> 2) & 3) -> conflict-free
-// ds_read_b128), one 16-byte read = 16 consecutive k of a row = the B operands of TWO MFMAs after v_cvt_pk_f32_fp8 /
-// v_cvt_pk_bf16_f32, so the A operand takes its 16-byte chunks in the matching order (chunk 4j + 2 hi + e for MFMA 2j + e);
+// ds_read_b128), one 16-byte read = 16 consecutive k of a row = the B operands of TWO MFMAs after v_cvt_scalef32_pk_bf16_fp8
+// (scale 1), so the A operand takes its 16-byte chunks in the matching order (chunk 4j + 2 hi + e for MFMA 2j + e);
 // the row scale multiplies the accumulator in the epilogue (exact: the bf16 value of code * 2^k is code * 2^k).
 template <int ablate, bool W8>  // ablate 0 = the kernel; 1..4 = timing-only ablations, instantiated in the tuning build only (wrong results):
                        // 1 no DMA in the loop, 2 no DMA waits, 3 no fragment reads after the first tile, 4 no MFMA,
@@ -241,14 +241,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw8[jn][j][q], false);
-            const f32x2 hh = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw8[jn][j][q], true);
-            bf16x8& dst = fw[jn][2 * j + (q >> 1)];
-            dst[4 * (q & 1) + 0] = (bf16_t)lo[0];
-            dst[4 * (q & 1) + 1] = (bf16_t)lo[1];
-            dst[4 * (q & 1) + 2] = (bf16_t)hh[0];
-            dst[4 * (q & 1) + 3] = (bf16_t)hh[1];
+          for (int hf = 0; hf < 2; ++hf) {  // v_cvt_scalef32_pk_bf16_fp8: two fp8 -> one packed bf16x2 register (scale 1, exact)
+            u32x4 o;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+              const unsigned int raw = raw8[jn][j][2 * hf + qq];
+              o[2 * qq] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw, 1.0f, false));
+              o[2 * qq + 1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw, 1.0f, true));
+            }
+            fw[jn][2 * j + hf] = __builtin_bit_cast(bf16x8, o);
           }
     }
     G_BARRIER();

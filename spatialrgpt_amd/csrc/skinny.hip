@@ -8,16 +8,23 @@
 // MFMA operand fragments need lane (r = l & 15, g = l >> 4) to hold 16 bytes of ROW r -- loading them straight from
 // HBM puts 16 different rows in one instruction (64-byte pieces; measured slow, scripts/ubench_stream.hip), so each
 // wave stages its 16 x 256 weight tile through a PRIVATE 8 KiB LDS region: 8 coalesced global loads -> 8 ds_write_b128
-// -> 8 conflict-free ds_read_b128 fragments (row stride padded to 528 B).  The matching [rows][256] slice of the
+// -> 8 conflict-free ds_read_b128 fragments (row stride padded to 544 B).  The matching [rows][256] slice of the
 // (normalised) activations goes through a second private region the same way (it comes from L2).  Nothing in the K loop
 // is shared between waves, so there is NO block barrier in it (LDS ops of one wave execute in order) and the 8-12 waves
 // of a CU drift apart like the GEMV's do: some stream while others multiply.
 //
-// Work decomposition: a unit = 16 output columns (SwiGLU: 16 gate rows + the 16 matching up rows = 2 sub-units);
-// block b owns units b, b + grid, ...; up to 4 sub-units per pass keep their 16x16 fp32 accumulators in registers
-// (4 VGPRs each).  The 4 waves of a block split K in interleaved 256-wide slices, so every block uses all its waves
+// Work decomposition: block b owns the `cw` consecutive output columns [b cw, (b + 1) cw), cut into tiles of 16 (the last one
+// partial: its missing rows are not loaded); cw = ceil(N / blocks) makes every CU stream the same number of weight rows
+// (6144 q/k/v columns = 24 per CU, 14336 gate/up pairs = 56 -- whole 16-column units left a quarter of the CUs with half the
+// work).  A tile is one sub-unit (SwiGLU: the 16 gate rows + the 16 matching up rows = 2 sub-units); up to 4 sub-units per
+// pass keep their 16x16 fp32 accumulators in registers (4 VGPRs each).  The 4 waves of a block split K in interleaved 256-wide slices, so every block uses all its waves
 // even when N/16 is only one tile per CU (o_proj / down_proj); their partial sums are added in a fixed order through
 // LDS at the end of the pass (deterministic).
+//
+// The K loop is written for counted waits: every load in it is issued unconditionally, so the compiler can leave the
+// prefetched stage in flight across the LDS writes (a branch around a load makes it wait for vmcnt(0) -- the prefetch was being
+// drained every stage); the fragment reads of 4 k steps go out together in front of their MFMAs, which alternate between two
+// accumulators (the compiler's own order was read -> wait -> MFMA per step: a full LDS latency each).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -29,27 +36,40 @@ int srgpt_gemv_w8_valu(const void* x, const void* W8, const float* wscale, const
 
 namespace {
 
-constexpr int WSK = 256;               // k per wave slice
-constexpr int WROWB = WSK * 2 + 16;    // bytes per staged row (padded: fragment reads hit 64 distinct banks)
+constexpr int WROWB = 512 + 32;        // bytes per staged weight row: 136 dwords = 8 mod 64 banks -> the lane groups of ds_read_b128
+                                       // (MI355X guide, LDS table) hit distinct banks; 528 measured 30 % conflict cycles
 constexpr int WSTAGEB = 16 * WROWB;    // weight stage per wave
 constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumulated per pass
+
+#ifndef SRGPT_SKINNY_DEPTH
+#define SRGPT_SKINNY_DEPTH 2           // register ring depth of weight stages (tuning builds override)
+#endif
+#ifndef SRGPT_SKINNY_FS
+#define SRGPT_SKINNY_FS 4              // MFMA k steps per fragment batch (8 LDS reads in flight per batch)
+#endif
 
 // NI = x rows staged per wave / 2: 2 (batch <= 4), 4 (batch <= 8) or 8 (batch <= 16).  NW = waves per block (the K split): 4, or 8 when
 // there are no more units than CUs so that one block per CU still keeps 8 waves streaming.
 // W8: the weights are OCP fp8 e4m3fn bytes with one fp32 scale per weight row (W8A16): a stage is 8 loads of 8 bytes per lane
 // (2 rows x 256 bytes each), widened to bf16 (exact) on the way into LDS; the row scale multiplies the fp32 dot product.
+// (Measured and dropped: 512-k fp8 slices with the raw bytes in LDS and the widening behind the fragment read -- a stage of as
+// many bytes as a bf16 one -- 69.2 vs 63.7 us per layer at 8 rows: this kernel is not bound by bytes in flight.)
 template <bool SWIGLU, int NI, int NW, bool W8>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const bf16_t* __restrict__ x, const void* __restrict__ Wv,
                                                                           const float* __restrict__ wscale,
                                                                           const bf16_t* __restrict__ norm_w, float norm_eps,
                                                                           const bf16_t* __restrict__ residual, void* __restrict__ out,
-                                                                          int B, int N, int K, int out_f32) {
+                                                                          int B, int N, int K, int out_f32, int cw) {
+  constexpr int SK = 256;                   // k per wave slice
+  constexpr int XROWB = WROWB;              // bytes per staged activation row
+  constexpr int XL = NI;                    // activation loads per slice: 2 rows x 512 B each
   constexpr int R = SWIGLU ? 2 : 1;
   constexpr int MAXU = MAXSU / R;
-  constexpr int XSTAGEB = 2 * NI * WROWB;
+  constexpr int XSTAGEB = 2 * NI * XROWB;
   constexpr int NT = 64 * NW;
   using WReg = typename std::conditional<W8, u32x2, u32x4>::type;  // one staged weight load per lane
-  constexpr int WEB = W8 ? 1 : 2;                                  // bytes per weight element
+  constexpr int WEB = W8 ? 1 : 2;                                       // bytes per weight element
+  constexpr int WEPL = 8;                                               // weight elements per lane-load
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // per wave: [x stage | w stage]; reused for the reduction
   __shared__ float rs_s[16];
   __shared__ float ss_s[16][NW / 2];
@@ -57,34 +77,37 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned char* xst = smem + wave * (XSTAGEB + WSTAGEB);
   unsigned char* wst = xst + XSTAGEB;
-  const int nsl = (K + WSK - 1) / WSK;  // K slices; wave w takes w, w + NW, ...
-  const int NU = (N + 15) >> 4;
-  const int grid = gridDim.x;
-  const int npass = (NU + grid * MAXU - 1) / (grid * MAXU);
+  const int nsl = (K + SK - 1) / SK;  // K slices; wave w takes w, w + NW, ...
+  const int c0 = (int)blockIdx.x * cw;                 // first output column of this block
+  const int cwb = min(cw, N - c0);                     // its column count (the last block may own fewer)
+  const int ntile = (cwb + 15) >> 4;                   // 16-column tiles, the last one possibly partial
+  const int npass = (ntile + MAXU - 1) / MAXU;
   const bool do_norm = norm_w != nullptr;
   const int lrow = lane >> 5, lchunk = lane & 31;  // staging loads: lane -> (row parity, 16-byte chunk of the 512-byte row piece)
+  const int xchunk = lchunk;
+  auto xrow_of = [&](int j) { return 2 * j + lrow; };
 
-  // activation slice: NI loads, each 2 rows x 512 contiguous bytes (rows past the batch re-read row B-1: their outputs
-  // are never stored), plus the 512 bytes of RMSNorm gains of the slice
-  u32x4 xr[NI];
+  // activation slice: XL loads covering 2*NI rows x SK k (rows past the batch re-read row B-1: their outputs are never
+  // stored), plus the RMSNorm gains of the lane's chunk
+  u32x4 xr[XL];
   u32x4 gr = {0u, 0u, 0u, 0u};
   auto load_x = [&](int sl) {
-    int kg = min(sl * WSK + lchunk * 8, K - 8);
+    int kg = min(sl * SK + xchunk * 8, K - 8);
     asm volatile("" : "+v"(kg));  // keep the row products out of loop-invariant registers (see issue_w)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const unsigned off = (unsigned)min(2 * j + lrow, B - 1) * (unsigned)K + (unsigned)kg;
+    for (int j = 0; j < XL; ++j) {
+      const unsigned off = (unsigned)min(xrow_of(j), B - 1) * (unsigned)K + (unsigned)kg;
       xr[j] = *reinterpret_cast<const u32x4*>(x + off);
     }
-    if (do_norm) gr = *reinterpret_cast<const u32x4*>(norm_w + kg);
+    gr = *reinterpret_cast<const u32x4*>((do_norm ? norm_w : x) + kg);  // unconditional: see the note on counted waits below
   };
-  auto stage_x = [&](int sl) {
-    const bool kvalid = sl * WSK + lchunk * 8 < K;
+  auto stage_x = [&](int sl, bool valid) {
+    const bool kvalid = valid && sl * SK + xchunk * 8 < K;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
+    for (int j = 0; j < XL; ++j) {
       u32x4 v = xr[j];
       if (do_norm) {
-        const float rsj = rs_s[2 * j + lrow];
+        const float rsj = rs_s[xrow_of(j)];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           // weight * hidden.to(dtype): two roundings, like the GEMV prologue
@@ -97,45 +120,50 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
         }
       }
       if (!kvalid) v = u32x4{0u, 0u, 0u, 0u};  // k past K contributes zeros (the weight loads there are clamped)
-      *reinterpret_cast<u32x4*>(xst + (2 * j + lrow) * WROWB + lchunk * 16) = v;
+      *reinterpret_cast<u32x4*>(xst + xrow_of(j) * XROWB + xchunk * 16) = v;
     }
   };
 
-  // weight stage of sub-unit su of (pass, slice): 8 loads, each 2 rows x 512 contiguous bytes
-  auto issue_w = [&](WReg* w, int pass, int sl, int su) {
-    const int unit = (pass * MAXU + su / R) * grid + (int)blockIdx.x;
-    // uniform 64-bit base of the unit's first row + a 32-bit per-lane offset.  The per-lane part is made opaque per call:
+  // weight stage of sub-unit su of (pass, slice): 8 loads, each 2 rows x 512 contiguous bytes (fp8: 2 rows x 256 bytes)
+  // Every load inside the K loop is issued UNCONDITIONALLY (`ok` false: all lanes re-read the unit's first 16 bytes, one cached
+  // line): behind a branch the compiler cannot count the loads in flight, waits for vmcnt(0) in front of the LDS writes and so
+  // drains the prefetched stage every step -- one full memory latency per stage, which is what bounded this kernel before.
+  auto issue_w = [&](WReg* w, int pass, int sl, int su, bool ok) {
+    const int cb = c0 + (pass * MAXU + su / R) * 16;  // first column of the tile
+    // uniform 64-bit base of the tile's first row + a 32-bit per-lane offset.  The per-lane part is made opaque per call:
     // left visible, LICM hoists the 8 x MAXSU row products out of the K loop and holds them in ~64 VGPRs.
-    const unsigned char* base = reinterpret_cast<const unsigned char*>(Wv) + ((size_t)unit * 16 + (size_t)(su % R) * N) * K * WEB;
-    const int rmax = N - 1 - unit * 16;  // last valid row of the unit (>= 15 except in the last unit)
-    int kg = min(sl * WSK + lchunk * 8, K - 8);
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(Wv) + ((size_t)cb + (size_t)(su % R) * N) * K * WEB;
+    const int rmax = c0 + cwb - 1 - cb;  // last valid row of the tile (>= 15 except in the block's last tile)
+    int kg = min(sl * SK + lchunk * WEPL, K - WEPL);
     asm volatile("" : "+v"(kg));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const unsigned off = ((unsigned)min(2 * j + lrow, rmax) * (unsigned)K + (unsigned)kg) * WEB;
+      // rows past the tile's last one are not fetched either (their outputs are never stored)
+      const unsigned off = (ok && 2 * j + lrow <= rmax) ? ((unsigned)(2 * j + lrow) * (unsigned)K + (unsigned)kg) * WEB : 0u;
       w[j] = __builtin_nontemporal_load(reinterpret_cast<const WReg*>(base + off));
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // 8 fp8 -> 8 bf16 (every e4m3 value is exactly representable: the high half of the fp32 conversion is the bf16)
-  auto widen = [&](const WReg& r) -> u32x4 {
-    if constexpr (W8) {
-      u32x4 o;
+  // 8 fp8 -> 8 bf16 (every e4m3 value is exactly representable in bf16)
+  auto widen = [&](const u32x2& r) -> u32x4 {
+    u32x4 o;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)r[h], false);
-        const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)r[h], true);
-        o[2 * h] = __builtin_amdgcn_perm(__float_as_uint(lo[1]), __float_as_uint(lo[0]), 0x07060302u);
-        o[2 * h + 1] = __builtin_amdgcn_perm(__float_as_uint(hi[1]), __float_as_uint(hi[0]), 0x07060302u);
-      }
-      return o;
-    } else {
-      return r;
+    for (int h = 0; h < 2; ++h) {  // v_cvt_scalef32_pk_bf16_fp8 (gfx950): two fp8 -> packed bf16x2 in one instruction, scale 1
+      o[2 * h] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[h], 1.0f, false));
+      o[2 * h + 1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[h], 1.0f, true));
     }
+    return o;
+  };
+  // what a staged weight load leaves in LDS: bf16
+  auto staged = [&](const WReg& r) -> u32x4 {
+    if constexpr (W8) return widen(r);
+    else return r;
   };
 
   const int cnt = wave < nsl ? (nsl - wave + NW - 1) / NW : 0;  // slices of this wave
-  if (cnt > 0) load_x(wave);
+  load_x(wave);
+
+  constexpr int DEPTH = SRGPT_SKINNY_DEPTH;
 
   // ---- RMSNorm statistics of every batch row (LlamaRMSNorm: fp32 mean of squares over K) ----
   auto rms_stats = [&]() {
@@ -189,11 +217,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   // one pass over K for NSU sub-units
   auto run_pass = [&](auto nsu_c, int pass, int nu) {
     constexpr int NSU = decltype(nsu_c)::value;
-    f32x4 acc[NSU];
+    constexpr int NS = SK / 32;           // MFMA k steps per stage
+    constexpr int FS = NI == 8 ? 2 : SRGPT_SKINNY_FS;  // k steps whose fragments are read together (16 staged rows: fewer, registers)
+    constexpr bool TWO_ACC = NI < 8;  // even / odd k steps on separate accumulators (16 staged rows: the registers are not there)
+    f32x4 acc[NSU], acc2[TWO_ACC ? NSU : 1];
 #pragma unroll
     for (int su = 0; su < NSU; ++su) acc[su] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int su = 0; su < (TWO_ACC ? NSU : 1); ++su) acc2[su] = f32x4{0.f, 0.f, 0.f, 0.f};
     // register ring of DEPTH weight stages with static slot indices (a trip = DEPTH slices x NSU stages, a multiple of
-    // DEPTH): the loads of stage t+DEPTH-1 are issued before stage t is multiplied.  bf16: 2 x 8 KiB, fp8: 2 x 4 KiB.
+    // DEPTH): the loads of stage t+DEPTH-1 are issued before stage t is multiplied.  A stage is 8 KiB per wave (fp8: 4 KiB).
+    WReg wb[DEPTH][8];
     // epilogue operands that do not depend on the products -- row scales (W8) and residual elements -- are requested now:
     // fetched at their use they would each add a memory round trip after the last barrier of the pass
     constexpr int EIT0 = ((NSU / R) * 256 + NT - 1) / NT;  // epilogue iterations per thread
@@ -204,55 +238,80 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
       const int e = tid + i * NT;
       const int u = e >> 8, l2 = e & 63, q = (e >> 6) & 3;
       const int b = min(4 * (l2 >> 4) + q, B - 1);
-      const int unit = (pass * MAXU + u) * grid + (int)blockIdx.x;
-      const int n = min(unit * 16 + (l2 & 15), N - 1);
+      const int n = min(c0 + (pass * MAXU + u) * 16 + (l2 & 15), c0 + cwb - 1);
 #pragma unroll
       for (int r = 0; r < R; ++r) pre_sc[i][r] = W8 ? wscale[n + r * N] : 1.f;
       pre_res[i] = (!SWIGLU && residual) ? (float)residual[(size_t)b * N + n] : 0.f;
     }
-    constexpr int DEPTH = 2;  // measured: a 4-deep ring of 4 KiB fp8 stages is slower than 2-deep (3.61 vs 3.85 TB/s on gate/up)
-    WReg wb[DEPTH][8];
 #pragma unroll
     for (int f = 0; f < DEPTH - 1; ++f)
-      if (f / NSU < cnt) issue_w(wb[f % DEPTH], pass, wave + NW * (f / NSU), f % NSU);
-    for (int i = 0; i < cnt; i += DEPTH) {
-#pragma unroll
-      for (int h = 0; h < DEPTH; ++h) {
-        const int sl = wave + NW * (i + h);
-        if (i + h < cnt) {
+      issue_w(wb[f % DEPTH], pass, wave + NW * (f / NSU), f % NSU, f / NSU < cnt);
+    // one slice (h-th of the trip that starts at slice index i): NSU stages
+    auto slice = [&](int i, auto h_c) {
+      constexpr int h = decltype(h_c)::value;
+      const int sl = wave + NW * (i + h);
+      {
 #pragma unroll
           for (int su = 0; su < NSU; ++su) {
             const int cur = (h * NSU + su) % DEPTH;
             const int fn = h * NSU + su + DEPTH - 1;  // stage to prefetch, relative to this trip
-            if (i + fn / NSU < cnt) issue_w(wb[fn % DEPTH], pass, wave + NW * (i + fn / NSU), fn % NSU);
+            issue_w(wb[fn % DEPTH], pass, wave + NW * (i + fn / NSU), fn % NSU, i + fn / NSU < cnt);
             if (su == 0) {
-              stage_x(sl);
-              if (i + h + 1 < cnt) load_x(sl + NW);
-              else if (pass + 1 < npass) load_x(wave);
+              stage_x(sl, true);
+              load_x(i + h + 1 < cnt ? sl + NW : wave);  // next slice, or the first one of the next pass
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(wst + (2 * j + lrow) * WROWB + lchunk * 16) = widen(wb[cur][j]);
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(wst + (2 * j + lrow) * WROWB + lchunk * 16) = staged(wb[cur][j]);
             __builtin_amdgcn_wave_barrier();
-            // x fragments are re-read per sub-unit rather than held: 32 VGPRs buy nothing, LDS has the headroom
+            // The fragment reads of FS k steps are issued together in front of their MFMAs, which alternate between two
+            // accumulators.  Left to the compiler the unrolled loop became read -> wait -> MFMA per k step on ONE accumulator: a
+            // full LDS latency per step, ~1.5k cycles per stage and sub-unit -- the kernel was bound by that, not by HBM.
             const int xrow = lane & (2 * NI - 1);  // rows past the staged ones alias valid rows: their outputs are never stored
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-              const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xst + xrow * WROWB + (4 * s + (lane >> 4)) * 16);
-              const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wst + (lane & 15) * WROWB + (4 * s + (lane >> 4)) * 16);
-              // D[batch row][weight row] += x[batch row][k] * W[weight row][k]
-              acc[su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, wf, acc[su], 0, 0, 0);
+            for (int s0 = 0; s0 < NS; s0 += FS) {
+              bf16x8 xf[FS];
+              bf16x8 wfr[FS];
+#pragma unroll
+              for (int t = 0; t < FS; ++t) {
+                const int s = s0 + t;
+                xf[t] = *reinterpret_cast<const bf16x8*>(xst + xrow * XROWB + (4 * s + (lane >> 4)) * 16);
+                wfr[t] = *reinterpret_cast<const bf16x8*>(wst + (lane & 15) * WROWB + (4 * s + (lane >> 4)) * 16);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int t = 0; t < FS; ++t) {
+                const bf16x8 wf = wfr[t];
+                // D[batch row][weight row] += x[batch row][k] * W[weight row][k]
+                if (TWO_ACC && (t & 1)) acc2[TWO_ACC ? su : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t], wf, acc2[TWO_ACC ? su : 0], 0, 0, 0);
+                else acc[su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t], wf, acc[su], 0, 0, 0);
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_wave_barrier();
           }
-        }
       }
+    };
+    // full trips run branch-free; the last cnt % DEPTH slices are guarded (nothing is left to prefetch behind them, so the
+    // conservative waits the guard brings cost nothing)
+    int i = 0;
+    for (; i + DEPTH <= cnt; i += DEPTH) {
+      slice(i, std::integral_constant<int, 0>{});
+      if constexpr (DEPTH > 1) slice(i, std::integral_constant<int, 1>{});
+      if constexpr (DEPTH > 2) slice(i, std::integral_constant<int, 2>{});
+      if constexpr (DEPTH > 3) slice(i, std::integral_constant<int, 3>{});
     }
+    if (i < cnt) slice(i, std::integral_constant<int, 0>{});
+    if constexpr (DEPTH > 2)
+      if (i + 1 < cnt) slice(i, std::integral_constant<int, 1>{});
+    if constexpr (DEPTH > 3)
+      if (i + 2 < cnt) slice(i, std::integral_constant<int, 2>{});
+    static_assert(DEPTH >= 2 && DEPTH <= 4, "ring depth");
 
     // ---- cross-wave reduction (fixed order) + epilogue ----
     __syncthreads();
     float* redf = reinterpret_cast<float*>(smem);  // [NW waves][MAXSU][64 lanes][4]
 #pragma unroll
-    for (int su = 0; su < NSU; ++su) *reinterpret_cast<f32x4*>(redf + ((wave * MAXSU + su) * 64 + lane) * 4) = acc[su];
+    for (int su = 0; su < NSU; ++su) *reinterpret_cast<f32x4*>(redf + ((wave * MAXSU + su) * 64 + lane) * 4) = TWO_ACC ? acc[su] + acc2[TWO_ACC ? su : 0] : acc[su];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < EIT; ++i) {
@@ -260,8 +319,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
       if (e >= (NSU / R) * 256) break;
       const int u = e >> 8, l2 = e & 63, q = (e >> 6) & 3;
       const int b = 4 * (l2 >> 4) + q;
-      const int unit = (pass * MAXU + u) * grid + (int)blockIdx.x;
-      const int n = unit * 16 + (l2 & 15);
+      const int n = c0 + (pass * MAXU + u) * 16 + (l2 & 15);
       float a[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -271,7 +329,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
         if (W8) t *= pre_sc[i][r];
         a[r] = t;
       }
-      if (b < B && n < N) {
+      if (b < B && n < c0 + cwb) {
         if (SWIGLU) {
           const float g = rnd<bf16_t>(a[0]), up = rnd<bf16_t>(a[R - 1]);
           reinterpret_cast<bf16_t*>(out)[(size_t)b * N + n] = (bf16_t)(rnd<bf16_t>(silu(g)) * up);
@@ -292,7 +350,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   for (int pass = 0; pass < npass; ++pass) {
     int nu = 0;
 #pragma unroll
-    for (int u = 0; u < MAXU; ++u) nu += ((pass * MAXU + u) * grid + (int)blockIdx.x < NU) ? 1 : 0;
+    for (int u = 0; u < MAXU; ++u) nu += (pass * MAXU + u < ntile) ? 1 : 0;
     if (nu == 0) break;  // uniform per block; later passes are empty too
     switch (nu * R) {
       case 1: run_pass(std::integral_constant<int, 1>{}, pass, nu); break;
@@ -305,15 +363,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
 
 template <bool SWIGLU, int NI, int NW, bool W8>
 int launch_skinny(const void* x, const void* W, const float* wscale, const void* norm_w, float eps, const void* residual,
-                  void* out, int batch, int N, int K, int out_f32, int grid, hipStream_t s) {
+                  void* out, int batch, int N, int K, int out_f32, int grid, int cw, hipStream_t s) {
   constexpr int lds = NW * (2 * NI * WROWB + WSTAGEB);
   static_assert(lds >= NW * MAXSU * 64 * 4 * 4, "reduction buffer must fit");
   static_assert(lds <= 160 * 1024, "LDS");
+  static_assert(NW == 8 || 2 * lds <= 160 * 1024, "two 4-wave blocks per CU");
   auto kfn = skinny_kernel<SWIGLU, NI, NW, W8>;
   static std::atomic<uint64_t> attr_done{0};
   SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)kfn, lds));
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * NW), lds, s, (const bf16_t*)x, W, wscale, (const bf16_t*)norm_w, eps,
-                     (const bf16_t*)residual, out, batch, N, K, out_f32);
+                     (const bf16_t*)residual, out, batch, N, K, out_f32, cw);
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }
@@ -321,14 +380,19 @@ int launch_skinny(const void* x, const void* W, const float* wscale, const void*
 template <bool SWIGLU, int NI, bool W8>
 int launch_skinny_nw(const void* x, const void* W, const float* wscale, const void* norm_w, float eps, const void* residual,
                      void* out, int batch, int N, int K, int out_f32, hipStream_t s) {
+  // Two 4-wave blocks per CU, or one 8-wave block per CU; both split the columns evenly over their blocks.  Measured per decode
+  // step (profiles/r02_skinny_ab.txt): 4-wave blocks win (o_proj 8.8 vs 9.7 us, fp8 gate/up 27.4 vs 30.4) except where a block
+  // would own few columns AND has the RMSNorm statistics to compute first (q/k/v: 24 columns per CU, 14.1 vs 14.3 us bf16,
+  // 12.3 vs 13.7 fp8) -- there the prologue is shared by twice the threads.
   const int cus = srgpt_device_cus();
-  const int NU = (N + 15) / 16;
-  if (NU <= cus) return launch_skinny<SWIGLU, NI, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, NU, s);
-  // balanced grid: every block gets the same number of units whenever N allows (e.g. 896 SwiGLU units -> 448 blocks x 2)
-  const int maxgrid = cus * 2;
-  const int per = (NU + maxgrid - 1) / maxgrid;  // units per block (more than MAXSU/R -> several passes in the kernel)
-  const int grid = (NU + per - 1) / per;
-  return launch_skinny<SWIGLU, NI, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, grid, s);
+  int waves = SRGPT_KNOB("SRGPT_SKINNY_WAVES", 0);
+  if (waves != 4 && waves != 8) waves = (norm_w != nullptr && (N + cus - 1) / cus <= 32) ? 8 : 4;
+  const int blocks = waves == 8 ? cus : 2 * cus;
+  int cw = (N + blocks - 1) / blocks;
+  if (cw < 16) cw = 16;
+  const int grid = (N + cw - 1) / cw;
+  if (waves == 8) return launch_skinny<SWIGLU, NI, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, grid, cw, s);
+  return launch_skinny<SWIGLU, NI, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, grid, cw, s);
 }
 
 template <bool W8>

@@ -203,10 +203,21 @@ def test_fp8_decode_matches_torch_float8():
     out = ops.gemv_w8(x.to(DEV), w8.to(DEV), torch.ones(n, dtype=torch.float32, device=DEV), out_f32=True)
     ref = codes.view(torch.float8_e4m3fn).float()
     assert torch.equal(out[0].cpu(), ref)
+    # the MFMA skinny kernel (3+ rows) widens with v_cvt_scalef32_pk_bf16_fp8: same table, every code, both staging forms
+    for rows in (3, 8, 16):
+        xb = torch.zeros((rows, 64), dtype=torch.bfloat16)
+        xb[:, 0] = 1.0
+        ob = ops.gemv_w8(xb.to(DEV), w8.to(DEV), torch.ones(n, dtype=torch.float32, device=DEV), out_f32=True)
+        assert torch.equal(ob.cpu(), ref[None].expand(rows, -1)), rows
 
 
 @pytest.mark.parametrize("B,N,K", [(1, 1000, 4096), (2, 4096, 4096), (4, 1001, 2560), (8, 512, 11008), (16, 333, 1024),
-                                   (20, 130, 264), (1, 33000, 256)])
+                                   (20, 130, 264), (1, 33000, 256),
+                                   # 3..8 rows, K % 16 == 0: the 512-k fp8 form of the skinny kernel (raw bytes in LDS) -- one block
+                                   # per unit with 8 waves (N/16 <= CUs), balanced 4-wave grid, several passes, K tails of a
+                                   # 512-slice, a single partial slice; K % 16 != 0 and 9..16 rows keep the 256-k form
+                                   (8, 4096, 4096), (5, 6144, 4096), (3, 1024, 4096), (7, 33000, 528), (8, 40, 48), (6, 64, 264),
+                                   (8, 14336, 1024), (4, 4096, 14336)])
 def test_gemv_w8_variants(B, N, K):
     """W8A16 decode product vs fp32 torch on the dequantised weights (tolerance: bf16 output rounding)."""
     ops, L = _ops()
@@ -233,7 +244,7 @@ def test_gemv_w8_variants(B, N, K):
     assert_close(ops.gemv_w8(xd, q8, sc), ops.gemv(xd, deq).float().cpu(), _tol(ref, dtype, 2), 0, "w8 vs bf16(deq)")
 
 
-@pytest.mark.parametrize("B,N,K", [(1, 1024, 4096), (8, 333, 512), (16, 100, 264)])
+@pytest.mark.parametrize("B,N,K", [(1, 1024, 4096), (8, 333, 512), (16, 100, 264), (8, 14336, 4096), (4, 1000, 2560), (5, 512, 1040)])
 def test_gemv_w8_swiglu(B, N, K):
     ops, L = _ops()
     dtype = torch.bfloat16
