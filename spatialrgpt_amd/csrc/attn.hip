@@ -66,34 +66,50 @@ __global__ __launch_bounds__(256) void flash_bf16_kernel(AttnArgs a) {
   const bf16_t* kb = a.k + b * a.k_bs + hk * a.k_hs;
   const bf16_t* vb = a.v + b * a.v_bs + hk * a.v_hs;
 
+  // The K / V rows of tile t + 1 are requested (into registers) before tile t is multiplied: without that every tile paid a
+  // full memory latency between two barriers (12 tiles per ViT head: more than half of the kernel).  The loads are
+  // unconditional with clamped addresses -- rows / columns outside the problem are zeroed when the registers go to LDS -- so the
+  // compiler can count them instead of draining the queue.
+  constexpr int NLD = NS / 4;  // 16-byte loads per thread and operand for one tile
+  u32x4 kreg[NLD], vreg[NLD];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + 256 * i;
+      const int key = idx / NS, c = idx - key * NS;
+      kreg[i] = *reinterpret_cast<const u32x4*>(kb + (int64_t)min(k0 + key, klen - 1) * a.k_ts + (c * 8 < a.D ? c * 8 : 0));
+      const int vkey = (idx & 15) | (((idx >> 6) & 3) << 4);
+      const int vc = ((idx >> 4) & 3) | ((idx >> 8) << 2);
+      vreg[i] = *reinterpret_cast<const u32x4*>(vb + (int64_t)min(k0 + vkey, klen - 1) * a.v_ts + (vc * 8 < a.D ? vc * 8 : 0));
+    }
+  };
+  if (kend > 0) fetch(0);
+
   for (int k0 = 0; k0 < kend; k0 += KVBLK) {
     __syncthreads();  // previous tile fully consumed
     // ---- stage K (row-major, swizzled slots) ----
 #pragma unroll
-    for (int i = 0; i < NS / 4; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int idx = tid + 256 * i;
       const int key = idx / NS, c = idx - key * NS;
-      u32x4 val = {0, 0, 0, 0};
-      if (k0 + key < klen && c * 8 < a.D)
-        val = *reinterpret_cast<const u32x4*>(kb + (int64_t)(k0 + key) * a.k_ts + c * 8);
+      u32x4 val = kreg[i];
+      if (!(k0 + key < klen && c * 8 < a.D)) val = u32x4{0, 0, 0, 0};
       *reinterpret_cast<u32x4*>(Ks + key * HDP + ((c ^ (key & SWM)) << 3)) = val;
     }
     // ---- stage V transposed: Vt[d][key] ----
 #pragma unroll
-    for (int i = 0; i < NS / 4; ++i) {
+    for (int i = 0; i < NLD; ++i) {
       const int idx = tid + 256 * i;
       const int key = (idx & 15) | (((idx >> 6) & 3) << 4);
       const int c = ((idx >> 4) & 3) | ((idx >> 8) << 2);
-      bf16x8 val;
-      if (k0 + key < klen && c * 8 < a.D)
-        val = *reinterpret_cast<const bf16x8*>(vb + (int64_t)(k0 + key) * a.v_ts + c * 8);
-      else
-#pragma unroll
-        for (int j = 0; j < 8; ++j) val[j] = (bf16_t)0.f;
+      u32x4 raw = vreg[i];
+      if (!(k0 + key < klen && c * 8 < a.D)) raw = u32x4{0, 0, 0, 0};
+      const bf16x8 val = __builtin_bit_cast(bf16x8, raw);
 #pragma unroll
       for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VT_LD + key] = val[j];
     }
     __syncthreads();
+    fetch(k0 + KVBLK);  // next tile (the one past the last re-reads valid rows and is never used)
 
     // ---- S^T = K Q^T : acc[s][r] = score(key = k0 + 16 s + 4 g + r, query = qrow) ----
     float p[4][4];
@@ -245,13 +261,15 @@ constexpr int DEC_SPLIT_MAX = 64;
 
 typedef SrgptPrefetch DecodePrefetch;  // common.h: L2 prefetch blocks appended to the launch (here: o_proj's weights)
 
-// splits per (sequence, kv head): enough blocks for ~2 per CU (a single sequence needs 16 splits to spread its K/V rows over
-// the chip; at 8 sequences the batch already does that and 16 splits only multiply the merge work), never fewer than the
-// score buffer requires (DEC_CHUNK_MAX keys per split)
+// splits per (sequence, kv head): enough blocks for ~2 per CU, capped at 16 for a single sequence (it needs them to spread its
+// K/V rows over the chip) and at 8 from two sequences up (the batch already spreads; more splits only multiply the merge work --
+// decode step at 4 sequences 3.44 ms with 8 splits vs 3.47 with 16, at 8 sequences 3.60 / 3.66, profiles/r02_decode_splits.txt),
+// never fewer than the score buffer requires (DEC_CHUNK_MAX keys per split)
 static inline int decode_nsplit(int max_pos, int B, int Hkv) {
   const int force = SRGPT_KNOB("SRGPT_DECODE_MIN_SPLITS", 0);  // tuning build: fixed split count
   int want = cdiv(2 * srgpt_device_cus(), Hkv * B);
-  if (want > 16) want = 16;
+  const int cap = B == 1 ? 16 : 8;
+  if (want > cap) want = cap;
   if (want < 1) want = 1;
   if (force > 0) want = force;
   int n = cdiv(max_pos, DEC_CHUNK_MAX);
@@ -272,7 +290,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   constexpr int KPW = 64 / LPK;  // keys per wave-instruction
   constexpr int HALF = D / 2;
   constexpr int STRIDE = 4 * KPW;  // keys per block iteration
-  constexpr int PF = 2;            // key iterations whose K/V rows are fetched up front (covers T <= 16*2*STRIDE)
+  constexpr int PF = 2;            // key iterations whose K/V rows are fetched up front (3 and 4 measured: no difference)
   __shared__ float qs[G][D];
   __shared__ float knew[D], vnew[D];
   __shared__ float sc[G][DEC_CHUNK_MAX];
