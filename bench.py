@@ -297,8 +297,10 @@ def main():
     eng = model.engine
     roof = None
     if rank == 0:
-        x = torch.randn((1, cfg.hidden), device=device).to(dtype)
-        outb = torch.empty((1, cfg.inter), device=device, dtype=dtype)
+        # the product as the timed workload launches it: one activation row per request of the batch (1-2 rows: the VALU GEMV,
+        # 3+ rows: the MFMA skinny kernel)
+        x = torch.randn((args.batch, cfg.hidden), device=device).to(dtype)
+        outb = torch.empty((args.batch, cfg.inter), device=device, dtype=dtype)
         fp8 = args.weights == "fp8"
         wgu = eng.w.llm_q["wgu"][0] if fp8 else eng.w.llm_t["wgu"]
         wsc = eng.w.llm_q["wgu"][1] if fp8 else [None] * len(wgu)
@@ -326,7 +328,7 @@ def main():
         alg_bytes = wgu[0].numel() * wgu[0].element_size()  # every weight byte exactly once per launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # whole decode phase (graph replays incl. attention + launch gaps), same events technique
-        st, _, _ = eng.prefill(torch.randn((1, 259, cfg.hidden), device=device).to(dtype), max_new=G)
+        st, _, _ = eng.prefill(torch.randn((args.batch, 259, cfg.hidden), device=device).to(dtype), max_new=G)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
@@ -341,15 +343,18 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemv.json")
         if not os.path.exists(pmc):
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")
-        if args.model == "vila15_8b" and os.path.exists(pmc) and not fp8:
+        if args.model == "vila15_8b" and os.path.exists(pmc) and not fp8 and rows == 1:
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
             traffic_src = f"static: {os.path.relpath(pmc, ROOT)} (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction; not measured in this run)"
-        roof = {"bound": "hbm", "kernel": ("skinny_kernel<swiglu, W8> (decode gate/up projection, fp8 weights)" if fp8 else
-                                           "gemv_kernel<bf16,1,swiglu> (decode gate/up projection, 54% of streamed bytes)"),
+        rows = args.batch
+        kname = (("skinny_kernel<swiglu, W8>" if rows > 2 else "gemv_w8_kernel<swiglu>") if fp8 else
+                 ("skinny_kernel<swiglu>" if rows > 2 else f"gemv_kernel<bf16,{rows},swiglu>"))
+        roof = {"bound": "hbm", "kernel": f"{kname} (decode gate/up projection at {rows} activation row(s), 54% of streamed bytes"
+                                          + (", fp8 weights)" if fp8 else ")"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5),
                 "how": "hip events around each launch on the launch stream, 3 sweeps over the 32 layers' matrices (cold in L3)",
-                "decode_ms_per_token": round(dec_ms, 4), "decode_weight_bytes_per_token": wbytes,
+                "decode_ms_per_step": round(dec_ms, 4), "decode_ms_per_token": round(dec_ms / rows, 4), "decode_rows": rows, "decode_weight_bytes_per_token": wbytes,
                 "decode_hbm_gbs_whole_step": round(wbytes / (dec_ms * 1e-3) / 1e9, 1),
                 "decode_frac_whole_step": round(wbytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 

@@ -5,7 +5,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
-for lib in old new; do
+for lib in ${LIBS:-old new}; do
   so=$R/spatialrgpt_amd/libsrgpt_hip_tuning.so; [ $lib = old ] && so=$R/spatialrgpt_amd/libsrgpt_hip_tuning_old.so
   for cfg in "8 fp8" "4 bf16"; do
     set -- $cfg
