@@ -299,7 +299,8 @@ def main():
     if rank == 0:
         # the product as the timed workload launches it: one activation row per request of the batch (1-2 rows: the VALU GEMV,
         # 3+ rows: the MFMA skinny kernel)
-        x = torch.randn((args.batch, cfg.hidden), device=device).to(dtype)
+        rows = args.batch
+        x = torch.randn((rows, cfg.hidden), device=device).to(dtype)
         outb = torch.empty((args.batch, cfg.inter), device=device, dtype=dtype)
         fp8 = args.weights == "fp8"
         wgu = eng.w.llm_q["wgu"][0] if fp8 else eng.w.llm_t["wgu"]
@@ -346,7 +347,6 @@ def main():
         if args.model == "vila15_8b" and os.path.exists(pmc) and not fp8 and rows == 1:
             traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
             traffic_src = f"static: {os.path.relpath(pmc, ROOT)} (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction; not measured in this run)"
-        rows = args.batch
         kname = (("skinny_kernel<swiglu, W8>" if rows > 2 else "gemv_w8_kernel<swiglu>") if fp8 else
                  ("skinny_kernel<swiglu>" if rows > 2 else f"gemv_kernel<bf16,{rows},swiglu>"))
         roof = {"bound": "hbm", "kernel": f"{kname} (decode gate/up projection at {rows} activation row(s), 54% of streamed bytes"
