@@ -259,6 +259,14 @@ __global__ __launch_bounds__(64) void simple_attn_kernel(const T* __restrict__ q
 constexpr int DEC_CHUNK_MAX = 256;
 constexpr int DEC_SPLIT_MAX = 64;
 
+#ifdef SRGPT_TUNING_KNOBS
+// phase stamps of the decode attention kernel (tuning build only; scripts/ubench_decode_stamps.py): block 0 -> slots 0..15, the
+// block that merges (kv head 0, sequence 0) -> slots 16..31
+__device__ unsigned long long srgpt_dbg_stamps[32];
+#define DEC_STAMP(i) do { if (stamp_base >= 0 && threadIdx.x == 0) srgpt_dbg_stamps[stamp_base + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DEC_STAMP(i) do { } while (0)
+#endif
 typedef SrgptPrefetch DecodePrefetch;  // common.h: L2 prefetch blocks appended to the launch (here: o_proj's weights)
 
 // splits per (sequence, kv head): enough blocks for ~2 per CU, capped at 16 for a single sequence (it needs them to spread its
@@ -303,6 +311,10 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
     return;
   }
   const int hk = (int)blockIdx.x % Hkv, split = ((int)blockIdx.x / Hkv) % nsplit, b = (int)blockIdx.x / (Hkv * nsplit);
+#ifdef SRGPT_TUNING_KNOBS
+  int stamp_base = blockIdx.x == 0 ? 0 : -1;
+#endif
+  DEC_STAMP(0);
   const int P = pos[b];
   const int total = P + 1;
   // the key ranges depend on the sequence length only (NOT on the cache capacity: fixed capacity-based ranges were measured --
@@ -326,6 +338,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
     }
   }
 
+  DEC_STAMP(1);
   // ---- rotate q (G heads) and the new k; stage v.  Every global load of this stage is issued before any of
   //      them is consumed (unrolled, index wrapped instead of branched): one L2 latency instead of three. ----
   {
@@ -361,7 +374,9 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
     }
     if (tid < D) vnew[tid] = vraw;
   }
+  DEC_STAMP(2);
   __syncthreads();
+  DEC_STAMP(3);
   if (split == 0) {  // exactly one block per (b, hk) appends; nobody reads position P from the cache
     for (int d = tid; d < D; d += 256) {
       kc[(size_t)P * D + d] = from_f<T>(knew[d]);
@@ -393,8 +408,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
       float part = 0.f;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) part = fmaf(kv[i], qs[gq][dl + i], part);
-#pragma unroll
-      for (int off = LPK >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off);
+      part = lanes_sum<LPK>(part);  // DPP / permlane: a ds_bpermute chain here cost ~2k cycles per key batch
       if ((lane % LPK) == 0) sc[gq][key - kbeg] = part * scale;
     }
   };
@@ -420,25 +434,27 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
     }
     score(key, kv);
   }
+  DEC_STAMP(4);
   __syncthreads();
   // ---- softmax statistics of the chunk, one wave per q head ----
   const int n = kend - kbeg;
   for (int gq = wave; gq < G; gq += 4) {
     float mx = -INFINITY;
     for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sc[gq][i]);
-    mx = wave_max(mx);
+    mx = lanes_max<64>(mx);
     float sum = 0.f;
     for (int i = lane; i < n; i += 64) {
       const float pv = __expf(sc[gq][i] - mx);
       sc[gq][i] = pv;
       sum += pv;
     }
-    sum = wave_sum(sum);
+    sum = lanes_sum<64>(sum);
     if (lane == 0) {
       stat_m[gq] = mx;
       stat_l[gq] = sum;
     }
   }
+  DEC_STAMP(5);
   __syncthreads();
   // ---- pass 2: O = P V ----
   float acc[G][VEC];
@@ -480,11 +496,10 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   for (int gq = 0; gq < G; ++gq)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      float x = acc[gq][i];
-#pragma unroll
-      for (int off = LPK; off < 64; off <<= 1) x += __shfl_xor(x, off);
+      const float x = strided_sum<LPK>(acc[gq][i]);  // over the wave's KPW key sub-groups
       if (sub == 0) red[wave][gq][dl + i] = x;
     }
+  DEC_STAMP(6);
   __syncthreads();
   // 8-byte write-through stores (pairs of floats; rows of D + 2 floats are 8-byte aligned because D is even)
   for (int w = tid; w < G * (D / 2); w += 256) {
@@ -499,14 +514,21 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   // ---- arrival ticket: every storing wave drains its write-through stores, one lane takes the ticket; the block that draws
   //      the last one merges the nsplit partials of its G query heads (fixed split order: the result does not depend on
   //      which block came last) and re-arms the ticket for the next launch on this stream ----
+  DEC_STAMP(7);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  DEC_STAMP(8);
   if (tid == 0) {
     const int t = __hip_atomic_fetch_add(tickets + (size_t)b * Hkv + hk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stat_l[0] = (t == nsplit - 1) ? 1.f : 0.f;  // stat_l is free again: broadcast "I am last" through the existing LDS
   }
   __syncthreads();
+  DEC_STAMP(9);
   if (stat_l[0] == 0.f) return;
+#ifdef SRGPT_TUNING_KNOBS
+  if (hk == 0 && b == 0) stamp_base = 16;
+#endif
+  DEC_STAMP(0);
   __syncthreads();
   // The first 16 splits' partials of this thread's pair of output dims AND the per-split statistics are requested back to
   // back: the merge pays one memory latency.  (G * D / 2 <= 256 * MAXW items; one or two per thread for the shipped shapes.)
@@ -533,12 +555,13 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
     const float ms_raw = __uint_as_float((unsigned)ml), ls_raw = __uint_as_float((unsigned)(ml >> 32));
     const float ms = ok ? ms_raw : -INFINITY;
     const float ls = ok ? ls_raw : 0.f;
-    const float M = wave_max(ms);
+    const float M = lanes_max<64>(ms);
     const float wv = (ms > -INFINITY) ? __expf(ms - M) : 0.f;
-    const float den = wave_sum(wv * ls);
+    const float den = lanes_sum<64>(wv * ls);
     sc[gq][lane] = wv;
     if (lane == 0) stat_m[gq] = den > 0.f ? 1.f / den : 0.f;
   }
+  DEC_STAMP(1);
   __syncthreads();
 #pragma unroll
   for (int wi = 0; wi < MAXW; ++wi) {
@@ -564,6 +587,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
       op[1] = from_f<T>(n1 * stat_m[gq]);
     }
   }
+  DEC_STAMP(2);
   if (tid == 0) __hip_atomic_store(tickets + (size_t)b * Hkv + hk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -615,6 +639,12 @@ int launch_decode(const void* qkv, void* kc, void* vc, const int* pos, const voi
 }
 
 }  // namespace
+
+#ifdef SRGPT_TUNING_KNOBS
+extern "C" int srgpt_debug_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(srgpt_dbg_stamps), sizeof(unsigned long long) * (n < 32 ? n : 32));
+}
+#endif
 
 extern "C" int64_t srgpt_decode_attn_ws_floats(int B, int Hq, int D) {
   return (int64_t)B * Hq * DEC_SPLIT_MAX * (D + 2) + (int64_t)B * Hq;  // partials + arrival tickets (<= B * Hkv ints)

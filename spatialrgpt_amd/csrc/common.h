@@ -119,6 +119,58 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Cross-lane sums / maxima on the VALU (DPP row operations + v_permlane16/32_swap) instead of ds_bpermute (what __shfl_xor
+// compiles to on gfx950: an LDS-crossbar round trip of ~100+ cycles per step, and reductions are dependent chains of them).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// v_permlane16_swap a, b swaps the odd 16-lane rows of a with the even rows of b; v_permlane32_swap the upper half-wave of a with
+// the lower half of b.  Fed two copies of v: a = the value of the lane's even row (lower half), b = of its odd row (upper half),
+// in every lane -- op(a, b) is the pairwise reduction with the same operand order, hence the same bits, in both partners.
+// (Inline asm: the builtins' second result comes back as a copy of the first with hipcc 7.2; the s_nops cover the VALU-write ->
+// permlane-read and permlane-write -> VALU-read hazards the assembler cannot see around an asm block.)
+template <typename Op>
+__device__ __forceinline__ float rows_pair(float v, Op op) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return op(a, b);
+}
+template <typename Op>
+__device__ __forceinline__ float halves_pair(float v, Op op) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return op(a, b);
+}
+// reduction over aligned groups of N lanes (N = 2, 4, ..., 64); every lane of a group ends with the same bits:
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror, then the row / half-wave swaps
+template <int N, typename Op>
+__device__ __forceinline__ float lanes_reduce(float v, Op op) {
+  if constexpr (N >= 2) v = op(v, dpp_mov<0xB1>(v));
+  if constexpr (N >= 4) v = op(v, dpp_mov<0x4E>(v));
+  if constexpr (N >= 8) v = op(v, dpp_mov<0x141>(v));
+  if constexpr (N >= 16) v = op(v, dpp_mov<0x140>(v));
+  if constexpr (N >= 32) v = rows_pair(v, op);
+  if constexpr (N >= 64) v = halves_pair(v, op);
+  return v;
+}
+template <int N>
+__device__ __forceinline__ float lanes_sum(float v) { return lanes_reduce<N>(v, [](float a, float b) { return a + b; }); }
+template <int N>
+__device__ __forceinline__ float lanes_max(float v) { return lanes_reduce<N>(v, [](float a, float b) { return fmaxf(a, b); }); }
+// sum over the lanes l, l + S, l + 2S, ... of the wave (S = 1, 2, ..., 32 a power of two): rotations inside the 16-lane row, then
+// the row / half-wave swaps; every lane ends with the sum of its residue class mod S
+template <int S>
+__device__ __forceinline__ float strided_sum(float v) {
+  if constexpr (S <= 8) v += dpp_mov<0x128>(v);   // row_ror:8
+  if constexpr (S <= 4) v += dpp_mov<0x124>(v);   // row_ror:4
+  if constexpr (S <= 2) v += dpp_mov<0x122>(v);   // row_ror:2
+  if constexpr (S <= 1) v += dpp_mov<0x121>(v);   // row_ror:1
+  if constexpr (S <= 16) v = rows_pair(v, [](float a, float b) { return a + b; });
+  if constexpr (S <= 32) v = halves_pair(v, [](float a, float b) { return a + b; });
+  return v;
+}
+
 // block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` is >= 16 floats of LDS
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);
