@@ -108,16 +108,6 @@ __device__ __forceinline__ float rnd(float x) { return to_f(from_f<T>(x)); }
 __device__ __forceinline__ float bf16lo(unsigned int u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16hi(unsigned int u) { return __uint_as_float(u & 0xffff0000u); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
 
 // Cross-lane sums / maxima on the VALU (DPP row operations + v_permlane16/32_swap) instead of ds_bpermute (what __shfl_xor
 // compiles to on gfx950: an LDS-crossbar round trip of ~100+ cycles per step, and reductions are dependent chains of them).
@@ -158,6 +148,23 @@ template <int N>
 __device__ __forceinline__ float lanes_sum(float v) { return lanes_reduce<N>(v, [](float a, float b) { return a + b; }); }
 template <int N>
 __device__ __forceinline__ float lanes_max(float v) { return lanes_reduce<N>(v, [](float a, float b) { return fmaxf(a, b); }); }
+// whole-wave reductions (every lane gets the result): 4 DPP steps + 2 swaps, ~50 cycles -- the __shfl_xor butterfly they replace is
+// six dependent ds_bpermute round trips (~700 cycles), which in the GEMV sat between a row's last FMA and the next row's loads
+#ifndef SRGPT_WAVE_BPERMUTE  // (A/B builds only: the butterfly)
+__device__ __forceinline__ float wave_sum(float v) { return lanes_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return lanes_max<64>(v); }
+#else
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+#endif
 // sum over the lanes l, l + S, l + 2S, ... of the wave (S = 1, 2, ..., 32 a power of two): rotations inside the 16-lane row, then
 // the row / half-wave swaps; every lane ends with the sum of its residue class mod S
 template <int S>
