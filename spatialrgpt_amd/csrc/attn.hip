@@ -133,8 +133,9 @@ __global__ __launch_bounds__(256) void flash_bf16_kernel(AttnArgs a) {
         mx = fmaxf(mx, sv);
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    // over the four 16-lane rows (the 4 g groups of a query column): v_permlane16/32_swap, not ds_bpermute (common.h)
+    mx = rows_pair(mx, [](float a, float b) { return fmaxf(a, b); });
+    mx = halves_pair(mx, [](float a, float b) { return fmaxf(a, b); });
     const float m_new = fmaxf(m, mx);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
     const float alpha = __expf(m - m_use);  // m = -inf -> 0
@@ -146,8 +147,8 @@ __global__ __launch_bounds__(256) void flash_bf16_kernel(AttnArgs a) {
         p[s][r] = __expf(p[s][r] - m_use);
         rs += p[s][r];
       }
-    rs += __shfl_xor(rs, 16);
-    rs += __shfl_xor(rs, 32);
+    rs = rows_pair(rs, [](float a, float b) { return a + b; });
+    rs = halves_pair(rs, [](float a, float b) { return a + b; });
     l = l * alpha + rs;
     m = m_new;
 #pragma unroll
