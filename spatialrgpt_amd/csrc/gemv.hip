@@ -15,6 +15,8 @@
 // Rounding points mirror PyTorch's bf16 materialisation of each intermediate.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 // Optional per-wave timestamping (scripts/ubench_gemv_ts.hip builds this file with -DSRGPT_GEMV_TS)
@@ -35,6 +37,10 @@ extern "C" void* srgpt_gemv_ts_ptr() {
 
 int srgpt_skinny_launch(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
                         int batch, int N, int K, int swiglu, int out_f32, hipStream_t s);  // skinny.hip
+
+#ifndef SRGPT_GEMV_PIPE
+#define SRGPT_GEMV_PIPE 1  // 0: issue -> consume per batch, nothing in flight across the prologue / reductions (A/B builds)
+#endif
 
 namespace {
 
@@ -79,6 +85,23 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
   const int nit = (nchunks + 63) >> 6;  // chunk iterations per row (64 lanes each)
   SRGPT_TS(0);
 
+  // one batch = 8 independent 1-KiB wave loads (R rows x U chunks), issued back to back in consumption order, indices clamped,
+  // never branched, so the compiler can place counted s_waitcnt vmcnt(N) in front of each consumer
+  u32x4 w[R][U];
+  auto issue = [&](int unit, int it0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(unit + r * N) * K);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        w[r][j] = __builtin_nontemporal_load(p + min((it0 + j) * 64 + lane, nchunks - 1));
+        // pin ISSUE order == CONSUMPTION order: left alone, the scheduler issued the first-consumed chunk last,
+        // which turns the counted waits below into a full vmcnt(0) drain before the first FMA
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
   // ---- prologue: stage x (and RMSNorm it) into LDS ----
   // All global loads of the prologue (activation chunks AND norm gains) are issued up front, branch-free, so the
   // block pays one L2 latency.  NXMAX (2 or 8, picked by the host) = chunks per thread held in registers; unused
@@ -101,6 +124,13 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
       xr[j] = *reinterpret_cast<const Vec16<T>*>(x + (size_t)c * VEC);
       gr[j] = *reinterpret_cast<const Vec16<T>*>((do_norm ? norm_w : x) + (size_t)(c % nchunks) * VEC);
     }
+#if SRGPT_GEMV_PIPE
+    // the wave's first weight batch goes out BEHIND the prologue's own loads (in-order return: the statistics below wait for the
+    // activations only) and its HBM latency overlaps the RMSNorm, the LDS staging and the barrier
+    __builtin_amdgcn_sched_barrier(0);
+    issue(min((int)blockIdx.x * 4 + wave, N - 1), 0);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     float ss[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) ss[b] = 0.f;
@@ -178,21 +208,10 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
       for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
 
     for (int it0 = 0; it0 < nit; it0 += U) {
-      // one batch: 8 independent 1-KiB wave loads go out back to back (indices clamped, never branched, so the
-      // compiler can place counted s_waitcnt vmcnt(N) in front of each consumer), then they are consumed in order.
       // Waves drift apart naturally, so some stream while others multiply; 8 waves/CU keep 64 KiB in flight.
-      u32x4 w[R][U];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(unit + r * N) * K);
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          w[r][j] = __builtin_nontemporal_load(p + min((it0 + j) * 64 + lane, nchunks - 1));
-          // pin ISSUE order == CONSUMPTION order: left alone, the scheduler issued the first-consumed chunk last,
-          // which turns the counted waits below into a full vmcnt(0) drain before the first FMA
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+#if !SRGPT_GEMV_PIPE
+      issue(unit, it0);
+#endif
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         // branch-free: a chunk index past the row end is clamped for the loads and its weights are zeroed here.
@@ -220,6 +239,14 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
           }
         }
       }
+#if SRGPT_GEMV_PIPE
+      // the registers are free again: the next batch of this wave's stream (the row's next chunks, or the first chunks of its
+      // next unit; past the last unit a valid row is re-read and dropped) goes out before the reduction and the store
+      {
+        const bool more = it0 + U < nit;
+        issue(more ? unit : min(unit + (int)gridDim.x * 4, N - 1), more ? it0 + U : 0);
+      }
+#endif
     }
 
 #pragma unroll
@@ -267,6 +294,23 @@ __global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunks = K / VEC;
 
+  // one batch of the weight stream: the static chunks IT0 .. IT0 + U - 1 of the unit's R rows (issue order == consumption order)
+  u32x4 w[R][U];
+  auto issue = [&](int unit, auto it0_c) {
+    constexpr int IT0 = decltype(it0_c)::value;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(unit + r * N) * K);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        if (IT0 + j < NIT) {  // static
+          w[r][j] = __builtin_nontemporal_load(p + min((IT0 + j) * 64 + lane, nchunks - 1));
+          __builtin_amdgcn_sched_barrier(0);  // issue order == consumption order (see gemv_kernel)
+        }
+      }
+    }
+  };
+
   // ---- prologue: the lane's chunks of x (and gains), straight to registers; nothing here is shared between waves ----
   u32x4 xp[NIT];
   float res_pre = 0.f;
@@ -282,6 +326,12 @@ __global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restri
       xp[j] = *reinterpret_cast<const u32x4*>(x + (size_t)c * VEC);
       if (NORM) gr[j] = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * VEC);
     }
+#if SRGPT_GEMV_PIPE
+    // first weight batch behind the activation loads (see gemv_kernel): its latency overlaps theirs and the statistics
+    __builtin_amdgcn_sched_barrier(0);
+    issue(min((int)blockIdx.x * 4 + wave, N - 1), std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (NORM) {
       float ss = 0.f;
 #pragma unroll
@@ -314,20 +364,11 @@ __global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restri
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int it0 = 0; it0 < NIT; it0 += U) {
-      u32x4 w[R][U];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)(unit + r * N) * K);
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          if (it0 + j < NIT) {  // static
-            w[r][j] = __builtin_nontemporal_load(p + min((it0 + j) * 64 + lane, nchunks - 1));
-            __builtin_amdgcn_sched_barrier(0);  // issue order == consumption order (see gemv_kernel)
-          }
-        }
-      }
+    auto batch = [&](auto it0_c) {
+      constexpr int it0 = decltype(it0_c)::value;
+#if !SRGPT_GEMV_PIPE
+      issue(unit, it0_c);
+#endif
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         if (it0 + j < NIT) {  // static
@@ -344,11 +385,22 @@ __global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restri
           }
         }
       }
-    }
+#if SRGPT_GEMV_PIPE
+      // the next batch of the wave's stream goes out before the reduction and the store (past the last unit: a valid row, dropped)
+      if constexpr (it0 + U < NIT) issue(unit, std::integral_constant<int, it0 + U>{});
+      else issue(min(unit + (int)gridDim.x * 4, N - 1), std::integral_constant<int, 0>{});
+#endif
+    };
+    batch(std::integral_constant<int, 0>{});
+    if constexpr (U < NIT) batch(std::integral_constant<int, U>{});
+    if constexpr (2 * U < NIT) batch(std::integral_constant<int, 2 * U>{});
+    if constexpr (3 * U < NIT) batch(std::integral_constant<int, 3 * U>{});
+    static_assert(4 * U >= NIT, "gemv_reg_kernel: at most 4 batches per row");
     float a[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) a[r] = wave_sum(acc[r]);
-    const float res_b = __shfl(res_pre, uk < RES_MAXU ? uk : 0);
+    // lane uk of res_pre holds the residual element of this unit (uniform index: v_readlane, not a ds_bpermute)
+    const float res_b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, res_pre), uk < RES_MAXU ? uk : 0));
     if (lane == 0) {
       if (SWIGLU) {
         const float g = rnd<T>(a[0]), u = rnd<T>(a[R - 1]);

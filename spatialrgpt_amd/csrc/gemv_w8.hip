@@ -40,6 +40,32 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
   const int nit = (wchunks + 63) >> 6;   // weight-chunk iterations per row (64 lanes each)
   const int NUNIT = (N + 1) >> 1;
 
+  // rows of a unit (wave-uniform: scalar addressing).  plain: rows 2u, 2u+1; SwiGLU: gate rows 2u, 2u+1 and up rows N+2u, N+2u+1.
+  // The second row of an odd-N tail unit is clamped and never stored.
+  auto unit_rows = [&](int unit, int* rows) {
+    rows[0] = __builtin_amdgcn_readfirstlane(2 * unit);
+    rows[1] = __builtin_amdgcn_readfirstlane(min(2 * unit + 1, N - 1));
+    if (SWIGLU) {
+      rows[R - 2] = __builtin_amdgcn_readfirstlane(N + 2 * unit);
+      rows[R - 1] = __builtin_amdgcn_readfirstlane(N + min(2 * unit + 1, N - 1));
+    }
+  };
+  // one batch of the weight stream: R rows x U chunks, issued in consumption order, indices clamped, never branched
+  u32x4 w[R][U];
+  auto issue = [&](int unit, int it0) {
+    int rows[R];
+    unit_rows(unit, rows);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)rows[r] * K);
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        w[r][j] = __builtin_nontemporal_load(p + min((it0 + j) * 64 + lane, wchunks - 1));
+        __builtin_amdgcn_sched_barrier(0);  // issue order == consumption order (see gemv.hip)
+      }
+    }
+  };
+
   // ---- prologue: stage x (and RMSNorm it) into LDS ----
   // All global loads of the prologue (activation chunks AND norm gains) are issued up front, branch-free, so the
   // block pays one L2 latency.  NXMAX (2 or 8, picked by the host) = chunks per thread held in registers; unused
@@ -63,6 +89,10 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
       xr[j] = *reinterpret_cast<const Vec16<T>*>(x + (size_t)c * VEC);
       gr[j] = *reinterpret_cast<const Vec16<T>*>((do_norm ? norm_w : x) + (size_t)(c % nchunks) * VEC);
     }
+    // first weight batch behind the prologue's own loads: its HBM latency overlaps the RMSNorm, the LDS staging and the barrier
+    __builtin_amdgcn_sched_barrier(0);
+    issue(min((int)blockIdx.x * 4 + wave, NUNIT - 1), 0);
+    __builtin_amdgcn_sched_barrier(0);
     float ss[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) ss[b] = 0.f;
@@ -132,16 +162,8 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
 
   int uk = 0;
   for (int unit = blockIdx.x * 4 + wave; unit < NUNIT; unit += gridDim.x * 4, ++uk) {
-    // rows of the unit (the second row of an odd-N tail unit is clamped and never stored)
-    // rows of the unit (wave-uniform: scalar addressing).  plain: rows 2u, 2u+1; SwiGLU: gate rows 2u, 2u+1 and up rows
-    // N+2u, N+2u+1.  The second row of an odd-N tail unit is clamped and never stored.
     int rows[R];
-    rows[0] = __builtin_amdgcn_readfirstlane(2 * unit);
-    rows[1] = __builtin_amdgcn_readfirstlane(min(2 * unit + 1, N - 1));
-    if (SWIGLU) {
-      rows[R - 2] = __builtin_amdgcn_readfirstlane(N + 2 * unit);
-      rows[R - 1] = __builtin_amdgcn_readfirstlane(N + min(2 * unit + 1, N - 1));
-    }
+    unit_rows(unit, rows);
     // the row scales are requested BEFORE the weight stream (scalar loads): placed at their use they would queue behind
     // the weight loads and expose a memory latency per unit (same trap as the residual element, see gemv.hip)
     float sc[R];
@@ -154,16 +176,6 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
       for (int b = 0; b < B; ++b) acc[r][b] = 0.f;
 
     for (int it0 = 0; it0 < nit; it0 += U) {
-      u32x4 w[R][U];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const u32x4* p = reinterpret_cast<const u32x4*>(W + (size_t)rows[r] * K);
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          w[r][j] = __builtin_nontemporal_load(p + min((it0 + j) * 64 + lane, wchunks - 1));
-          __builtin_amdgcn_sched_barrier(0);  // issue order == consumption order (see gemv.hip)
-        }
-      }
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         const int ch = (it0 + j) * 64 + lane;
@@ -198,6 +210,11 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
             }
           }
         }
+      }
+      // the next batch of the wave's stream goes out before the reduction and the store (past the last unit: a valid unit, dropped)
+      {
+        const bool more = it0 + U < nit;
+        issue(more ? unit : min(unit + (int)gridDim.x * 4, NUNIT - 1), more ? it0 + U : 0);
       }
     }
 
