@@ -44,6 +44,9 @@ constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumu
 #ifndef SRGPT_SKINNY_DEPTH
 #define SRGPT_SKINNY_DEPTH 2           // register ring depth of weight stages (tuning builds override)
 #endif
+#ifndef SRGPT_SKINNY_PRE
+#define SRGPT_SKINNY_PRE 1            // first weight stage of a block requested before its RMSNorm statistics are reduced
+#endif
 #ifndef SRGPT_SKINNY_FS
 #define SRGPT_SKINNY_FS 4              // MFMA k steps per fragment batch (8 LDS reads in flight per batch)
 #endif
@@ -164,11 +167,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   load_x(wave);
 
   constexpr int DEPTH = SRGPT_SKINNY_DEPTH;
+  // measured per decode step (profiles/r02_skinny_ab.txt, section 6): 5-8 rows bf16 -1.8 %, 3-4 rows bf16 +-0, fp8 +0.8..1 % -> bf16 only;
+  // 16 staged rows: the registers are not there
+  constexpr bool PRE = SRGPT_SKINNY_PRE != 0 && !W8 && NI == 4;
 
   // ---- RMSNorm statistics of every batch row (LlamaRMSNorm: fp32 mean of squares over K) ----
-  auto rms_stats = [&]() {
+  // `between` runs once, after the statistics' first batch of loads has been issued and before it is reduced
+  auto rms_stats = [&](auto&& between) {
     constexpr int HT = NT / 2;                      // threads per row parity
-    constexpr int UF = 16 / NI;                     // 16 loads in flight per thread
+    constexpr int UF = (PRE && NI >= 4 ? 8 : 16) / NI;  // loads in flight per thread (8 when a weight stage is in flight too)
     const int half = tid / HT, kc = tid % HT;       // thread -> rows {2i + half}, chunks kc, kc + HT, ...
     float ss[NI];
 #pragma unroll
@@ -184,6 +191,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
           const int c = min(c0 + u * HT + kc, nch - 1);
           v[u][i] = *reinterpret_cast<const u32x4*>(x + (size_t)b * K + (size_t)c * 8);
         }
+      if (c0 == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        between();
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int u = 0; u < UF; ++u) {
         const bool ok = c0 + u * HT + kc < nch;
@@ -243,8 +255,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
       for (int r = 0; r < R; ++r) pre_sc[i][r] = W8 ? wscale[n + r * N] : 1.f;
       pre_res[i] = (!SWIGLU && residual) ? (float)residual[(size_t)b * N + n] : 0.f;
     }
+    // pass 0: the first weight stage goes out behind the statistics' own loads (in-order return: the reduction waits for its
+    // activations only), so its HBM latency overlaps the reduction and the two block barriers -- as in the GEMV's prologue
+    if (PRE && pass == 0 && do_norm) rms_stats([&]() { issue_w(wb[0], 0, wave, 0, cnt > 0); });
+    else issue_w(wb[0], pass, wave, 0, cnt > 0);
 #pragma unroll
-    for (int f = 0; f < DEPTH - 1; ++f)
+    for (int f = 1; f < DEPTH - 1; ++f)
       issue_w(wb[f % DEPTH], pass, wave + NW * (f / NSU), f % NSU, f / NSU < cnt);
     // one slice (h-th of the trip that starts at slice index i): NSU stages
     auto slice = [&](int i, auto h_c) {
@@ -346,7 +362,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     __syncthreads();  // the reduction buffer aliases the wave-private stages of the next pass
   };
 
-  if (do_norm) rms_stats();
+  if (!PRE && do_norm) rms_stats([]() {});
   for (int pass = 0; pass < npass; ++pass) {
     int nu = 0;
 #pragma unroll
