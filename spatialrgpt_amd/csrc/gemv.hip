@@ -38,6 +38,10 @@ extern "C" void* srgpt_gemv_ts_ptr() {
 int srgpt_skinny_launch(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
                         int batch, int N, int K, int swiglu, int out_f32, hipStream_t s);  // skinny.hip
 
+#ifndef SRGPT_GEMV_REG_PIPE
+#define SRGPT_GEMV_REG_PIPE 0  // the same for the register-resident variant (o_proj: its weights are L2-prefetched; measured
+                               // 3.036 vs 3.042 ms per token, o_proj 5.0 vs 5.45 us -- off)
+#endif
 #ifndef SRGPT_GEMV_PIPE
 #define SRGPT_GEMV_PIPE 1  // 0: issue -> consume per batch, nothing in flight across the prologue / reductions (A/B builds)
 #endif
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restri
       xp[j] = *reinterpret_cast<const u32x4*>(x + (size_t)c * VEC);
       if (NORM) gr[j] = *reinterpret_cast<const u32x4*>(norm_w + (size_t)c * VEC);
     }
-#if SRGPT_GEMV_PIPE
+#if SRGPT_GEMV_REG_PIPE
     // first weight batch behind the activation loads (see gemv_kernel): its latency overlaps theirs and the statistics
     __builtin_amdgcn_sched_barrier(0);
     issue(min((int)blockIdx.x * 4 + wave, N - 1), std::integral_constant<int, 0>{});
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restri
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
     auto batch = [&](auto it0_c) {
       constexpr int it0 = decltype(it0_c)::value;
-#if !SRGPT_GEMV_PIPE
+#if !SRGPT_GEMV_REG_PIPE
       issue(unit, it0_c);
 #endif
 #pragma unroll
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restri
           }
         }
       }
-#if SRGPT_GEMV_PIPE
+#if SRGPT_GEMV_REG_PIPE
       // the next batch of the wave's stream goes out before the reduction and the store (past the last unit: a valid row, dropped)
       if constexpr (it0 + U < NIT) issue(unit, std::integral_constant<int, it0 + U>{});
       else issue(min(unit + (int)gridDim.x * 4, N - 1), std::integral_constant<int, 0>{});
