@@ -2,6 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from spatialrgpt_amd import _lib
+if os.environ.get("SRGPT_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["SRGPT_LIB"])
 from spatialrgpt_amd import ops
 
 dev = "cuda"

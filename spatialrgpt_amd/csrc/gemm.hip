@@ -159,12 +159,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma(const bf16_t* __restrict__
 template <int BM, int BN, int NBUF>
 __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_bf16_glds(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                          int K, int lda, Epilogue e) {
-  constexpr int TM = BM / 64, TN = BN / 64;
+  // wave layout: 2 x 2 waves of (BM/2) x (BN/2) when BM is a multiple of 64; BM = 96 (three 32-row MFMA tiles -- 259 rows pad to
+  // 288 instead of 320 and a tile step moves 17.8 instead of 23.4 bytes per kFLOP through the fill path that bounds this kernel):
+  // 1 x 4 waves of 96 x (BN/4)
+  constexpr int WAVES_M = BM % 64 == 0 ? 2 : 1, WAVES_N = 4 / WAVES_M;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // rows / columns of a wave's sub-tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM * 32 * WAVES_M == BM && TN * 32 * WAVES_N == BN && BM % 32 == 0 && BN % 32 == 0, "tile / wave layout");
   constexpr int TILE = (BM + BN) * BK;  // elements per stage buffer
   __shared__ __attribute__((aligned(1024))) bf16_t lds[NBUF * TILE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WAVES_M == 2 ? wave >> 1 : 0, wn = WAVES_M == 2 ? wave & 1 : wave;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   // row within the 8-row group; logical chunk this lane fetches = physical slot ^ swz(row), swz(row) = (row >> 1) & 7
   // (group base rows are multiples of 8: (row >> 1) & 7 = ((wave & 1) << 2) | (lr >> 1) for every group of this wave)
@@ -227,12 +233,12 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_bf16_glds(const b
       const int slot = ks * 2 + (lane >> 5);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int r = wm * (BM / 2) + i * 32 + (lane & 31);
+        const int r = wm * WTM + i * 32 + (lane & 31);
         fa[i] = *reinterpret_cast<const bf16x8*>(As + r * BK + ((slot ^ ((r >> 1) & 7)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int r = wn * (BN / 2) + j * 32 + (lane & 31);
+        const int r = wn * WTN + j * 32 + (lane & 31);
         fw[j] = *reinterpret_cast<const bf16x8*>(Ws + r * BK + ((slot ^ ((r >> 1) & 7)) << 3));
       }
 #pragma unroll
@@ -265,8 +271,8 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_bf16_glds(const b
 #pragma clang loop unroll(full)
     for (int j = 0; j < TN; ++j) {
       const f32x16 a = acc[i][j];
-      const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-      const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+      const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+      const int mb = m0 + wm * WTM + i * 32 + 4 * (lane >> 5);
       if (e.splits > 1) {
         float* slab = e.partial + (size_t)blockIdx.z * e.M * e.N;
 #pragma clang loop unroll(full)
@@ -536,6 +542,11 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
   if (t128 < 1024 || pad_waste) {
     bm = 64;
     tiles = t64x128;
+    // 96-row tiles (three 32-row MFMA tiles per wave, 1 x 4 waves) where they do not pad M by more than 8 % over 64-row tiles:
+    // this kernel is bound by the global -> LDS fill rate, and a 96x128 step moves 17.8 B/kFLOP against 23.4 (M = 259 pads to
+    // 288 instead of 320: gate/up 156 -> 106 us, ViT fc1 38 -> 25 us, profiles/r02_gemm_bm96.txt).  The split count keeps
+    // following the 64-row tile count (the measured configuration).
+    if (M > 64 && (long)cdiv(M, 96) * 96 * 100 <= (long)cdiv(M, 64) * 64 * 108) bm = 96;
     if (tiles < 384 && ws) {
       splits = (int)((512 + tiles - 1) / tiles);
       if (splits > nk / 8) splits = nk / 8;  // keep >= 8 K-tiles (512 columns of K) per split
@@ -547,7 +558,7 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
   {  // tuning knobs (scripts/ubench_gemm.py sweeps them); unset in production
     const int f_bm = SRGPT_KNOB("SRGPT_GEMM_FORCE_BM", 0);
     const int f_sp = SRGPT_KNOB("SRGPT_GEMM_FORCE_SPLITS", 0);
-    if (f_bm == 64 || f_bm == 128) bm = f_bm;
+    if (f_bm == 64 || f_bm == 128 || f_bm == 96) bm = f_bm;
     if (f_sp > 0 && ws) {
       splits = f_sp;
       if (splits > nk) splits = nk;
@@ -571,6 +582,17 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
     else
 #endif
       hipLaunchKernelGGL((gemm_bf16_glds<128, 128, 1>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+  } else if (bm == 96) {
+    dim3 grid(cdiv(N, 128), cdiv(M, 96), e.splits);  // (96x256 tiles measured: slower on every shape)
+    const int f_nbuf = SRGPT_KNOB("SRGPT_GEMM_FORCE_NBUF", 0);
+    const long blocks = (long)grid.x * grid.y * e.splits;
+    // single buffer (5 blocks per CU overlap each other's K steps) only for un-split grids of >= 2 blocks per CU (gate/up 672,
+    // ViT fc1 544 blocks: 106 vs 134 us, 25 vs 33 us); split-K and smaller grids double-buffer (q/k/v 34 vs 38 us)
+    const bool dbuf = f_nbuf ? f_nbuf == 2 : !(e.splits <= 1 && blocks >= 2L * srgpt_device_cus());
+    if (dbuf)
+      hipLaunchKernelGGL((gemm_bf16_glds<96, 128, 2>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
+    else
+      hipLaunchKernelGGL((gemm_bf16_glds<96, 128, 1>), grid, dim3(256), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
   } else {
     dim3 grid(cdiv(N, 128), cdiv(M, 64), e.splits);
     const int f_nbuf = SRGPT_KNOB("SRGPT_GEMM_FORCE_NBUF", 0);

@@ -33,7 +33,10 @@ def _tol(ref, dtype, k=1.0):
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(130, 200, 136), (259, 512, 1024), (64, 64, 64), (729, 1152, 592), (100, 264, 4304),
-                                   (8, 4096, 1152), (300, 1000, 72)])
+                                   (8, 4096, 1152), (300, 1000, 72),
+                                   # 96-row tiles (1 x 4 waves): single-buffered un-split grid (>= 2 blocks per CU), double-buffered
+                                   # split-K, ragged last row tile (259 = 2 x 96 + 67), ragged N, K tail through registers
+                                   (259, 28672, 512), (259, 4096, 4096), (1458, 4304, 1152), (97, 130, 200), (288, 640, 64)])
 def test_gemm_plain(dtype, M, N, K):
     ops, L = _ops()
     if dtype == torch.float32 and K % 4:
