@@ -1,4 +1,4 @@
-// Batched decode-path weight-streaming product for 5..16 rows: out[b, n] = W[n, :] . x[b, :]   (bf16, HBM-bound)
+// Batched decode-path weight-streaming product for 3..16 rows: out[b, n] = W[n, :] . x[b, :]   (bf16, HBM-bound)
 //
 // Same contract and fusions as the GEMV (gemv.hip: RMSNorm prologue, SwiGLU epilogue, residual add, fp32 logits), but
 // above 4 rows the VALU formulation runs out of issue slots and LDS bandwidth (B LDS reads + 8 B FMAs per 16 weight
@@ -17,9 +17,9 @@
 // partial: its missing rows are not loaded); cw = ceil(N / blocks) makes every CU stream the same number of weight rows
 // (6144 q/k/v columns = 24 per CU, 14336 gate/up pairs = 56 -- whole 16-column units left a quarter of the CUs with half the
 // work).  A tile is one sub-unit (SwiGLU: the 16 gate rows + the 16 matching up rows = 2 sub-units); up to 4 sub-units per
-// pass keep their 16x16 fp32 accumulators in registers (4 VGPRs each).  The 4 waves of a block split K in interleaved 256-wide slices, so every block uses all its waves
-// even when N/16 is only one tile per CU (o_proj / down_proj); their partial sums are added in a fixed order through
-// LDS at the end of the pass (deterministic).
+// pass keep their 16x16 fp32 accumulators in registers (2 x 4 VGPRs each).  The waves of a block split K in interleaved 256-wide
+// slices, so every block uses all its waves even when it owns a single tile (o_proj / down_proj); their partial sums are added
+// in a fixed order through LDS at the end of the pass (deterministic).
 //
 // The K loop is written for counted waits: every load in it is issued unconditionally, so the compiler can leave the
 // prefetched stage in flight across the LDS writes (a branch around a load makes it wait for vmcnt(0) -- the prefetch was being
@@ -51,8 +51,8 @@ constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumu
 #define SRGPT_SKINNY_FS 4              // MFMA k steps per fragment batch (8 LDS reads in flight per batch)
 #endif
 
-// NI = x rows staged per wave / 2: 2 (batch <= 4), 4 (batch <= 8) or 8 (batch <= 16).  NW = waves per block (the K split): 4, or 8 when
-// there are no more units than CUs so that one block per CU still keeps 8 waves streaming.
+// NI = x rows staged per wave / 2: 2 (batch <= 4), 4 (batch <= 8) or 8 (batch <= 16).  NW = waves per block (the K split): two 4-wave
+// blocks per CU, or one 8-wave block per CU (the launcher's rule, below).
 // W8: the weights are OCP fp8 e4m3fn bytes with one fp32 scale per weight row (W8A16): a stage is 8 loads of 8 bytes per lane
 // (2 rows x 256 bytes each), widened to bf16 (exact) on the way into LDS; the row scale multiplies the fp32 dot product.
 // (Measured and dropped: 512-k fp8 slices with the raw bytes in LDS and the widening behind the fragment read -- a stage of as
