@@ -131,9 +131,13 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __rest
   }
 }
 
-// stage 2 + bookkeeping: one wave per batch row merges the partials -> tok / out_ids[:, step] / pos / step
+// stage 2 + bookkeeping: one wave per batch row merges the partials -> tok / out_ids[:, step] / pos / step, and (embed != NULL)
+// the embedding rows of the picked tokens go straight into the residual-stream buffer of the next step (one launch fewer per token)
+constexpr int ADVANCE_MAXB = 256;
 __global__ void advance_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int nb, int64_t* tok,
-                               int64_t* out_ids, int* pos, int* step, int B, int max_new, int bump_pos) {
+                               int64_t* out_ids, int* pos, int* step, int B, int max_new, int bump_pos,
+                               const unsigned char* __restrict__ embed, unsigned char* __restrict__ xd, int row_bytes) {
+  __shared__ int picked[ADVANCE_MAXB];
   const int s = *step;
   const int lane = threadIdx.x & 63;
   for (int b = threadIdx.x >> 6; b < B; b += blockDim.x >> 6) {
@@ -159,19 +163,35 @@ __global__ void advance_kernel(const float* __restrict__ pv, const int* __restri
     if (lane == 0) {
       const int64_t t = bi == 0x7fffffff ? 0 : bi;
       tok[b] = t;
+      if (embed && b < ADVANCE_MAXB) picked[b] = (int)t;
       if (s < max_new) out_ids[(size_t)b * max_new + s] = t;
       if (bump_pos) pos[b] += 1;
     }
   }
   __syncthreads();
   if (threadIdx.x == 0) *step = s + 1;
+  if (embed) {
+    const int per_row = row_bytes >> 4;  // 16-byte chunks per embedding row
+    for (int i = threadIdx.x; i < B * per_row; i += blockDim.x) {
+      const int b = i / per_row, c = i - b * per_row;
+      *reinterpret_cast<u32x4*>(xd + (size_t)b * row_bytes + (size_t)c * 16) =
+          *reinterpret_cast<const u32x4*>(embed + (size_t)picked[b] * row_bytes + (size_t)c * 16);
+    }
+  }
+}
+
+// the next step's embedding rows can come from advance_kernel when they are whole 16-byte chunks and the batch fits its LDS list
+static inline bool advance_embeds(const srgpt_llm_weights* w, const srgpt_llm_state* st) {
+  return st->batch <= ADVANCE_MAXB && ((size_t)w->hidden * dtype_size(w->dtype)) % 16 == 0;
 }
 
 static int greedy_pick(const srgpt_llm_weights* w, srgpt_llm_state* st, const LlmWs& d, int bump_pos, hipStream_t s) {
   const int B = st->batch;
+  const bool emb = advance_embeds(w, st);
   hipLaunchKernelGGL(argmax_partial_kernel, dim3(ARGMAX_BLOCKS, B), dim3(256), 0, s, st->logits, d.amax_v, d.amax_i, w->vocab);
   hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(256), 0, s, d.amax_v, d.amax_i, ARGMAX_BLOCKS, st->tok, st->out_ids,
-                     st->pos, st->step, B, st->max_new, bump_pos);
+                     st->pos, st->step, B, st->max_new, bump_pos, emb ? reinterpret_cast<const unsigned char*>(w->embed) : nullptr,
+                     reinterpret_cast<unsigned char*>(d.xd), (int)((size_t)w->hidden * dtype_size(w->dtype)));
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }
@@ -374,7 +394,9 @@ extern "C" int srgpt_llm_sample_first(const srgpt_llm_weights* w, srgpt_llm_stat
   return greedy_pick(w, st, d, 0, s);
 }
 
-extern "C" int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream) {
+// embed_first = false: the residual-stream buffer already holds the embeddings of st->tok (written by the advance_kernel of the
+// step before: the graph-captured greedy loop); the public entry always embeds (st->tok may have been set by the caller)
+static int decode_step_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream, bool embed_first) {
   SRGPT_TRY(check_llm(w, st));
   const int dt = w->dtype, Hd = w->hidden, I = w->inter, Hq = w->heads, Hkv = w->kv_heads, D = w->head_dim;
   const int B = st->batch, QW = (Hq + 2 * Hkv) * D;
@@ -382,7 +404,7 @@ extern "C" int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state
   hipStream_t s = as_stream(stream);
   const LlmWs d = carve_llm(w, B, st->ws_tokens, st->ws);  // same carve as prefill (sized by ws_tokens)
   const size_t layer_kv = (size_t)B * Hkv * st->max_pos * D * es;
-  SRGPT_TRY(srgpt_embed_rows(w->embed, st->tok, d.xd, B, Hd, dt, stream));
+  if (embed_first) SRGPT_TRY(srgpt_embed_rows(w->embed, st->tok, d.xd, B, Hd, dt, stream));
   // fp8 copies present -> the decode step streams them (W8A16, half the bytes per token)
   const bool w8 = w->wqkv8 != nullptr;
   if (w8)
@@ -413,6 +435,10 @@ extern "C" int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state
   return greedy_pick(w, st, d, 1, s);
 }
 
+extern "C" int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream) {
+  return decode_step_impl(w, st, stream, true);
+}
+
 // ================================================================================================
 // hipGraph of one decode step
 // ================================================================================================
@@ -427,7 +453,8 @@ extern "C" int srgpt_llm_decode_graph_create(const srgpt_llm_weights* w, srgpt_l
     srgpt_set_error("hipStreamBeginCapture failed");
     return SRGPT_ERR_STATE;
   }
-  const int rc = srgpt_llm_decode_step(w, st, stream);
+  // replays continue from the token the previous step (or srgpt_llm_sample_first) picked: its embedding is already in place
+  const int rc = decode_step_impl(w, st, stream, !advance_embeds(w, st));
   const hipError_t ee = hipStreamEndCapture(s, &graph);
   if (rc != SRGPT_OK) {
     if (graph) (void)hipGraphDestroy(graph);
