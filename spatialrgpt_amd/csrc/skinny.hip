@@ -36,6 +36,14 @@ int srgpt_gemv_w8_valu(const void* x, const void* W8, const float* wscale, const
 
 namespace {
 
+#ifdef SRGPT_TUNING_KNOBS
+// phase stamps of block 0 / wave 0 of the last skinny launch (tuning build only; scripts/ubench_skinny_stamps.py)
+__device__ unsigned long long srgpt_skinny_stamps[16];
+#define SK_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) srgpt_skinny_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SK_STAMP(i) do { } while (0)
+#endif
+
 constexpr int WROWB = 512 + 32;        // bytes per staged weight row: 136 dwords = 8 mod 64 banks -> the lane groups of ds_read_b128
                                        // (MI355X guide, LDS table) hit distinct banks; 528 measured 30 % conflict cycles
 constexpr int WSTAGEB = 16 * WROWB;    // weight stage per wave
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   };
 
   const int cnt = wave < nsl ? (nsl - wave + NW - 1) / NW : 0;  // slices of this wave
+  SK_STAMP(0);
   load_x(wave);
 
   constexpr int DEPTH = SRGPT_SKINNY_DEPTH;
@@ -262,6 +271,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
 #pragma unroll
     for (int f = 1; f < DEPTH - 1; ++f)
       issue_w(wb[f % DEPTH], pass, wave + NW * (f / NSU), f % NSU, f / NSU < cnt);
+    if (pass == 0) SK_STAMP(1);
     // one slice (h-th of the trip that starts at slice index i): NSU stages
     auto slice = [&](int i, auto h_c) {
       constexpr int h = decltype(h_c)::value;
@@ -312,6 +322,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     int i = 0;
     for (; i + DEPTH <= cnt; i += DEPTH) {
       slice(i, std::integral_constant<int, 0>{});
+      if (pass == 0 && i == 0) SK_STAMP(2);
       if constexpr (DEPTH > 1) slice(i, std::integral_constant<int, 1>{});
       if constexpr (DEPTH > 2) slice(i, std::integral_constant<int, 2>{});
       if constexpr (DEPTH > 3) slice(i, std::integral_constant<int, 3>{});
@@ -323,8 +334,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
       if (i + 2 < cnt) slice(i, std::integral_constant<int, 2>{});
     static_assert(DEPTH >= 2 && DEPTH <= 4, "ring depth");
 
+    if (pass == 0) SK_STAMP(3);
     // ---- cross-wave reduction (fixed order) + epilogue ----
     __syncthreads();
+    if (pass == 0) SK_STAMP(4);
     float* redf = reinterpret_cast<float*>(smem);  // [NW waves][MAXSU][64 lanes][4]
 #pragma unroll
     for (int su = 0; su < NSU; ++su) *reinterpret_cast<f32x4*>(redf + ((wave * MAXSU + su) * 64 + lane) * 4) = TWO_ACC ? acc[su] + acc2[TWO_ACC ? su : 0] : acc[su];
@@ -359,6 +372,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
         }
       }
     }
+    if (pass == 0) SK_STAMP(5);
     __syncthreads();  // the reduction buffer aliases the wave-private stages of the next pass
   };
 
@@ -427,6 +441,12 @@ int skinny_dispatch(const void* x, const void* W, const float* wscale, const voi
 }
 
 }  // namespace
+
+#ifdef SRGPT_TUNING_KNOBS
+extern "C" int srgpt_skinny_debug_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(srgpt_skinny_stamps), sizeof(unsigned long long) * (n < 16 ? n : 16));
+}
+#endif
 
 // host entry used by srgpt_gemv (gemv.hip) for batches of up to 16 rows, bf16 weights
 int srgpt_skinny_launch(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
