@@ -180,3 +180,30 @@ def test_pil_bicubic_tables_random_sizes_match_pillow():
             acc = (row[:, x0:x0 + n, :].astype(np.int64) * k[xx, :n][None, :, None]).sum(1) + (1 << 21)
             out[:, xx, :] = np.clip(acc >> 22, 0, 255)
         assert np.array_equal(out, ref), (w_in, w_out)
+
+
+def test_bench_presets_map_to_baseline_configs(monkeypatch):
+    """bench.py's presets / flags name the BASELINE.json configuration they measure (no GPU needed: argument plumbing only)."""
+    import importlib
+    import sys as _sys
+
+    bench = importlib.import_module("bench")
+    from spatialrgpt_amd.config import SrgptConfig
+
+    def wl(argv):
+        monkeypatch.setattr(_sys, "argv", ["bench.py"] + argv)
+        a = bench.parse()
+        cfg = bench.make_cfg(a.model)
+        return a, bench.workload_name(a, cfg, a.prompt_len - 1 + 196)
+
+    a, name = wl([])
+    assert a.gpus == 1 and a.batch == 1 and "BASELINE configs[1]" in name and "T=259" in name
+    a, name = wl(["--preset", "config2"])
+    assert a.batch == 4 and "configs[2]" in name
+    a, name = wl(["--preset", "config3"])
+    assert a.model == "llama2_7b" and a.regions == 16 and a.prompt_len == 512 and "configs[3]" in name and "T=707" in name
+    a, name = wl(["--preset", "config4"])
+    assert a.weights == "fp8" and a.batch == 8 and "configs[4]" in name
+    a, name = wl(["--batch", "3"])
+    assert "non-BASELINE" in name
+    assert isinstance(bench.make_cfg("vila15_8b_clip336"), SrgptConfig)
