@@ -46,8 +46,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--batch", type=int, default=1, help="equal-length requests per generate() call per GPU")
-    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
-                    help="fp8 = BASELINE configs[4]: weight-only OCP e4m3fn for the streamed LLM matrices (W8A16); NOT the headline")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8_w8a8"],
+                    help="fp8 = BASELINE configs[4]: weight-only OCP e4m3fn for the streamed LLM matrices (W8A16); fp8_w8a8 = the "
+                         "same weights, prefill on the fp8 matrix pipe with per-token e4m3 activations (opt-in); NOT the headline")
     ap.add_argument("--preset", default=None, choices=["config1", "config2", "config3", "config4"],
                     help="BASELINE.json configs[i] per-GPU shape: config1 = bs 1 (default); config2 = bs 32 over 8 GPUs = 4 requests "
                          "per GPU; config3 = llama2_7b, 16 regions, 512-id prompt; config4 = fp8 weights, bs 64 over 8 GPUs = 8 per GPU")
@@ -78,8 +79,10 @@ def workload_name(args, cfg, T):
         tag = "BASELINE configs[2] per-GPU shape (bs 32 over 8 GPUs = 4 requests per GPU)"
     elif args.model == "llama2_7b" and args.regions == 16 and args.prompt_len == 512:
         tag = "BASELINE configs[3]"
-    elif args.model == "vila15_8b" and args.weights == "fp8" and args.batch == 8:
+    elif args.model == "vila15_8b" and args.weights in ("fp8", "fp8_w8a8") and args.batch == 8:
         tag = "BASELINE configs[4] per-GPU shape (fp8 LLM weights, bs 64 over 8 GPUs = 8 requests per GPU)"
+        if args.weights == "fp8_w8a8":
+            tag += ", W8A8 prefill on the fp8 matrix pipe"
     else:
         tag = "non-BASELINE variant"
     return (f"{tag}: {geo[args.model]}, {args.regions} region masks, bs={args.batch} per GPU, prompt {args.prompt_len} ids -> "
@@ -244,7 +247,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
     model = LlavaLlamaModel(cfg, sd, device=device, dtype=dtype, rope_positions=1024, consume_state_dict=True,
-                            llm_weight_format="fp8" if args.weights == "fp8" else "native")
+                            llm_weight_format=args.weights if args.weights != "bf16" else "native")
     del sd
     model.engine.use_graph = not args.no_graph
     torch.cuda.synchronize()
@@ -302,7 +305,7 @@ def main():
         rows = args.batch
         x = torch.randn((rows, cfg.hidden), device=device).to(dtype)
         outb = torch.empty((args.batch, cfg.inter), device=device, dtype=dtype)
-        fp8 = args.weights == "fp8"
+        fp8 = args.weights != "bf16"
         wgu = eng.w.llm_q["wgu"][0] if fp8 else eng.w.llm_t["wgu"]
         wsc = eng.w.llm_q["wgu"][1] if fp8 else [None] * len(wgu)
 
@@ -377,7 +380,8 @@ def main():
             "metric": f"region-grounded output tokens/sec @ {'VILA1.5-8B' if args.model.startswith('vila15_8b') else args.model}, {args.regions} regions, greedy",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.weights == "bf16" else "bf16 activations / fp8-e4m3fn LLM weights (W8A16)", "data": "synthetic (seeded random weights of the named architecture; random images/depth/box masks/ids)",
+            "dtype": ("bf16" if args.weights == "bf16" else "bf16 activations / fp8-e4m3fn LLM weights (W8A16)" if args.weights == "fp8"
+                      else "fp8-e4m3fn LLM weights; prefill W8A8 (per-token e4m3 activations, fp8 MFMA), decode W8A16"), "data": "synthetic (seeded random weights of the named architecture; random images/depth/box masks/ids)",
             "config": {"workload": workload_name(args, cfg, args.prompt_len - 1 + 196),
                        "requests_per_step_per_gpu": args.batch, "new_tokens_per_request": G, "parallelism": f"dp{world}",
                        "decode": "hipGraph" if not args.no_graph else "eager", "build_s": round(t_build, 1),

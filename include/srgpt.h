@@ -82,6 +82,20 @@ int srgpt_gemm_w8(const void* A, const void* W8, const float* wscale, const void
                   int M, int N, int K, int lda, int ldc, int act, int out_f32, void* ws, int64_t ws_bytes,
                   srgpt_stream_t stream);
 
+/* W8A8 on the fp8 matrix pipe (v_mfma_scale_f32_16x16x128_f8f6f4) -- the opt-in prefill mode of BASELINE configs[4]; the
+ * reference has no counterpart (it offers bitsandbytes 8/4-bit loading, llava/model/builder.py:51-60).
+ * srgpt_quant_rows_e4m3: x [M, K] bf16 (row stride ldx) -> q [M, K] OCP e4m3fn bytes + scale [M] fp32, per row (token):
+ *   scale = the smallest power of two with max|x[m,:]| / scale <= 448, q = e4m3fn(x / scale) round-to-nearest-even (the rule the
+ *   weights are quantised with).  K % 8 == 0, 16-byte aligned rows.
+ * srgpt_gemm_w8a8: C[M,N] = ( (A8[M,K] @ W8[N,K]^T) * ascale[m] * wscale[n] + bias[n] ) + residual[M,N], fp32 accumulation of
+ *   exact e4m3 x e4m3 products, bias / residual / C bf16 (C fp32 if out_f32) with srgpt_gemm's rounding points (the product is
+ *   rounded to bf16 before the residual is added): the GEMM of the dequantised operands up to the order of the fp32 sum.  K % 128 == 0, K >= 256, lda % 16 == 0, 16-byte aligned operands; anything else
+ *   returns SRGPT_ERR_UNSUPPORTED (no fallback).  ws: optional fp32 split-K workspace (srgpt_gemm_ws_bytes). */
+int srgpt_quant_rows_e4m3(const void* x, void* q, float* scale, int M, int K, int ldx, srgpt_stream_t stream);
+int srgpt_gemm_w8a8(const void* A8, const float* ascale, const void* W8, const float* wscale, const void* bias,
+                    const void* residual, void* C, int M, int N, int K, int lda, int ldc, int out_f32, void* ws,
+                    int64_t ws_bytes, srgpt_stream_t stream);
+
 /* Decode-only fused GEMVs (any batch; 1-2 rows: VALU kernel, 3+ rows: MFMA kernel, 16 rows per weight pass), weights
  * streamed once from HBM:
  *   norm_w != NULL : x <- RMSNorm(x) * norm_w first (modeling_llama.py:61-75) (rounded to dtype like torch)
@@ -283,6 +297,10 @@ typedef struct {
   const float* const* wgu_scale;
   const void* const* wdown8;
   const float* const* wdown_scale;
+  /* fp8 weights only.  0: W8A16 everywhere (exact weights x bf16 activations -- the default, what the parity tests pin).
+   * 1: prefill quantises each GEMM's input per token (srgpt_quant_rows_e4m3) and multiplies on the fp8 matrix pipe
+   * (srgpt_gemm_w8a8); decode and the all-position lm_head stay W8A16.  Needs hidden, inter and heads * head_dim % 128 == 0. */
+  int fp8_act;
 } srgpt_llm_weights;
 
 typedef struct {

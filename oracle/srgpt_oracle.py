@@ -419,9 +419,12 @@ class KVCache:
 
 
 def llama_forward(w, cfg: SrgptConfig, inputs_embeds, position_ids, kv: KVCache, key_padding_mask=None,
-                  last_only=False, collect_hidden=False):
+                  last_only=False, collect_hidden=False, act_quant=None):
     """inputs_embeds [B,T,H]; key_padding_mask [B, past+T] bool (True = attend) or None.
-    Returns logits fp32 [B,T,V] (or [B,1,V] when last_only) (+ list of hidden states)."""
+    Returns logits fp32 [B,T,V] (or [B,1,V] when last_only) (+ list of hidden states).
+    act_quant: None (the reference's arithmetic) or a callable applied to the input of the seven layer projections -- the
+    restatement of the opt-in W8A8 prefill (fp8_rowwise_fake_quant below; no counterpart in the reference)."""
+    lin = F.linear if act_quant is None else (lambda t, W: F.linear(act_quant(t), W))
     B, T, Hd = inputs_embeds.shape
     nh, nkv, d = cfg.heads, cfg.kv_heads, cfg.head_dim
     past = kv.seq_len()
@@ -441,9 +444,9 @@ def llama_forward(w, cfg: SrgptConfig, inputs_embeds, position_ids, kv: KVCache,
         p = f"{LM}model.layers.{i}."
         r = x
         h = rmsnorm(x, w[p + "input_layernorm.weight"], cfg.rms_eps)
-        q = F.linear(h, w[p + "self_attn.q_proj.weight"]).view(B, T, nh, d).transpose(1, 2)
-        k = F.linear(h, w[p + "self_attn.k_proj.weight"]).view(B, T, nkv, d).transpose(1, 2)
-        v = F.linear(h, w[p + "self_attn.v_proj.weight"]).view(B, T, nkv, d).transpose(1, 2)
+        q = lin(h, w[p + "self_attn.q_proj.weight"]).view(B, T, nh, d).transpose(1, 2)
+        k = lin(h, w[p + "self_attn.k_proj.weight"]).view(B, T, nkv, d).transpose(1, 2)
+        v = lin(h, w[p + "self_attn.v_proj.weight"]).view(B, T, nkv, d).transpose(1, 2)
         q, k = apply_rope(q, k, cos, sin)
         k, v = kv.update(i, k, v)
         rep = nh // nkv
@@ -452,13 +455,13 @@ def llama_forward(w, cfg: SrgptConfig, inputs_embeds, position_ids, kv: KVCache,
         a = torch.matmul(q, kk.transpose(2, 3)) * (d ** -0.5) + mask
         a = F.softmax(a, dim=-1, dtype=torch.float32).to(q.dtype)
         o = torch.matmul(a, vv).transpose(1, 2).contiguous().reshape(B, T, nh * d)
-        o = F.linear(o, w[p + "self_attn.o_proj.weight"])
+        o = lin(o, w[p + "self_attn.o_proj.weight"])
         x = r + o
         r = x
         h = rmsnorm(x, w[p + "post_attention_layernorm.weight"], cfg.rms_eps)
-        g = F.linear(h, w[p + "mlp.gate_proj.weight"])
-        u = F.linear(h, w[p + "mlp.up_proj.weight"])
-        x = r + F.linear(F.silu(g) * u, w[p + "mlp.down_proj.weight"])  # modeling_llama.py:221
+        g = lin(h, w[p + "mlp.gate_proj.weight"])
+        u = lin(h, w[p + "mlp.up_proj.weight"])
+        x = r + lin(F.silu(g) * u, w[p + "mlp.down_proj.weight"])  # modeling_llama.py:221
         if collect_hidden:
             hiddens.append(x)
     x = rmsnorm(x, w[LM + "model.norm.weight"], cfg.rms_eps)
@@ -643,6 +646,20 @@ def synth_inputs(cfg: SrgptConfig, *, batch=1, regions=8, prompt_len=64, seed=1,
         assert len(seq) == prompt_len, (len(seq), prompt_len)
         ids[b] = torch.tensor(seq)
     return ids, images, depths, masks
+
+
+def fp8_rowwise_fake_quant(x: torch.Tensor) -> torch.Tensor:
+    """The activation side of the opt-in W8A8 prefill (BASELINE config 5 "fp8 MFMA"; no counterpart in the reference): every
+    row (token) of x is replaced by dequant(quant(row)) -- scale = the smallest power of two with max|row| / scale <= 448, codes =
+    round-to-nearest-even OCP e4m3fn -- returned in x.dtype (code * 2^k is exact in bf16).  Passed as llama_forward(act_quant=...)
+    together with fp8_dequantised_weights it restates what srgpt_quant_rows_e4m3 + srgpt_gemm_w8a8 compute: fp32 accumulation of
+    exact products, one rounding to the activation dtype per projection."""
+    xf = x.float()
+    amax = xf.abs().amax(dim=-1, keepdim=True).clamp_min(2.0 ** -100)
+    m, e = torch.frexp(amax)                       # amax = m * 2^e, m in [0.5, 1)
+    k = e - 9 + (m > 0.875).to(e.dtype)            # 448 = 0.875 * 2^9
+    q = (xf * torch.ldexp(torch.ones_like(amax), -k)).to(torch.float8_e4m3fn)
+    return (q.float() * torch.ldexp(torch.ones_like(amax), k)).to(x.dtype)
 
 
 def fp8_dequantised_weights(w: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

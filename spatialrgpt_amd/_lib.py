@@ -45,6 +45,7 @@ class LlmWeights(C.Structure):
         ("lm_head8", vp), ("lm_head_scale", vp),
         ("wqkv8", C.POINTER(vp)), ("wqkv_scale", C.POINTER(vp)), ("wo8", C.POINTER(vp)), ("wo_scale", C.POINTER(vp)),
         ("wgu8", C.POINTER(vp)), ("wgu_scale", C.POINTER(vp)), ("wdown8", C.POINTER(vp)), ("wdown_scale", C.POINTER(vp)),
+        ("fp8_act", i32),
     ]
 
 
@@ -62,6 +63,8 @@ _SIGNATURES = {
     "srgpt_gemm_ws_bytes": (i64, [i32, i32]),
     "srgpt_gemm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
     "srgpt_gemm_w8": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp]),
+    "srgpt_quant_rows_e4m3": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "srgpt_gemm_w8a8": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp]),
     "srgpt_gemv": (i32, [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "srgpt_gemv_w8": (i32, [vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "srgpt_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, i32, i32, vp]),
@@ -127,7 +130,7 @@ def load() -> C.CDLL:
             raise SrgptNativeError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.srgpt_abi_version() != 2:
+    if lib.srgpt_abi_version() != 3:
         raise SrgptNativeError("libsrgpt_hip.so ABI version mismatch; rebuild the extension")
     _lib = lib
     return lib

@@ -461,6 +461,13 @@ __global__ __launch_bounds__(256) void gemm_w8_simple(const bf16_t* __restrict__
 
 }  // namespace
 
+// the split-K slab reduction + epilogue for kernels in other files (gemm_f8.hip)
+int srgpt_splitk_reduce_bf16(const Epilogue& e, hipStream_t s) {
+  launch_splitk_reduce<bf16_t>(e, s);
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
+
 extern "C" int64_t srgpt_gemm_ws_bytes(int M, int N) { return (int64_t)8 * M * N * 4; }
 
 extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const void* residual, void* C, int M,

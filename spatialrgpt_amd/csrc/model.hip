@@ -54,6 +54,8 @@ struct LlmWs {
   size_t gws_bytes;
   float* amax_v;  // [batch, ARGMAX_BLOCKS] partial maxima
   int* amax_i;    // [batch, ARGMAX_BLOCKS] their indices
+  void* a8;       // fp8_act: the e4m3 bytes of the current GEMM input [rows, max K]
+  float* a8s;     // fp8_act: their per-row scales [rows]
   size_t total;
 };
 constexpr int ARGMAX_BLOCKS = 128;
@@ -79,6 +81,15 @@ LlmWs carve_llm(const srgpt_llm_weights* w, int batch, int max_tokens, void* ws)
   l.gws = c.take(l.gws_bytes);
   l.amax_v = reinterpret_cast<float*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
   l.amax_i = reinterpret_cast<int*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
+  l.a8 = nullptr;
+  l.a8s = nullptr;
+  if (w->fp8_act) {
+    size_t kmax = (size_t)w->hidden;
+    if ((size_t)w->inter > kmax) kmax = (size_t)w->inter;
+    if ((size_t)w->heads * w->head_dim > kmax) kmax = (size_t)w->heads * w->head_dim;
+    l.a8 = c.take(rows * kmax);
+    l.a8s = reinterpret_cast<float*>(c.take(rows * 4));
+  }
   l.total = c.off;
   return l;
 }
@@ -314,8 +325,16 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
     SRGPT_CHECK(dt == SRGPT_BF16 && w->wo8 && w->wgu8 && w->wdown8 && w->lm_head8 && w->wqkv_scale && w->wo_scale &&
                     w->wgu_scale && w->wdown_scale && w->lm_head_scale,
                 SRGPT_ERR_ARG, "srgpt_llm_prefill: fp8 weights need bf16 activations and all five matrices + scales");
+  const bool a8 = w8 && w->fp8_act != 0;  // W8A8 prefill: per-token e4m3 activations on the fp8 matrix pipe (include/srgpt.h)
+  if (a8)
+    SRGPT_CHECK(Hd % 128 == 0 && I % 128 == 0 && (Hq * D) % 128 == 0 && Hd >= 256 && I >= 256 && Hq * D >= 256,
+                SRGPT_ERR_UNSUPPORTED, "srgpt_llm_prefill: fp8_act needs hidden, inter and heads * head_dim to be multiples of 128");
   auto mm = [&](const void* a, const void* Wd, const void* W8p, const float* sc, const void* res, void* out, int N, int K,
                 int f32, void* gws, int64_t gws_bytes) -> int {
+    if (a8 && !f32) {  // the layers' four products; the all-position lm_head (fp32 logits, parity hook) stays W8A16
+      SRGPT_TRY(srgpt_quant_rows_e4m3(a, l.a8, l.a8s, rows, K, K, stream));
+      return srgpt_gemm_w8a8(l.a8, l.a8s, W8p, sc, nullptr, res, out, rows, N, K, K, N, 0, gws, gws_bytes, stream);
+    }
     if (w8) return srgpt_gemm_w8(a, W8p, sc, nullptr, res, out, rows, N, K, K, N, SRGPT_ACT_NONE, f32, gws, gws_bytes, stream);
     return srgpt_gemm(a, Wd, nullptr, res, out, rows, N, K, K, N, SRGPT_ACT_NONE, 0, 0, f32, SRGPT_OUT_PLAIN, 0, gws, gws_bytes, dt,
                       stream);

@@ -139,6 +139,40 @@ def gemm_w8(a, w8, wscale, bias=None, residual=None, act=L.ACT_NONE, out=None, o
     return out
 
 
+def quant_rows_e4m3(x):
+    """per-row (per-token) fp8 quantisation of activations: x [M,K] bf16 (row stride may exceed K) -> (codes uint8 [M,K],
+    scale fp32 [M]); the power-of-two rule of quantize_fp8_rows, on the device (srgpt_quant_rows_e4m3)."""
+    _dev(x)
+    if x.dtype != torch.bfloat16 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("quant_rows_e4m3: x must be a bf16 matrix with contiguous rows")
+    M, K = x.shape
+    q = torch.empty((M, K), device=x.device, dtype=torch.uint8)
+    sc = torch.empty((M,), device=x.device, dtype=torch.float32)
+    L.check(L.load().srgpt_quant_rows_e4m3(_p(x), _p(q), _p(sc), M, K, x.stride(0), _stream()))
+    return q, sc
+
+
+def gemm_w8a8(a8, ascale, w8, wscale, bias=None, residual=None, out=None, out_f32=False):
+    """((fp8(a8) @ fp8(w8).T) * ascale[:,None] * wscale[None,:] + bias) + residual on the fp8 matrix pipe: a8 uint8 [M,K],
+    w8 uint8 [N,K] (OCP e4m3fn), ascale fp32 [M], wscale fp32 [N]; bias / residual / out bf16 (out fp32 if out_f32)."""
+    _dev(a8, ascale, w8, wscale, bias, residual)
+    if a8.dtype != torch.uint8 or w8.dtype != torch.uint8 or ascale.dtype != torch.float32 or wscale.dtype != torch.float32:
+        raise ValueError("gemm_w8a8: a8 / w8 must be uint8, ascale / wscale fp32")
+    for name, t in (("bias", bias), ("residual", residual)):
+        if t is not None and t.dtype != torch.bfloat16:
+            raise ValueError(f"gemm_w8a8: {name} must be bf16")
+    M, K = a8.shape
+    N = w8.shape[0]
+    assert w8.shape[1] == K and a8.stride(1) == 1 and w8.is_contiguous() and ascale.numel() == M and wscale.numel() == N
+    if out is None:
+        out = torch.empty((M, N), device=a8.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    ws = _splitk_ws(a8.device, M, N) if M * N <= (1 << 24) else None
+    L.check(L.load().srgpt_gemm_w8a8(_p(a8), _p(ascale), _p(w8), _p(wscale), _p(bias), _p(residual), _p(out), M, N, K,
+                                     a8.stride(0), out.stride(0), int(out_f32), _p(ws), 0 if ws is None else ws.numel(),
+                                     _stream()))
+    return out
+
+
 def layernorm(x, w, b, eps, act=L.ACT_NONE, out=None):
     _dev(x, w, b)
     _same_dtype("layernorm", x, weight=w, bias=b, out=out)

@@ -52,8 +52,15 @@ class PreparedWeights:
         fp8 bytes are the ONLY copy of those matrices in HBM: decode streams them (srgpt_gemv_w8), prefill multiplies them
         (srgpt_gemm_w8); `dequantised(name, layer)` rebuilds the bf16 values for checks."""
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
-        if llm_weight_format not in ("native", "fp8"):
+        if llm_weight_format not in ("native", "fp8", "fp8_w8a8"):
             raise ValueError(f"unknown llm_weight_format {llm_weight_format!r}")
+        # "fp8_w8a8": the same fp8 weights; prefill additionally quantises every GEMM input per token to e4m3 and multiplies on
+        # the fp8 matrix pipe (srgpt_gemm_w8a8) -- opt-in, it changes the numbers (DESIGN.md section 4); decode stays W8A16
+        self.fp8_act = llm_weight_format == "fp8_w8a8"
+        if self.fp8_act:
+            llm_weight_format = "fp8"
+            if cfg.hidden % 128 or cfg.inter % 128 or (cfg.heads * cfg.head_dim) % 128:
+                raise ValueError("fp8_w8a8 needs hidden, inter and heads * head_dim to be multiples of 128")
         if llm_weight_format == "fp8" and dtype != torch.bfloat16:
             raise ValueError("fp8 LLM weights need a bf16 engine")
         self.llm_weight_format = llm_weight_format
@@ -187,6 +194,7 @@ class PreparedWeights:
                 self._keep += [a8, asc]
                 setattr(lw, k + "8", a8)
                 setattr(lw, k + "_scale", asc)
+        lw.fp8_act = 1 if self.fp8_act else 0
         self.llm = lw
         self.vocab = self.embed.shape[0]
 
