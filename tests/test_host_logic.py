@@ -207,3 +207,40 @@ def test_bench_presets_map_to_baseline_configs(monkeypatch):
     a, name = wl(["--batch", "3"])
     assert "non-BASELINE" in name
     assert isinstance(bench.make_cfg("vila15_8b_clip336"), SrgptConfig)
+
+
+def test_fp8_quantisation_rules_agree_between_host_and_oracle():
+    """The power-of-two row scale + round-to-nearest-even e4m3fn rule exists three times: spatialrgpt_amd.ops.quantize_fp8_rows
+    (weights at load, the reference for the device quantiser srgpt_quant_rows_e4m3 in the GPU suite), the oracle's
+    fp8_dequantised_weights (log2 / ceil formulation) and its fp8_rowwise_fake_quant (the W8A8 restatement).  They must give the
+    same dequantised values on rows that sit exactly on a scale boundary (max = 448 * 2^k), one ulp either side, zeros, and
+    random rows; the default llama_forward (act_quant=None) stays the reference's arithmetic."""
+    import inspect
+    from oracle import srgpt_oracle as so
+    from spatialrgpt_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((40, 256), generator=g) * torch.exp2(torch.randint(-8, 8, (40, 1), generator=g).float())
+    x[0] = 0
+    x[1, 3] = 448.0 * 2.0 ** -5       # exactly on the boundary: codes reach 448
+    x[2, 3] = 452.0 * 2.0 ** 3        # the next bf16 value above a boundary: the scale doubles
+    x[3, 3] = 446.0 * 2.0 ** 3
+    x[1:4] = x[1:4].clamp(-1e9, 1e9)
+    x[1, :3] = 0.01
+    xb = x.to(torch.bfloat16)
+    for r, peak in ((1, 448.0 * 2.0 ** -5), (2, 452.0 * 2.0 ** 3), (3, 446.0 * 2.0 ** 3)):
+        xb[r] = (xb[r].float().clamp(-peak, peak)).to(torch.bfloat16)
+    q8, sc, deq = ops.quantize_fp8_rows(xb)
+    assert float(q8.view(torch.float8_e4m3fn).float().abs().max()) <= 448.0
+    assert torch.equal(torch.log2(sc), torch.log2(sc).round()), "scales are powers of two"
+    amax = xb.float().abs().amax(dim=1)
+    nz = amax > 0
+    assert bool(((amax / sc)[nz] <= 448.0).all()) and bool(((amax / sc)[nz] > 224.0).all()), "the smallest admissible power of two"
+    fake = so.fp8_rowwise_fake_quant(xb)
+    assert torch.equal(fake, deq), "oracle activation fake-quant == host quantise / dequantise"
+    wq = so.fp8_dequantised_weights({"llm.model.layers.0.mlp.down_proj.weight": xb})["llm.model.layers.0.mlp.down_proj.weight"]
+    assert torch.equal(wq, deq), "oracle weight rule (log2 / ceil form) == host rule (frexp form)"
+    # a 3-d activation tensor quantises per token (last dimension)
+    x3 = xb.view(5, 8, 256)
+    assert torch.equal(so.fp8_rowwise_fake_quant(x3).view(40, 256), deq)
+    assert inspect.signature(so.llama_forward).parameters["act_quant"].default is None
