@@ -58,6 +58,18 @@ def quick():
         print(f"{name:11s} M={M:5d} N={N:6d} K={K:6d}  W8A8 {t8:8.1f} us {2.0 * M * N * K / t8 / 1e6:7.1f} TF/s", flush=True)
 
 
+if "--pmc" in sys.argv:  # under rocprofv3 --pmc: a few plain launches of both kernels at the 8-request shapes and 8192^3
+    for name, M, N, K in cases[:4] + cases[-1:]:
+        w8 = torch.randint(0, 120, (N, K), device=dev, dtype=torch.uint8)
+        wsc = torch.full((N,), 2.0 ** -9, device=dev)
+        a = torch.randn((M, K), device=dev, dtype=torch.bfloat16)
+        a8, asc = ops.quant_rows_e4m3(a)
+        for _ in range(3):
+            ops.gemm_w8a8(a8, asc, w8, wsc)
+            ops.gemm_w8(a, w8, wsc)
+    torch.cuda.synchronize()
+    sys.exit(0)
+
 if "--quick" in sys.argv:
     quick()
     sys.exit(0)
