@@ -56,6 +56,8 @@ class LlmState(C.Structure):
     ]
 
 
+ABI_VERSION = 4  # include/srgpt.h; bumped with every export / layout change
+
 _SIGNATURES = {
     "srgpt_last_error": (C.c_char_p, []),
     "srgpt_abi_version": (i32, []),
@@ -95,6 +97,7 @@ _SIGNATURES = {
     "srgpt_llm_prefill_ragged": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp, i32, vp, vp, vp, vp]),
     "srgpt_llm_decode_step": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp]),
     "srgpt_llm_sample_first": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp]),
+    "srgpt_llm_decode_sync_state": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp]),
     "srgpt_llm_decode_graph_create": (i32, [C.POINTER(LlmWeights), C.POINTER(LlmState), vp, C.POINTER(vp)]),
     "srgpt_graph_launch": (i32, [vp, i32, vp]),
     "srgpt_graph_destroy": (i32, [vp]),
@@ -130,7 +133,7 @@ def load() -> C.CDLL:
             raise SrgptNativeError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.srgpt_abi_version() != 3:
+    if lib.srgpt_abi_version() != ABI_VERSION:
         raise SrgptNativeError("libsrgpt_hip.so ABI version mismatch; rebuild the extension")
     _lib = lib
     return lib

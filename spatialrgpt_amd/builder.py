@@ -21,6 +21,7 @@ import torch
 
 from .config import SrgptConfig
 from .constants import DEFAULT_DEPTH_TOKEN, DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_PATCH_TOKEN, DEFAULT_MASK_TOKEN
+from .generation import generation_config_from_files
 from .mm_utils import SrgptImageProcessor
 
 
@@ -64,7 +65,10 @@ def config_from_checkpoint(model_path: str) -> SrgptConfig:
         raise ValueError(f"Unknown projector type: {top['mm_projector_cfg']}")
     rs = lc.get("rope_scaling") or {}
     factor = float(rs.get("factor", 1.0)) if rs.get("type", rs.get("rope_type")) == "linear" else 1.0
-    eos = lc.get("eos_token_id")
+    # HF `from_pretrained` gives the LLM `<ckpt>/llm/generation_config.json` as its generation config when the file exists (else the
+    # generation fields of llm/config.json); `llm.generate` (llava_llama.py:212) stops on ITS eos ids -- a list for Llama-3
+    gp = os.path.join(model_path, "llm", "generation_config.json")
+    gen = generation_config_from_files(lc, _read_json(gp) if os.path.exists(gp) else None)
     return SrgptConfig(
         vit_hidden=vc["hidden_size"], vit_inter=vc["intermediate_size"], vit_layers=vc["num_hidden_layers"],
         vit_heads=vc["num_attention_heads"], image_size=vc["image_size"], patch_size=vc["patch_size"],
@@ -77,7 +81,7 @@ def config_from_checkpoint(model_path: str) -> SrgptConfig:
         enable_region=bool(top.get("enable_region", False)), enable_depth=bool(top.get("enable_depth", False)),
         tokenizer_model_max_length=lc.get("tokenizer_model_max_length"),
         padding_side=lc.get("tokenizer_padding_side", "right"),
-        eos_token_id=eos[0] if isinstance(eos, list) else eos, pad_token_id=lc.get("pad_token_id"),
+        eos_token_id=gen.get("eos_token_id"), pad_token_id=gen.get("pad_token_id"), generation_config=gen,
         image_aspect_ratio=top.get("image_aspect_ratio", "resize") or "resize",
         mm_use_im_start_end=bool(top.get("mm_use_im_start_end", False)),
         mm_use_im_patch_token=bool(top.get("mm_use_im_patch_token", True)),
@@ -124,14 +128,18 @@ def read_checkpoint(model_path: str, vision_resolution: int = -1, interpolate_mo
     return cfg, sd
 
 
-def load_tokenizer(model_path: str, cfg: SrgptConfig, sd=None):
-    """Tokenizer side effects of the loader (llava/model/builder.py:186-199): add <mask>/<depth> (and the optional
+def load_tokenizer(model_path: str, cfg: SrgptConfig, sd=None, model_max_length=None):
+    """The tokenizer as `build_llm_and_tokenizer` loads it (language_model/builder.py:84-91: `model_max_length=
+    llm_cfg.model_max_length, padding_side="right", use_fast=False, legacy=False`; `llm_cfg.model_max_length` is the loader's
+    `model_max_length` argument -- None on the eval / demo path, which OVERRIDES the value stored in tokenizer_config.json),
+    then the tokenizer side effects of the loader (llava/model/builder.py:186-199): add <mask>/<depth> (and the optional
     <im_patch>/<im_start>/<im_end>) as special tokens, record their ids, grow the embedding / lm_head tables to
     len(tokenizer) (new rows = mean of the old ones, what `resize_token_embeddings` initialises them to)."""
     from transformers import AutoTokenizer
 
     try:
-        tokenizer = AutoTokenizer.from_pretrained(os.path.join(model_path, "llm"), use_fast=False, legacy=False)
+        tokenizer = AutoTokenizer.from_pretrained(os.path.join(model_path, "llm"), model_max_length=model_max_length,
+                                                  padding_side="right", use_fast=False, legacy=False)
     except Exception as e:  # tokenizer problems must not hide the model; callers that need it fail on use
         import warnings
 
@@ -153,10 +161,8 @@ def load_tokenizer(model_path: str, cfg: SrgptConfig, sd=None):
             head = sd["llm.lm_head.weight"]
             sd["llm.lm_head.weight"] = torch.cat([head, head.float().mean(0, keepdim=True).to(head.dtype).expand(extra, -1)], 0)
         cfg.vocab = sd["llm.model.embed_tokens.weight"].shape[0]
-    if cfg.eos_token_id is None:
-        cfg.eos_token_id = tokenizer.eos_token_id
-    if cfg.pad_token_id is None:
-        cfg.pad_token_id = tokenizer.pad_token_id
+    # NOTE: the tokenizer's eos / pad ids are NOT copied into the generation defaults: HF generate() never consults the
+    # tokenizer (a checkpoint whose configs name no EOS id generates to max_new_tokens in the reference too)
     return tokenizer
 
 

@@ -3,7 +3,7 @@ SiglipVisionConfig and LlamaConfig: llava/model/configuration_llava.py:4-59 + th
 from __future__ import annotations
 
 from dataclasses import asdict, dataclass
-from typing import Optional
+from typing import List, Optional, Union
 
 
 @dataclass
@@ -37,8 +37,9 @@ class SrgptConfig:
     enable_depth: bool = True
     tokenizer_model_max_length: Optional[int] = None
     padding_side: str = "right"
-    eos_token_id: Optional[int] = None
+    eos_token_id: Optional[Union[int, List[int]]] = None  # an int or a LIST (Llama-3 generation_config.json: [128001, 128009])
     pad_token_id: Optional[int] = None
+    generation_config: Optional[dict] = None  # <ckpt>/llm/generation_config.json (or the generation fields of llm/config.json)
     image_aspect_ratio: str = "resize"
     mm_use_im_start_end: bool = False
     mm_use_im_patch_token: bool = False

@@ -434,24 +434,26 @@ class SrgptEngine:
         with torch.cuda.stream(self.stream):
             n_keep, eos = self._decode_loop(st, max_new_tokens, eos_token_id, stopping_criteria, check_every)
         cur.wait_stream(self.stream)
+        # the decode step hands data between workgroups inside a launch (arrival tickets, the fused attention / o_proj hand-off):
+        # a bounded wait that ever expired produced garbage instead of a hang -- fail loudly, never return such ids
+        L.check(L.load().srgpt_llm_decode_sync_state(C.byref(self.w.llm), C.byref(st.c), ops._stream()))
         out = st.out_ids[:, :n_keep].clone()
         if eos:
             # rows that finished early are padded with pad_token_id (HF behaviour)
-            pad = pad_token_id if pad_token_id is not None else next(iter(eos))
-            ids = out.to("cpu")
-            for b in range(st.batch):
-                hit = [i for i in range(n_keep) if int(ids[b, i]) in eos]
-                if hit and hit[0] + 1 < n_keep:
-                    out[b, hit[0] + 1:] = pad
+            pad = pad_token_id if pad_token_id is not None else eos[0]  # HF: pad defaults to the FIRST eos id
+            is_eos = (out[:, :, None] == torch.tensor(eos, device=out.device, dtype=out.dtype)[None, None, :]).any(-1)
+            after = (is_eos.int().cumsum(dim=1) - is_eos.int()) > 0  # strictly after a row's first EOS
+            out = torch.where(after, torch.full_like(out, pad), out)
         return out
 
     def _decode_loop(self, st: DecodeState, max_new_tokens: int, eos_token_id, stopping_criteria, check_every: int):
         lib = L.load()
         stream = ops._stream()
         L.check(lib.srgpt_llm_sample_first(C.byref(self.w.llm), C.byref(st.c), stream))
-        eos = None
+        eos = None  # ordered list of EOS ids (HF accepts an int or a list; Llama-3 checkpoints list two)
         if eos_token_id is not None:
-            eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else {int(eos_token_id)}
+            eos = [int(e) for e in eos_token_id] if isinstance(eos_token_id, (list, tuple, set)) else [int(eos_token_id)]
+            eos = eos or None
         interactive = stopping_criteria is not None and len(stopping_criteria) > 0
         chunk = 1 if interactive else (check_every if eos else max_new_tokens)
         done_step = 1

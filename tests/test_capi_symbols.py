@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/srgpt.h but not exported"
     assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.srgpt_abi_version() == 3
+    assert lib.srgpt_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_struct_layouts_match_header():
@@ -74,7 +74,7 @@ def test_argument_validation_without_gpu():
     assert rc == _lib.ERR_ARG and b"swiglu" in lib.srgpt_last_error()
     rc = lib.srgpt_gemv_w8(16, 16, None, None, 0.0, None, 16, 1, 8, 8, 0, 0, None)  # missing row scales
     assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
-    assert lib.srgpt_decode_attn_ws_floats(1, 32, 128) == 32 * 64 * 130 + 32  # split partials + arrival tickets
+    assert lib.srgpt_decode_attn_ws_floats(1, 32, 128) == 32 * 64 * 130 + 32 + 8  # split partials + arrival tickets + sync words
     rc = lib.srgpt_gemm_w8(16, 16, None, None, None, 16, 4, 4, 64, 64, 4, 0, 0, None, 0, None)  # missing row scales
     assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
     rc = lib.srgpt_gemm_w8(16, 16, 16, None, None, 16, 4, 4, 72, 64, 4, 0, 0, None, 0, None)  # lda < K

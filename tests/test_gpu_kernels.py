@@ -467,3 +467,54 @@ def test_cross_entropy_vs_torch(rows, V):
     assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
     loss0, n0 = ops.cross_entropy(logits.to(DEV), torch.full((rows,), -100, dtype=torch.int64, device=DEV))
     assert int(n0) == 0 and bool(torch.isnan(loss0))  # torch: mean over zero targets is nan
+
+
+@pytest.mark.parametrize("geom", ["gqa_4096", "mha_4096", "mha_2560"])
+def test_fused_attention_oproj_decode_step_equals_per_op_composition(geom):
+    """Round 3: at batch 1 (bf16) the decode attention launch carries o_proj (weights pulled into registers while the attention
+    chain runs, agent-scope hand-off of the attention vector, residual added in place).  The fused step must be BIT-identical to
+    the same layer composed from the public per-op entries (srgpt_gemv + srgpt_decode_attention + srgpt_gemv ...), step after
+    step (the sync words re-arm themselves), across a cache-granule boundary, and its bounded spin must never have expired."""
+    import ctypes as C
+
+    from spatialrgpt_amd import _lib as L
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.engine import SrgptEngine
+    from spatialrgpt_amd.weights import synth_state_dict
+
+    kw = dict(vit_hidden=64, vit_inter=176, vit_layers=2, vit_heads=4, image_size=42, patch_size=14, layers=3, vocab=4098,
+              mask_token_id=4096, depth_token_id=4097)
+    if geom == "gqa_4096":
+        kw.update(hidden=4096, inter=14336, heads=32, kv_heads=8)
+    elif geom == "mha_4096":
+        kw.update(hidden=4096, inter=11008, heads=32, kv_heads=32, rope_theta=10000.0)
+    else:
+        kw.update(hidden=2560, inter=6912, heads=20, kv_heads=20, rope_theta=10000.0)
+    cfg = SrgptConfig(**kw)
+    dt = torch.bfloat16
+    eng = SrgptEngine(cfg, synth_state_dict(cfg, seed=5, dtype=dt, device=DEV), device=DEV, dtype=dt, rope_positions=512)
+    w = eng.w
+    T0, G = 120, 14  # contexts 120 .. 133: crosses the 128-row cache granule
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = (torch.randn((1, T0, cfg.hidden), device=DEV, generator=g) * 0.5).to(dt)
+    st, _, _ = eng.prefill(x, max_new=G + 2)
+    Hq, Hkv, D, Hd = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.hidden
+    toks = torch.randint(3, 4096, (G,), device=DEV, generator=g)
+    # the per-op composition keeps its own copy of the cache (the engine's step appends to st's)
+    kc, vc = st.kcache.clone(), st.vcache.clone()
+    for t in range(G):
+        tok = toks[t:t + 1].reshape(1, 1)
+        got = eng.step(st, tok)  # fused launch inside srgpt_llm_decode_step
+        h = ops.embed_rows(w.embed, tok.reshape(-1))
+        pos = torch.tensor([T0 + t], device=DEV, dtype=torch.int32)
+        for i in range(cfg.layers):
+            qkv = ops.gemv(h, w.llm_t["wqkv"][i], norm_w=w.llm_t["attn_norm"][i], eps=cfg.rms_eps)
+            a = ops.decode_attention(qkv, kc[i], vc[i], pos, w.rope_cos, w.rope_sin, Hq, Hkv, D)
+            h = ops.gemv(a, w.llm_t["wo"][i], residual=h)
+            act = ops.gemv(h, w.llm_t["wgu"][i], norm_w=w.llm_t["mlp_norm"][i], eps=cfg.rms_eps, swiglu=True)
+            h = ops.gemv(act, w.llm_t["wdown"][i], residual=h)
+        ref = ops.gemv(h, w.lm_head, norm_w=w.final_norm, eps=cfg.rms_eps, out_f32=True)
+        assert torch.equal(got, ref), f"{geom}: step {t} (context {T0 + t}): max diff {float((got - ref).abs().max())}"
+    assert torch.equal(st.kcache[:, :, :, :T0 + G], kc[:, :, :, :T0 + G])
+    # sync words of the fused launch: arrivals / consumers re-armed to zero, error word never set
+    assert L.load().srgpt_llm_decode_sync_state(C.byref(w.llm), C.byref(st.c), ops._stream()) == 0, L.last_error()

@@ -177,3 +177,70 @@ class _nullcontext:
 
     def __exit__(self, *a):
         return False
+
+
+def test_generation_config_eos_list_stops_and_pads_like_hf(tmp_path):
+    """the reference generates through `self.llm.generate` (llava_llama.py:212) on an LLM whose generation config
+    came from <ckpt>/llm/generation_config.json -- a LIST of EOS ids for Llama-3 -- and eval_spatial.py:224-236 passes neither
+    eos / pad ids nor stopping criteria.  A checkpoint whose generation config lists two EOS ids must stop a row on EITHER,
+    pad the finished row with pad_token_id (default: the FIRST eos id), cut the output at the step where the last row finished,
+    and the sampling path must honour the same ids."""
+    from spatialrgpt_amd import load_pretrained_model
+
+    root, cfgd, dtype, w, inp, ref = _ckpt(tmp_path)
+    tokenizer, model, _, _ = load_pretrained_model(root, "SpatialRGPT-tiny")
+    assert model.config.eos_token_id == 2  # from llm/config.json (no generation_config.json yet)
+    ids0 = _remap_ids(inp["input_ids"], cfgd, model)
+    ids1 = ids0.clone()
+    ids1[0, 1] = 3 + (int(ids1[0, 1]) + 11) % 50  # a second, different request
+    input_ids = torch.cat([ids0, ids1], 0).cuda()
+    images = inp["images"].cuda().bfloat16().repeat(2, 1, 1, 1)
+    depths = inp["depths"].cuda().bfloat16().repeat(2, 1, 1, 1)
+    masks = [inp["masks"][0].cuda().bfloat16(), inp["masks"][0].cuda().bfloat16()]
+    kw = dict(images=images, depths=depths, masks=masks)
+    G = 24
+    free = model.generate(input_ids, do_sample=False, max_new_tokens=G, eos_token_id=None, **kw).cpu()
+    assert free.shape == (2, G)
+
+    def first_new(row, start):  # first step >= start whose id did not occur earlier in the row
+        for j in range(start, G):
+            if int(free[row, j]) not in free[row, :j].tolist():
+                return j
+        pytest.skip("degenerate free-running ids on this fixture")
+
+    j0, j1 = first_new(0, 2), first_new(1, 9)
+    eos = [int(free[1, j1]), int(free[0, j0])]  # row 1's stopper listed FIRST: the default pad id must be eos[0]
+
+    def expect(ids, eos_ids, pad, max_new):
+        stops = []
+        for b in range(ids.shape[0]):
+            hit = [j for j in range(max_new) if int(ids[b, j]) in eos_ids]
+            stops.append(hit[0] + 1 if hit else max_new)
+        n = max(stops)
+        out = ids[:, :n].clone()
+        for b, s_ in enumerate(stops):
+            out[b, s_:] = pad
+        return out
+
+    json.dump({"bos_token_id": 1, "eos_token_id": eos, "do_sample": True, "temperature": 0.6, "top_p": 0.9},
+              open(os.path.join(root, "llm", "generation_config.json"), "w"))
+    del model
+    tokenizer, model, _, _ = load_pretrained_model(root, "SpatialRGPT-tiny")
+    assert model.config.eos_token_id == eos and model.generation_defaults()["top_p"] == 0.9
+    # eval_spatial.py:224-236 verbatim keywords: nothing about eos / pad / stopping criteria
+    ev = dict(do_sample=False, temperature=0, top_p=None, num_beams=1, max_new_tokens=G, use_cache=True)
+    got = model.generate(input_ids, **kw, **ev).cpu()
+    want = expect(free, eos, eos[0], G)
+    assert want.shape[1] < G, "the fixture must stop early for this test to mean anything"
+    assert torch.equal(got, want), (got, want)
+    # an explicit pad id wins; a single row stops on ITS id and is not padded
+    got = model.generate(input_ids, pad_token_id=0, **kw, **ev).cpu()
+    assert torch.equal(got, expect(free, eos, 0, G))
+    one = model.generate(input_ids[:1], images=images[:1], depths=depths[:1], masks=masks[:1], **ev).cpu()
+    assert torch.equal(one, free[:1, :j0 + 1]) or int(one[0, -1]) in eos
+    # eos_token_id=None (explicit) switches token stopping off again; an int overrides the list
+    assert torch.equal(model.generate(input_ids, eos_token_id=None, **kw, **ev).cpu(), free)
+    assert torch.equal(model.generate(input_ids, eos_token_id=eos[1], **kw, **ev).cpu(), expect(free, [eos[1]], eos[1], G))
+    # sampling path (demo, gradio_web_server_multi.py:202-213): top_k=1 makes it deterministic = greedy; same stop / pad rules
+    smp = model.generate(input_ids, do_sample=True, temperature=0.7, top_k=1, max_new_tokens=G, **kw).cpu()
+    assert torch.equal(smp, want), (smp, want)
