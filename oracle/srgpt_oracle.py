@@ -490,8 +490,10 @@ def prepare_inputs(w, cfg, input_ids, images, depths=None, masks=None, attention
 
 @torch.no_grad()
 def generate(w, cfg: SrgptConfig, input_ids, images, depths=None, masks=None, attention_mask=None,
-             max_new_tokens=16, eos_token_id=None, return_stages=False, model_dtype=None):
-    """Greedy decode; returns only the new ids [B,G].  Finished rows are padded with eos."""
+             max_new_tokens=16, eos_token_id=None, return_stages=False, model_dtype=None, prefill_act_quant=None):
+    """Greedy decode; returns only the new ids [B,G].  Finished rows are padded with eos.
+    prefill_act_quant: None (the reference's arithmetic) or the activation quantiser of the opt-in W8A8 prefill
+    (fp8_rowwise_fake_quant), applied to the PREFILL pass only -- decode steps stay W8A16, as in the engine."""
     embeds, am, pid, st = prepare_inputs(w, cfg, input_ids, images, depths, masks, attention_mask)
     if model_dtype is not None:
         embeds = embeds.to(model_dtype)  # llava_llama.py:210
@@ -501,7 +503,7 @@ def generate(w, cfg: SrgptConfig, input_ids, images, depths=None, masks=None, at
     # HF: position_ids = cumsum(mask) - 1, pads set to 1 (modeling_llama.py:1127-1133)
     pos = kpm.long().cumsum(-1) - 1
     pos = pos.masked_fill(~kpm, 1)
-    logits = llama_forward(w, cfg, embeds, pos, kv, key_padding_mask=kpm, last_only=False)
+    logits = llama_forward(w, cfg, embeds, pos, kv, key_padding_mask=kpm, last_only=False, act_quant=prefill_act_quant)
     st["prefill_logits"] = logits
     # last *valid* position per row is only well defined for left padding / no padding; HF takes [:, -1]
     nxt = logits[:, -1].argmax(-1)

@@ -290,7 +290,11 @@ struct DecodeFuse {
   int* sync;
   int expect;        // arrivals to wait for (= Hkv * B)
   int nblocks;       // o_proj blocks appended to the launch
-  SrgptPrefetch pf2; // L2 prefetch of what the NEXT launch (gate/up GEMV) reads first, issued behind the o_proj rows
+  int sleep0;        // o_proj blocks hold their weight burst back by sleep0 x 512 cycles: the attention blocks' q/k/v and cache
+                     // rows (the head of the latency chain) must not queue behind 33.5 MB of weights
+  int poll_sleep;    // s_sleep argument between polls of the arrival counter
+  int pf_when;       // gate/up L2 prefetch: 0 = behind the weight rows (before the wait), 1 = after the o_proj rows are stored
+  SrgptPrefetch pf2; // L2 prefetch of what the NEXT launch (gate/up GEMV) reads first
 };
 constexpr int FUSE_SPIN_LIMIT = 1 << 18;  // polls (~0.2 us each): far beyond any legitimate wait, short of a watchdog reset
 
@@ -314,10 +318,16 @@ __device__ __forceinline__ void fuse_prefetch_rows(const SrgptPrefetch& pf, int 
 
 template <int NIT>
 __device__ __forceinline__ void fused_oproj_block(const DecodeFuse& f, const bf16_t* __restrict__ attn, int p, int wave, int lane,
-                                                  float* flag_lds) {
+                                                  unsigned int* xlds) {
   const int nchunks = f.K >> 3;
   const int stride = f.nblocks * 4;
   const int u0 = p * 4 + wave;
+#ifdef SRGPT_TUNING_KNOBS
+  const int stamp_base = p == 0 ? 24 : -1;  // o_proj block 0 -> stamp slots 24..31
+#endif
+  DEC_STAMP(0);
+  for (int i = 0; i < f.sleep0; ++i) __builtin_amdgcn_s_sleep(8);
+  DEC_STAMP(1);
   // ---- the wave's weight rows: every load issued before anything is waited for ----
   u32x4 w[2][NIT];
 #pragma unroll
@@ -330,8 +340,12 @@ __device__ __forceinline__ void fused_oproj_block(const DecodeFuse& f, const bf1
   float res[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) res[r] = (float)f.x[min(u0 + r * stride, f.N - 1)];
-  fuse_prefetch_rows(f.pf2, p, wave, lane);
-  // ---- wait for the merged heads ----
+  if (f.pf_when == 0) fuse_prefetch_rows(f.pf2, p, wave, lane);
+  // ---- wait for the merged heads: the rows have to land first anyway, so the polling (one lane per block, every poll a
+  //      fabric request to ONE word) starts only then -- by that time the attention chain is nearly through ----
+  DEC_STAMP(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DEC_STAMP(3);
   if (threadIdx.x == 0) {
     int it = 0;
     while (__hip_atomic_load(f.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.expect) {
@@ -339,7 +353,7 @@ __device__ __forceinline__ void fused_oproj_block(const DecodeFuse& f, const bf1
         __hip_atomic_store(f.sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
-      __builtin_amdgcn_s_sleep(2);
+      if (f.poll_sleep > 4) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(2);
     }
     const int c = __hip_atomic_fetch_add(f.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (c == f.nblocks - 1) {  // every o_proj block has passed its wait: re-arm for the next launch on this stream
@@ -348,13 +362,33 @@ __device__ __forceinline__ void fused_oproj_block(const DecodeFuse& f, const bf1
     }
   }
   __syncthreads();
-  // ---- the attention vector: agent-scope loads (it was produced by other CUs inside this launch) ----
+  DEC_STAMP(4);
+  // ---- the attention vector: agent-scope loads (it was produced by other CUs inside this launch).  The block fetches it ONCE,
+  //      cooperatively (32 bytes per thread), into LDS: 2048 waves pulling the same 64 lines with L2-bypassing loads each took
+  //      3.4 us (stamps); 512 blocks x 8 KiB is a quarter of that traffic ----
+  {
+    unsigned long long* xl = reinterpret_cast<unsigned long long*>(xlds);
+    const unsigned long long* xg = reinterpret_cast<const unsigned long long*>(attn);
+    const int n8 = f.K >> 2;  // 8-byte words of the vector
+    unsigned long long t[NIT / 2 + 1];
+#pragma unroll
+    for (int i = 0; i < NIT / 2 + 1; ++i) {
+      const int wi = min((int)threadIdx.x + 256 * i, n8 - 1);
+      t[i] = __hip_atomic_load(xg + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT / 2 + 1; ++i) {
+      const int wi = (int)threadIdx.x + 256 * i;
+      if (wi < n8) xl[wi] = t[i];
+    }
+  }
+  __syncthreads();
   unsigned long long xa[NIT][2];
 #pragma unroll
   for (int j = 0; j < NIT; ++j) {
-    const unsigned long long* xp = reinterpret_cast<const unsigned long long*>(attn) + (size_t)min(j * 64 + lane, nchunks - 1) * 2;
-    xa[j][0] = __hip_atomic_load(xp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    xa[j][1] = __hip_atomic_load(xp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(xlds + (size_t)min(j * 64 + lane, nchunks - 1) * 4);
+    xa[j][0] = (unsigned long long)v[0] | ((unsigned long long)v[1] << 32);
+    xa[j][1] = (unsigned long long)v[2] | ((unsigned long long)v[3] << 32);
   }
   float acc[2] = {0.f, 0.f};
 #pragma unroll
@@ -378,6 +412,9 @@ __device__ __forceinline__ void fused_oproj_block(const DecodeFuse& f, const bf1
     const int row = u0 + r * stride;
     if (lane == 0 && row < f.N) f.x[row] = (bf16_t)(rnd<bf16_t>(res[r] + rnd<bf16_t>(a)));  // same rounding points as srgpt_gemv
   }
+  DEC_STAMP(5);
+  if (f.pf_when == 1) fuse_prefetch_rows(f.pf2, p, wave, lane);
+  DEC_STAMP(6);
 }
 
 // splits per (sequence, kv head): enough blocks for ~2 per CU, capped at 16 for a single sequence (it needs them to spread its
@@ -414,12 +451,13 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   __shared__ float knew[D], vnew[D];
   __shared__ float sc[G][DEC_CHUNK_MAX];
   __shared__ float red[4][G][D];
+  __shared__ __attribute__((aligned(16))) unsigned int xvec[FNIT > 0 ? FNIT * 256 : 4];  // fused o_proj: the attention vector
   __shared__ float stat_m[G], stat_l[G];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= n_attn) {
     if constexpr (FNIT > 0) {  // ---- o_proj block of the fused launch ----
-      fused_oproj_block<FNIT>(fuse, reinterpret_cast<const bf16_t*>(out), (int)blockIdx.x - n_attn, wave, lane, stat_l);
+      fused_oproj_block<FNIT>(fuse, reinterpret_cast<const bf16_t*>(out), (int)blockIdx.x - n_attn, wave, lane, xvec);
     } else {  // ---- prefetch block (common.h) ----
       srgpt_prefetch_block(pf, (int)blockIdx.x - n_attn, wave, lane);
     }
@@ -717,6 +755,7 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its write-through stores ...
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(fuse.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ... then one arrival
+    DEC_STAMP(3);
   }
 }
 
@@ -805,7 +844,7 @@ int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const
               "srgpt_decode_attention: null pointer");
   SRGPT_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, SRGPT_ERR_ARG, "srgpt_decode_attention: bad heads");
   if (fused) *fused = 0;
-  DecodeFuse fuse{nullptr, nullptr, 0, 0, nullptr, 0, 0, SrgptPrefetch{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0}};
+  DecodeFuse fuse{nullptr, nullptr, 0, 0, nullptr, 0, 0, 0, 0, 0, SrgptPrefetch{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0}};
   const int cus = srgpt_device_cus();
   const int fuse_on = SRGPT_KNOB("SRGPT_DECODE_FUSE_OPROJ", 1);
   const int fgrid = 2 * cus;  // o_proj blocks (256 threads, <= 2 rows per wave held in registers)
@@ -816,6 +855,9 @@ int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const
     fuse.N = wo_n;
     fuse.K = wo_k;
     fuse.nblocks = fgrid;
+    fuse.sleep0 = SRGPT_KNOB("SRGPT_FUSE_SLEEP", 5);
+    fuse.poll_sleep = SRGPT_KNOB("SRGPT_FUSE_POLL_SLEEP", 2);
+    fuse.pf_when = SRGPT_KNOB("SRGPT_FUSE_PF_WHEN", 1);
     // the L2 (4 MiB per XCD) is free now: one round of the gate/up GEMV's units = 2 rows x 8 KiB x 2048 waves = 33.5 MB
     const int gu_rounds = SRGPT_KNOB("SRGPT_DECODE_PF_GATEUP_ROUNDS", 1);
     const int gu_prefix = SRGPT_KNOB("SRGPT_DECODE_PF_GATEUP_PREFIX", 0);

@@ -478,6 +478,7 @@ def test_fused_attention_oproj_decode_step_equals_per_op_composition(geom):
     import ctypes as C
 
     from spatialrgpt_amd import _lib as L
+    from spatialrgpt_amd import ops
     from spatialrgpt_amd.config import SrgptConfig
     from spatialrgpt_amd.engine import SrgptEngine
     from spatialrgpt_amd.weights import synth_state_dict
