@@ -152,9 +152,8 @@ int srgpt_rope_kv_append(void* qkv, void* kcache, void* vcache, const int* pos0,
  * q/k and the cache append (same reference lines as above + flash-attn decode, modeling_llama.py:540-566).
  *   qkv [B, (Hq+2Hkv)*D] raw projections of the new token; pos (device int[B]) = tokens already cached.
  *   ws: fp32 workspace of srgpt_decode_attn_ws_floats(B,Hq,D) floats: per-split partials followed by one arrival ticket per
- *   (sequence, kv head) and 8 sync words (arrivals / consumers / error of the fused attention + o_proj launch of the decode
- *   step).  Tickets and sync words must be ZERO before the first launch (zero the workspace once when it is allocated); every
- *   launch leaves them zero again.  One kernel: the split that arrives last merges the partials.  out [B, Hq*D]. */
+ *   (sequence, kv head).  The tickets must be ZERO before the first launch (zero the workspace once when it is allocated);
+ *   every launch leaves them zero again.  One kernel: the split that arrives last merges the partials.  out [B, Hq*D]. */
 int64_t srgpt_decode_attn_ws_floats(int B, int Hq, int D);
 int srgpt_decode_attention(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
                            const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D,
@@ -314,9 +313,9 @@ typedef struct {
   int* step;      /* device int[1]: decode step counter */
   int max_new;
   int ws_tokens;  /* max prompt tokens per sequence the workspace was sized for */
-  void* ws;       /* workspace, srgpt_llm_ws_bytes(w, batch, ws_tokens).  It holds the decode attention's arrival tickets / sync
-                   * words, which must be zero before a decode step: every srgpt_llm_prefill* zeroes them (so a hipMalloc'ed,
-                   * never-zeroed workspace is fine as long as a prefill precedes the first step, which it must anyway) */
+  void* ws;       /* workspace, srgpt_llm_ws_bytes(w, batch, ws_tokens).  It holds the decode attention's arrival tickets, which
+                   * must be zero before a decode step: every srgpt_llm_prefill* zeroes them (so a hipMalloc'ed, never-zeroed
+                   * workspace is fine as long as a prefill precedes the first step, which it must anyway) */
   float* logits;  /* [batch, vocab] fp32 (last position) */
 } srgpt_llm_state;
 
@@ -336,8 +335,8 @@ int srgpt_llm_prefill_ragged(const srgpt_llm_weights* w, srgpt_llm_state* st, co
 /* One greedy decode step, entirely device-side: embeds st->tok, runs the layers against the cache,
  * argmax -> st->tok, st->out_ids[:, *step], ++pos, ++*step.  No host sync. */
 int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream);
-/* Health check of the decode step's in-launch hand-offs (synchronises `stream`): 0 when every arrival ticket / counter in st->ws
- * is re-armed and no bounded wait ever expired; SRGPT_ERR_STATE otherwise (srgpt_last_error says which). */
+/* Health check of the decode step's in-launch hand-off (synchronises `stream`): 0 when every arrival ticket of the decode
+ * attention in st->ws is re-armed (zero); SRGPT_ERR_STATE otherwise (srgpt_last_error says which). */
 int srgpt_llm_decode_sync_state(const srgpt_llm_weights* w, const srgpt_llm_state* st, srgpt_stream_t stream);
 /* first token after prefill: argmax(st->logits) -> tok / out_ids[:,0] / step=1 */
 int srgpt_llm_sample_first(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream);

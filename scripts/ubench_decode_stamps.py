@@ -28,9 +28,3 @@ for i in range(1, 10):
 print("merging block of (sequence 0, kv head 0):")
 print(f"  partials + statistics loaded, weights  +{v[17] - v[16]:7d}")
 print(f"  merge + store                          +{v[18] - v[17]:7d}")
-print(f"  arrival counted (fused launch)         +{v[19] - v[18]:7d}   (merging block: entry at t = {v[16] - v[0]} of block 0's clock)")
-if v[24]:
-    on = ["entry", "hold-back sleep", "rows + residual issued", "rows landed", "arrivals complete", "attention vector + FMA + store", "gate/up prefetch issued"]
-    print(f"o_proj block 0 of the fused launch (entry at t = {v[24] - v[0]} of block 0's clock, same XCD):")
-    for i in range(1, 7):
-        print(f"  {on[i]:32s} +{v[24 + i] - v[24 + i - 1]:7d}   (t = {v[24 + i] - v[0]})")

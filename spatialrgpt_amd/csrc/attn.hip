@@ -9,8 +9,6 @@
 //     keys, fused RoPE of the new q/k and cache append.  HBM/latency bound.
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "common.h"
 
 namespace {
@@ -272,151 +270,6 @@ __device__ unsigned long long srgpt_dbg_stamps[32];
 #endif
 typedef SrgptPrefetch DecodePrefetch;  // common.h: L2 prefetch blocks appended to the launch (here: o_proj's weights)
 
-// ------------------------------------------------------------------------------------------------
-// o_proj fused into the attention launch (round 3; batch 1, bf16).  The attention phase of a decode layer is a pure latency
-// chain (~10 us, HBM idle) followed by a launch boundary and a GEMV whose 33.5 MB were only warmed in L2.  Here the blocks
-// appended to the attention grid are the o_proj GEMV itself: each wave pulls its (<= 2) weight rows into REGISTERS while the
-// attention blocks work, then waits for the Hkv merged head groups (one agent-scope arrival counter), reads the attention
-// vector with agent-scope loads (the merging blocks stored it write-through: guide "handoff-flag", sc1 payload -> vmcnt(0) ->
-// counter), multiplies from registers, adds the residual and stores.  One launch and one ramp fewer per layer, and the L2 is
-// free for the head of the gate/up stream (pf2).  All blocks are co-resident (grid <= 2.5 blocks per CU of 256 threads), the
-// spin is bounded (sync[2] is set if it ever expires -- the host checks it), the counters re-arm themselves:
-//   sync[0] arrivals of merging blocks   sync[1] o_proj blocks that passed the wait (the last one zeroes both)   sync[2] error
-// ------------------------------------------------------------------------------------------------
-struct DecodeFuse {
-  const bf16_t* W;   // o_proj weights [N, K] (NULL: not fused)
-  bf16_t* x;         // residual stream [N]: read (residual) and written
-  int N, K;
-  int* sync;
-  int expect;        // arrivals to wait for (= Hkv * B)
-  int nblocks;       // o_proj blocks appended to the launch
-  int sleep0;        // o_proj blocks hold their weight burst back by sleep0 x 512 cycles: the attention blocks' q/k/v and cache
-                     // rows (the head of the latency chain) must not queue behind 33.5 MB of weights
-  int poll_sleep;    // s_sleep argument between polls of the arrival counter
-  int pf_when;       // gate/up L2 prefetch: 0 = behind the weight rows (before the wait), 1 = after the o_proj rows are stored
-  SrgptPrefetch pf2; // L2 prefetch of what the NEXT launch (gate/up GEMV) reads first
-};
-constexpr int FUSE_SPIN_LIMIT = 1 << 18;  // polls (~0.2 us each): far beyond any legitimate wait, short of a watchdog reset
-
-__device__ __forceinline__ void fuse_prefetch_rows(const SrgptPrefetch& pf, int p, int wave, int lane) {
-  // like srgpt_prefetch_block, but a row's loads are issued together (one latency per row, not one per 1-KiB piece)
-  if (!pf.base) return;
-  const int per_row = (int)((pf.prefix_bytes < pf.row_bytes ? (long long)pf.prefix_bytes : pf.row_bytes) >> 10);
-  int done = 0;
-  for (int u = p * 4 + wave; u < pf.n_units && done < pf.rounds; u += pf.gemv_grid * 4, ++done)
-    for (int r = 0; r < pf.unit_rows; ++r) {
-      const char* row = pf.base + (size_t)((long long)u * pf.umul + (long long)r * pf.rstride) * pf.row_bytes + lane * 16;
-      for (int c0 = 0; c0 < per_row; c0 += 8) {
-        u32x4 v[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = *reinterpret_cast<const u32x4*>(row + ((size_t)min(c0 + c, per_row - 1) << 10));
-#pragma unroll
-        for (int c = 0; c < 8; ++c) asm volatile("" ::"v"(v[c]));  // keep the loads; the data is dropped
-      }
-    }
-}
-
-template <int NIT>
-__device__ __forceinline__ void fused_oproj_block(const DecodeFuse& f, const bf16_t* __restrict__ attn, int p, int wave, int lane,
-                                                  unsigned int* xlds) {
-  const int nchunks = f.K >> 3;
-  const int stride = f.nblocks * 4;
-  const int u0 = p * 4 + wave;
-#ifdef SRGPT_TUNING_KNOBS
-  const int stamp_base = p == 0 ? 24 : -1;  // o_proj block 0 -> stamp slots 24..31
-#endif
-  DEC_STAMP(0);
-  for (int i = 0; i < f.sleep0; ++i) __builtin_amdgcn_s_sleep(8);
-  DEC_STAMP(1);
-  // ---- the wave's weight rows: every load issued before anything is waited for ----
-  u32x4 w[2][NIT];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int row = min(u0 + r * stride, f.N - 1);
-    const u32x4* wp = reinterpret_cast<const u32x4*>(f.W + (size_t)row * f.K);
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) w[r][j] = __builtin_nontemporal_load(wp + min(j * 64 + lane, nchunks - 1));
-  }
-  float res[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) res[r] = (float)f.x[min(u0 + r * stride, f.N - 1)];
-  if (f.pf_when == 0) fuse_prefetch_rows(f.pf2, p, wave, lane);
-  // ---- wait for the merged heads: the rows have to land first anyway, so the polling (one lane per block, every poll a
-  //      fabric request to ONE word) starts only then -- by that time the attention chain is nearly through ----
-  DEC_STAMP(2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  DEC_STAMP(3);
-  if (threadIdx.x == 0) {
-    int it = 0;
-    while (__hip_atomic_load(f.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.expect) {
-      if (++it > FUSE_SPIN_LIMIT) {
-        __hip_atomic_store(f.sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      if (f.poll_sleep > 4) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(2);
-    }
-    const int c = __hip_atomic_fetch_add(f.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (c == f.nblocks - 1) {  // every o_proj block has passed its wait: re-arm for the next launch on this stream
-      __hip_atomic_store(f.sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(f.sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __syncthreads();
-  DEC_STAMP(4);
-  // ---- the attention vector: agent-scope loads (it was produced by other CUs inside this launch).  The block fetches it ONCE,
-  //      cooperatively (32 bytes per thread), into LDS: 2048 waves pulling the same 64 lines with L2-bypassing loads each took
-  //      3.4 us (stamps); 512 blocks x 8 KiB is a quarter of that traffic ----
-  {
-    unsigned long long* xl = reinterpret_cast<unsigned long long*>(xlds);
-    const unsigned long long* xg = reinterpret_cast<const unsigned long long*>(attn);
-    const int n8 = f.K >> 2;  // 8-byte words of the vector
-    unsigned long long t[NIT / 2 + 1];
-#pragma unroll
-    for (int i = 0; i < NIT / 2 + 1; ++i) {
-      const int wi = min((int)threadIdx.x + 256 * i, n8 - 1);
-      t[i] = __hip_atomic_load(xg + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int i = 0; i < NIT / 2 + 1; ++i) {
-      const int wi = (int)threadIdx.x + 256 * i;
-      if (wi < n8) xl[wi] = t[i];
-    }
-  }
-  __syncthreads();
-  unsigned long long xa[NIT][2];
-#pragma unroll
-  for (int j = 0; j < NIT; ++j) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(xlds + (size_t)min(j * 64 + lane, nchunks - 1) * 4);
-    xa[j][0] = (unsigned long long)v[0] | ((unsigned long long)v[1] << 32);
-    xa[j][1] = (unsigned long long)v[2] | ((unsigned long long)v[3] << 32);
-  }
-  float acc[2] = {0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < NIT; ++j) {
-    const bool valid = j * 64 + lane < nchunks;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const unsigned int xq = (unsigned int)(xa[j][q >> 1] >> ((q & 1) * 32));
-      const float x0 = bf16lo(xq), x1 = bf16hi(xq);
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const unsigned int wq = valid ? w[r][j][q] : 0u;
-        acc[r] = fmaf(bf16lo(wq), x0, acc[r]);
-        acc[r] = fmaf(bf16hi(wq), x1, acc[r]);
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const float a = wave_sum(acc[r]);
-    const int row = u0 + r * stride;
-    if (lane == 0 && row < f.N) f.x[row] = (bf16_t)(rnd<bf16_t>(res[r] + rnd<bf16_t>(a)));  // same rounding points as srgpt_gemv
-  }
-  DEC_STAMP(5);
-  if (f.pf_when == 1) fuse_prefetch_rows(f.pf2, p, wave, lane);
-  DEC_STAMP(6);
-}
-
 // splits per (sequence, kv head): enough blocks for ~2 per CU, capped at 16 for a single sequence (it needs them to spread its
 // K/V rows over the chip) and at 8 from two sequences up (the batch already spreads; more splits only multiply the merge work --
 // decode step at 4 sequences 3.44 ms with 8 splits vs 3.47 with 16, at 8 sequences 3.60 / 3.66, profiles/r02_decode_splits.txt),
@@ -434,13 +287,13 @@ static inline int decode_nsplit(int max_pos, int B, int Hkv) {
   return n;
 }
 
-template <typename T, int D, int G, int FNIT>
+template <typename T, int D, int G>
 __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__ qkv, T* __restrict__ kcache,
                                                            T* __restrict__ vcache, const int* __restrict__ pos,
                                                            const T* __restrict__ cos_tab, const T* __restrict__ sin_tab,
                                                            float* __restrict__ ws, int* __restrict__ tickets,
                                                            T* __restrict__ out, int Hq, int Hkv, int max_pos,
-                                                           int nsplit, float scale, int n_attn, DecodePrefetch pf, DecodeFuse fuse) {
+                                                           int nsplit, float scale, int n_attn, DecodePrefetch pf) {
   constexpr int VEC = Vec16<T>::N;
   constexpr int LPK = D / VEC;   // lanes per key
   constexpr int KPW = 64 / LPK;  // keys per wave-instruction
@@ -451,16 +304,11 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   __shared__ float knew[D], vnew[D];
   __shared__ float sc[G][DEC_CHUNK_MAX];
   __shared__ float red[4][G][D];
-  __shared__ __attribute__((aligned(16))) unsigned int xvec[FNIT > 0 ? FNIT * 256 : 4];  // fused o_proj: the attention vector
   __shared__ float stat_m[G], stat_l[G];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((int)blockIdx.x >= n_attn) {
-    if constexpr (FNIT > 0) {  // ---- o_proj block of the fused launch ----
-      fused_oproj_block<FNIT>(fuse, reinterpret_cast<const bf16_t*>(out), (int)blockIdx.x - n_attn, wave, lane, xvec);
-    } else {  // ---- prefetch block (common.h) ----
-      srgpt_prefetch_block(pf, (int)blockIdx.x - n_attn, wave, lane);
-    }
+  if ((int)blockIdx.x >= n_attn) {  // ---- prefetch block (common.h) ----
+    srgpt_prefetch_block(pf, (int)blockIdx.x - n_attn, wave, lane);
     return;
   }
   const int hk = (int)blockIdx.x % Hkv, split = ((int)blockIdx.x / Hkv) % nsplit, b = (int)blockIdx.x / (Hkv * nsplit);
@@ -736,47 +584,23 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
         n1 = fmaf(sc[gq][sp], __uint_as_float((unsigned)(u >> 32)), n1);
       }
       T* op = out + ((size_t)b * Hq + (size_t)hk * G + gq) * D + d;
-      if constexpr (FNIT > 0) {
-        // write-through pair: the o_proj blocks of this launch read it with agent-scope loads
-        bf16x2 pr;
-        pr[0] = (bf16_t)(n0 * stat_m[gq]);
-        pr[1] = (bf16_t)(n1 * stat_m[gq]);
-        __hip_atomic_store(reinterpret_cast<unsigned int*>(op), __builtin_bit_cast(unsigned int, pr), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        op[0] = from_f<T>(n0 * stat_m[gq]);
-        op[1] = from_f<T>(n1 * stat_m[gq]);
-      }
+      op[0] = from_f<T>(n0 * stat_m[gq]);
+      op[1] = from_f<T>(n1 * stat_m[gq]);
     }
   }
   DEC_STAMP(2);
   if (tid == 0) __hip_atomic_store(tickets + (size_t)b * Hkv + hk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if constexpr (FNIT > 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its write-through stores ...
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(fuse.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ... then one arrival
-    DEC_STAMP(3);
-  }
 }
 
 template <typename T, int D>
 int launch_decode_d(int G, const void* qkv, void* kc, void* vc, const int* pos, const void* ct, const void* st,
                     float* ws, int* tickets, void* out, int B, int Hq, int Hkv, int max_pos, int nsplit, float scale,
-                    const DecodePrefetch& pf, const DecodeFuse& fuse, hipStream_t s) {
+                    const DecodePrefetch& pf, hipStream_t s) {
   const int n_attn = Hkv * nsplit * B;
-  const int fnit = (fuse.W && std::is_same<T, bf16_t>::value) ? fuse.K / 512 : 0;  // 16-byte chunks per lane and row
-  dim3 grid(n_attn + (fnit ? fuse.nblocks : (pf.base ? pf.nblocks : 0)));
-#define LDF(GG, FN)                                                                                                    \
-  hipLaunchKernelGGL((decode_split_kernel<T, D, GG, FN>), grid, dim3(256), 0, s, (const T*)qkv, (T*)kc, (T*)vc, pos, \
-                     (const T*)ct, (const T*)st, ws, tickets, (T*)out, Hq, Hkv, max_pos, nsplit, scale, n_attn, pf, fuse)
-#define LD(GG)                                                   \
-  do {                                                           \
-    if constexpr (std::is_same<T, bf16_t>::value && D == 128) {  \
-      if (fnit == 8) { LDF(GG, 8); break; }                      \
-      if (fnit == 5) { LDF(GG, 5); break; }                      \
-    }                                                            \
-    LDF(GG, 0);                                                  \
-  } while (0)
+  dim3 grid(n_attn + (pf.base ? pf.nblocks : 0));
+#define LD(GG)                                                                                                     \
+  hipLaunchKernelGGL((decode_split_kernel<T, D, GG>), grid, dim3(256), 0, s, (const T*)qkv, (T*)kc, (T*)vc, pos, \
+                     (const T*)ct, (const T*)st, ws, tickets, (T*)out, Hq, Hkv, max_pos, nsplit, scale, n_attn, pf)
   switch (G) {
     case 1: LD(1); break;
     case 2: LD(2); break;
@@ -787,13 +611,12 @@ int launch_decode_d(int G, const void* qkv, void* kc, void* vc, const int* pos, 
       return SRGPT_ERR_UNSUPPORTED;
   }
 #undef LD
-#undef LDF
   return SRGPT_OK;
 }
 
 template <typename T>
 int launch_decode(const void* qkv, void* kc, void* vc, const int* pos, const void* ct, const void* st, void* out,
-                  float* ws, int B, int Hq, int Hkv, int D, int max_pos, const DecodePrefetch& pf, DecodeFuse fuse, hipStream_t s) {
+                  float* ws, int B, int Hq, int Hkv, int D, int max_pos, const DecodePrefetch& pf, hipStream_t s) {
   const int G = Hq / Hkv;
   const int nsplit = decode_nsplit(max_pos, B, Hkv);
   // a split's scores live in LDS (sc[G][DEC_CHUNK_MAX]): the longest chunk is ceil(max_pos / nsplit) keys
@@ -801,14 +624,12 @@ int launch_decode(const void* qkv, void* kc, void* vc, const int* pos, const voi
               "srgpt_decode_attention: max_pos %d exceeds %d cached positions", max_pos, DEC_SPLIT_MAX * DEC_CHUNK_MAX);
   const float scale = 1.0f / sqrtf((float)D);
   int* tickets = reinterpret_cast<int*>(ws + (size_t)B * Hq * DEC_SPLIT_MAX * (D + 2));  // int[B * Hkv] behind the partials
-  fuse.sync = tickets + (size_t)B * Hq;  // int[8] behind the tickets (srgpt_decode_attn_ws_floats)
-  fuse.expect = Hkv * B;
   int rc;
   switch (D) {
-    case 16: rc = launch_decode_d<T, 16>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, pf, fuse, s); break;
-    case 32: rc = launch_decode_d<T, 32>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, pf, fuse, s); break;
-    case 64: rc = launch_decode_d<T, 64>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, pf, fuse, s); break;
-    case 128: rc = launch_decode_d<T, 128>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, pf, fuse, s); break;
+    case 16: rc = launch_decode_d<T, 16>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, pf, s); break;
+    case 32: rc = launch_decode_d<T, 32>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, pf, s); break;
+    case 64: rc = launch_decode_d<T, 64>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, pf, s); break;
+    case 128: rc = launch_decode_d<T, 128>(G, qkv, kc, vc, pos, ct, st, ws, tickets, out, B, Hq, Hkv, max_pos, nsplit, scale, pf, s); break;
     default:
       srgpt_set_error("srgpt_decode_attention: head_dim %d not supported (16,32,64,128)", D);
       return SRGPT_ERR_UNSUPPORTED;
@@ -827,61 +648,35 @@ extern "C" int srgpt_debug_stamps(unsigned long long* host, int n) {
 #endif
 
 extern "C" int64_t srgpt_decode_attn_ws_floats(int B, int Hq, int D) {
-  // partials + arrival tickets (<= B * Hkv ints) + the 8 sync words of the fused attention / o_proj launch
-  return (int64_t)B * Hq * DEC_SPLIT_MAX * (D + 2) + (int64_t)B * Hq + 8;
+  return (int64_t)B * Hq * DEC_SPLIT_MAX * (D + 2) + (int64_t)B * Hq;  // partials + arrival tickets (<= B * Hkv ints)
 }
 
-// internal entry (model.hip): decode attention + what rides on its launch.
-//   wo != NULL, fuse_x == NULL : L2 prefetch of o_proj's weights (the separate o_proj GEMV follows)        [round 2]
-//   wo != NULL, fuse_x != NULL : o_proj (+ residual, in place on fuse_x) fused into the launch (batch 1, bf16, K % 512 == 0,
-//                                N <= 2 rows per wave); gu_w (optional) = the gate/up matrix whose head is pulled into L2 [round 3]
-// Returns 1 in *fused when the fused form was launched (the caller then skips its o_proj GEMV).
+// internal entry (model.hip): decode attention + L2 prefetch of the weight matrix the next GEMV streams.
+// next_w = NULL -> no prefetch.  batch > 2 goes through the skinny kernel: no prefetch there (measured, common.h).
 int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
                               const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D, int max_pos, int dtype,
-                              const void* wo, int wo_n, int wo_k, int wo_fp8, void* fuse_x, const void* gu_w, int gu_n, int gu_k,
-                              int* fused, srgpt_stream_t stream) {
+                              const void* next_w, int next_n, int next_k, int next_fp8, srgpt_stream_t stream) {
   SRGPT_CHECK(qkv && kcache && vcache && pos && cos_tab && sin_tab && out && ws, SRGPT_ERR_ARG,
               "srgpt_decode_attention: null pointer");
   SRGPT_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, SRGPT_ERR_ARG, "srgpt_decode_attention: bad heads");
-  if (fused) *fused = 0;
-  DecodeFuse fuse{nullptr, nullptr, 0, 0, nullptr, 0, 0, 0, 0, 0, SrgptPrefetch{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0}};
-  const int cus = srgpt_device_cus();
-  const int fuse_on = SRGPT_KNOB("SRGPT_DECODE_FUSE_OPROJ", 1);
-  const int fgrid = 2 * cus;  // o_proj blocks (256 threads, <= 2 rows per wave held in registers)
-  if (fuse_on && fuse_x && wo && !wo_fp8 && dtype == SRGPT_BF16 && B == 1 && D == 128 && (wo_k == 4096 || wo_k == 2560) &&
-      wo_n <= fgrid * 4 * 2 && wo_k == Hq * D) {
-    fuse.W = reinterpret_cast<const bf16_t*>(wo);
-    fuse.x = reinterpret_cast<bf16_t*>(fuse_x);
-    fuse.N = wo_n;
-    fuse.K = wo_k;
-    fuse.nblocks = fgrid;
-    fuse.sleep0 = SRGPT_KNOB("SRGPT_FUSE_SLEEP", 5);
-    fuse.poll_sleep = SRGPT_KNOB("SRGPT_FUSE_POLL_SLEEP", 2);
-    fuse.pf_when = SRGPT_KNOB("SRGPT_FUSE_PF_WHEN", 1);
-    // the L2 (4 MiB per XCD) is free now: one round of the gate/up GEMV's units = 2 rows x 8 KiB x 2048 waves = 33.5 MB
-    const int gu_rounds = SRGPT_KNOB("SRGPT_DECODE_PF_GATEUP_ROUNDS", 1);
-    const int gu_prefix = SRGPT_KNOB("SRGPT_DECODE_PF_GATEUP_PREFIX", 0);
-    if (gu_w && gu_rounds > 0) fuse.pf2 = srgpt_prefetch_for_gemv(gu_w, gu_n, gu_k, 1, 0, B, gu_rounds, gu_prefix);
-    if (fused) *fused = 1;
-  }
   // 0 = off; 2 = all of o_proj (measured 3.189 / 3.169 / 3.138 ms per token at 0 / 1 / 2 rounds)
   const int pf_rounds = SRGPT_KNOB("SRGPT_DECODE_PREFETCH_ROUNDS", 2);
-  const DecodePrefetch pf = (dtype == SRGPT_BF16 && !fuse.W) ? srgpt_prefetch_for_gemv(wo, wo_n, wo_k, 0, wo_fp8, B, pf_rounds, 0)
-                                                             : srgpt_prefetch_for_gemv(nullptr, 0, 0, 0, 0, B, 0, 0);
+  const DecodePrefetch pf = dtype == SRGPT_BF16 ? srgpt_prefetch_for_gemv(next_w, next_n, next_k, 0, next_fp8, B, pf_rounds, 0)
+                                                : srgpt_prefetch_for_gemv(nullptr, 0, 0, 0, 0, B, 0, 0);
   if (dtype == SRGPT_BF16)
-    return launch_decode<bf16_t>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos, pf, fuse,
+    return launch_decode<bf16_t>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos, pf,
                                  as_stream(stream));
   if (dtype == SRGPT_F32)
-    return launch_decode<float>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos, pf, fuse,
+    return launch_decode<float>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos, pf,
                                 as_stream(stream));
   srgpt_set_error("srgpt_decode_attention: bad dtype %d", dtype);
   return SRGPT_ERR_ARG;
 }
 
-// the arrival tickets and the sync words behind the partials (internal; model.hip zeroes them in every prefill so that a state
-// whose workspace was never zeroed, or whose last launch was aborted, heals -- ADVICE r2)
+// the arrival tickets behind the partials (internal; model.hip zeroes them in every prefill so that a state whose workspace was
+// never zeroed, or whose last launch was aborted, heals -- ADVICE r2 -- and srgpt_llm_decode_sync_state reads them back)
 void* srgpt_decode_attn_sync_words(float* ws, int B, int Hq, int D, size_t* bytes) {
-  if (bytes) *bytes = ((size_t)B * Hq + 8) * sizeof(int);
+  if (bytes) *bytes = (size_t)B * Hq * sizeof(int);
   return ws + (size_t)B * Hq * DEC_SPLIT_MAX * (D + 2);
 }
 
@@ -889,7 +684,7 @@ extern "C" int srgpt_decode_attention(const void* qkv, void* kcache, void* vcach
                                       const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D,
                                       int max_pos, int dtype, srgpt_stream_t stream) {
   return srgpt_decode_attention_pf(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos, dtype, nullptr, 0,
-                                   0, 0, nullptr, nullptr, 0, 0, nullptr, stream);
+                                   0, 0, stream);
 }
 
 extern "C" int srgpt_attention(const void* q, const void* k, const void* v, void* o, int B, int Tq, int Tk, int Hq,

@@ -7,8 +7,7 @@
 
 int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
                               const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D, int max_pos, int dtype,
-                              const void* wo, int wo_n, int wo_k, int wo_fp8, void* fuse_x, const void* gu_w, int gu_n, int gu_k,
-                              int* fused, srgpt_stream_t stream);  // attn.hip
+                              const void* next_w, int next_n, int next_k, int next_fp8, srgpt_stream_t stream);  // attn.hip
 void* srgpt_decode_attn_sync_words(float* ws, int B, int Hq, int D, size_t* bytes);  // attn.hip
 
 namespace {
@@ -448,16 +447,13 @@ static int decode_step_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, srg
     char* vc = reinterpret_cast<char*>(st->vcache) + (size_t)i * layer_kv;
     SRGPT_TRY(mv(d.xd, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, w->attn_norm[i], nullptr,
                  d.qkvd, QW, Hd, 0, 0));
-    // HBM is idle while the attention chain runs: at batch 1 (bf16) the launch carries o_proj itself (weights pulled into
-    // registers meanwhile, residual added in place) and warms L2 with the head of the gate/up stream; otherwise it pulls
-    // o_proj's weights into L2 and the o_proj GEMV follows
-    int fused = 0;
+    // the attention launch also pulls o_proj's weights into L2 (HBM is idle while it runs).  Round 3 built the next step -- o_proj
+    // itself inside this launch, weights in registers, agent-scope hand-off -- bit-exact and 3 us per layer SLOWER
+    // (profiles/r03_fused_attention_oproj.txt)
     SRGPT_TRY(srgpt_decode_attention_pf(d.qkvd, kc, vc, st->pos, w->rope_cos, w->rope_sin, d.attnd, d.dws, B, Hq, Hkv, D,
-                                        st->max_pos, dt, w8 ? w->wo8[i] : w->wo[i], Hd, Hq * D, w8 ? 1 : 0, d.xd,
-                                        w8 ? nullptr : w->wgu[i], I, Hd, &fused, stream));
-    if (!fused)
-      SRGPT_TRY(mv(d.attnd, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, nullptr, d.xd, d.xd, Hd,
-                   Hq * D, 0, 0));
+                                        st->max_pos, dt, w8 ? w->wo8[i] : w->wo[i], Hd, Hq * D, w8 ? 1 : 0, stream));
+    SRGPT_TRY(mv(d.attnd, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, nullptr, d.xd, d.xd, Hd,
+                 Hq * D, 0, 0));
     SRGPT_TRY(mv(d.xd, w->wgu[i], w8 ? w->wgu8[i] : nullptr, w8 ? w->wgu_scale[i] : nullptr, w->mlp_norm[i], nullptr,
                  d.actd, I, Hd, 1, 0));
     SRGPT_TRY(mv(d.actd, w->wdown[i], w8 ? w->wdown8[i] : nullptr, w8 ? w->wdown_scale[i] : nullptr, nullptr, d.xd, d.xd,
@@ -471,9 +467,9 @@ extern "C" int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state
   return decode_step_impl(w, st, stream, true);
 }
 
-// Health of the in-launch hand-offs of the decode step (synchronises `stream`): between steps every arrival ticket and both
-// counters of the fused attention / o_proj launch are zero again, and the error word is set only if a bounded spin ever expired
-// (the step then produced garbage instead of hanging).  Cheap enough to call once per generate().
+// Health of the in-launch hand-off of the decode step (synchronises `stream`): between steps every arrival ticket of the decode
+// attention (the split that draws the last ticket merges and re-arms it) must be zero again -- a non-zero ticket means a launch
+// was aborted or merged nothing, and every later step would silently use stale attention output.  Cheap: once per generate().
 extern "C" int srgpt_llm_decode_sync_state(const srgpt_llm_weights* w, const srgpt_llm_state* st, srgpt_stream_t stream) {
   SRGPT_TRY(check_llm(w, st));
   const LlmWs d = carve_llm(w, st->batch, st->ws_tokens, st->ws);
@@ -483,9 +479,8 @@ extern "C" int srgpt_llm_decode_sync_state(const srgpt_llm_weights* w, const srg
   SRGPT_HIP_TRY(hipMemcpyAsync(host.data(), sync, bytes, hipMemcpyDeviceToHost, as_stream(stream)), "srgpt_llm_decode_sync_state: copy");
   SRGPT_HIP_TRY(hipStreamSynchronize(as_stream(stream)), "srgpt_llm_decode_sync_state: synchronize");
   const size_t n = host.size();
-  SRGPT_CHECK(host[n - 8 + 2] == 0, SRGPT_ERR_STATE, "decode step: a bounded in-launch wait expired (attention -> o_proj hand-off)");
   for (size_t i = 0; i < n; ++i)
-    SRGPT_CHECK(host[i] == 0, SRGPT_ERR_STATE, "decode step: sync word %zu of %zu is %d between steps (expected 0)", i, n, host[i]);
+    SRGPT_CHECK(host[i] == 0, SRGPT_ERR_STATE, "decode step: arrival ticket %zu of %zu is %d between steps (expected 0)", i, n, host[i]);
   return SRGPT_OK;
 }
 

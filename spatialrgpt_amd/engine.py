@@ -434,8 +434,8 @@ class SrgptEngine:
         with torch.cuda.stream(self.stream):
             n_keep, eos = self._decode_loop(st, max_new_tokens, eos_token_id, stopping_criteria, check_every)
         cur.wait_stream(self.stream)
-        # the decode step hands data between workgroups inside a launch (arrival tickets, the fused attention / o_proj hand-off):
-        # a bounded wait that ever expired produced garbage instead of a hang -- fail loudly, never return such ids
+        # the decode attention hands partials between workgroups inside a launch (arrival tickets): a ticket left non-zero means a
+        # launch merged nothing and later steps used stale attention output -- fail loudly, never return such ids
         L.check(L.load().srgpt_llm_decode_sync_state(C.byref(self.w.llm), C.byref(st.c), ops._stream()))
         out = st.out_ids[:, :n_keep].clone()
         if eos:

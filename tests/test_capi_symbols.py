@@ -74,7 +74,7 @@ def test_argument_validation_without_gpu():
     assert rc == _lib.ERR_ARG and b"swiglu" in lib.srgpt_last_error()
     rc = lib.srgpt_gemv_w8(16, 16, None, None, 0.0, None, 16, 1, 8, 8, 0, 0, None)  # missing row scales
     assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
-    assert lib.srgpt_decode_attn_ws_floats(1, 32, 128) == 32 * 64 * 130 + 32 + 8  # split partials + arrival tickets + sync words
+    assert lib.srgpt_decode_attn_ws_floats(1, 32, 128) == 32 * 64 * 130 + 32  # split partials + arrival tickets
     rc = lib.srgpt_gemm_w8(16, 16, None, None, None, 16, 4, 4, 64, 64, 4, 0, 0, None, 0, None)  # missing row scales
     assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
     rc = lib.srgpt_gemm_w8(16, 16, 16, None, None, 16, 4, 4, 72, 64, 4, 0, 0, None, 0, None)  # lda < K

@@ -470,11 +470,12 @@ def test_cross_entropy_vs_torch(rows, V):
 
 
 @pytest.mark.parametrize("geom", ["gqa_4096", "mha_4096", "mha_2560"])
-def test_fused_attention_oproj_decode_step_equals_per_op_composition(geom):
-    """Round 3: at batch 1 (bf16) the decode attention launch carries o_proj (weights pulled into registers while the attention
-    chain runs, agent-scope hand-off of the attention vector, residual added in place).  The fused step must be BIT-identical to
-    the same layer composed from the public per-op entries (srgpt_gemv + srgpt_decode_attention + srgpt_gemv ...), step after
-    step (the sync words re-arm themselves), across a cache-granule boundary, and its bounded spin must never have expired."""
+def test_decode_step_equals_per_op_composition_bit_for_bit(geom):
+    """srgpt_llm_decode_step (what the hipGraph replays: fused prologues / epilogues, L2 prefetch blocks riding on the attention
+    launch, embedding rows dropped by the advance kernel) must be BIT-identical to the same layers composed from the public
+    per-op entries (srgpt_gemv + srgpt_decode_attention + srgpt_gemv ...), step after step, across a cache-granule boundary, and
+    leave every arrival ticket re-armed (srgpt_llm_decode_sync_state).  (Round 3 used this test to prove the fused attention +
+    o_proj launch bit-exact before measuring it slower and removing it.)"""
     import ctypes as C
 
     from spatialrgpt_amd import _lib as L
@@ -505,7 +506,7 @@ def test_fused_attention_oproj_decode_step_equals_per_op_composition(geom):
     kc, vc = st.kcache.clone(), st.vcache.clone()
     for t in range(G):
         tok = toks[t:t + 1].reshape(1, 1)
-        got = eng.step(st, tok)  # fused launch inside srgpt_llm_decode_step
+        got = eng.step(st, tok)
         h = ops.embed_rows(w.embed, tok.reshape(-1))
         pos = torch.tensor([T0 + t], device=DEV, dtype=torch.int32)
         for i in range(cfg.layers):
@@ -517,5 +518,5 @@ def test_fused_attention_oproj_decode_step_equals_per_op_composition(geom):
         ref = ops.gemv(h, w.lm_head, norm_w=w.final_norm, eps=cfg.rms_eps, out_f32=True)
         assert torch.equal(got, ref), f"{geom}: step {t} (context {T0 + t}): max diff {float((got - ref).abs().max())}"
     assert torch.equal(st.kcache[:, :, :, :T0 + G], kc[:, :, :, :T0 + G])
-    # sync words of the fused launch: arrivals / consumers re-armed to zero, error word never set
+    # the arrival tickets of the decode attention are re-armed (zero) between steps
     assert L.load().srgpt_llm_decode_sync_state(C.byref(w.llm), C.byref(st.c), ops._stream()) == 0, L.last_error()
