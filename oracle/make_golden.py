@@ -402,11 +402,62 @@ def mint_posembed_kat():
     print("  wrote posembed_kat.npz")
 
 
+def mint_checkpoint():
+    """tests/golden/ckpt_tiny/: a checkpoint directory written by the REFERENCE's own writer -- `LlavaLlamaModel.save_pretrained`
+    (llava_arch.py:181-250: tokenizer + HF sub-model directories llm/ vision_tower/ mm_projector/ region_extractor/ and the
+    top-level config.json with the nested sub-configs) -- for the loader tests, plus the ids the reference's `generate()` produces
+    on it (tests/golden/ckpt_tiny_kat.npz).  The model is the tiny fp32 model of tiny_fp32.npz (same seeds, same perturbed gains)."""
+    import shutil
+
+    out = os.path.join(GOLD, "ckpt_tiny")
+    shutil.rmtree(out, ignore_errors=True)
+    with tempfile.TemporaryDirectory() as td:
+        model, tok = rh.build_tiny_reference_model(td, llm=TINY_LLM, vit=TINY_VIT, dtype="torch.float32", seed=0)
+        g = torch.Generator().manual_seed(123)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.endswith("norm.weight") or "layernorm" in n or "layer_norm" in n or n.endswith("module.1.weight") \
+                        or n == "mm_projector.layers.1.weight":
+                    if n.endswith("weight"):
+                        p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                    else:
+                        p.copy_(0.1 * torch.randn(p.shape, generator=g))
+                elif n.endswith(".bias"):
+                    p.copy_(0.05 * torch.randn(p.shape, generator=g))
+        # a Llama-3 style generation config next to the weights: HF reads it back into `llm.generation_config`
+        model.llm.generation_config.eos_token_id = [2, 9]
+        model.llm.generation_config.pad_token_id = None
+        model.save_pretrained(out)  # <-- the reference's writer
+        cfg = cfg_from(model, tok)
+        ids, images, depths, masks = so.synth_inputs(cfg, batch=1, regions=2, prompt_len=15, seed=1)
+        with torch.no_grad():
+            gen = model.generate(input_ids=ids, images=images, depths=depths, masks=masks, do_sample=False, max_new_tokens=12,
+                                 use_cache=True, eos_token_id=None, pad_token_id=0, min_new_tokens=12)
+        prompt = "<image>\nhow far is region <mask> <depth> from region <mask> <depth> ?"
+        sys.path.insert(0, rh.REFERENCE_ROOT)
+        from llava.mm_utils import tokenizer_image_token
+
+        pids = tokenizer_image_token(prompt, tok, return_tensors="pt")
+    files = sorted(os.path.relpath(os.path.join(r, f), out) for r, _, fs in os.walk(out) for f in fs)
+    total = sum(os.path.getsize(os.path.join(out, f)) for f in files)
+    print(f"  reference save_pretrained wrote {len(files)} files, {total / 1e6:.2f} MB:", files)
+    np.savez_compressed(os.path.join(GOLD, "ckpt_tiny_kat.npz"), input_ids=ids.numpy(),
+                        images_q32=(images * 32).round().to(torch.int8).numpy(),
+                        depths_q32=(depths[:, :1] * 32).round().to(torch.int8).numpy(),
+                        masks_u8=torch.stack(masks).to(torch.uint8).numpy(), new_ids=gen.numpy(),
+                        prompt=np.frombuffer(prompt.encode(), dtype=np.uint8), prompt_ids=pids.numpy(),
+                        mask_token_id=cfg.mask_token_id, depth_token_id=cfg.depth_token_id)
+    print("  wrote ckpt_tiny/ and ckpt_tiny_kat.npz; reference ids:", gen.tolist())
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "posembed":
         mint_posembed_kat()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ckpt":  # only the reference-written checkpoint directory
+        mint_checkpoint()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "labels":  # only the labels / loss fixture (reuses tiny_fp32.npz's weights)
         mint_labels_kat()
@@ -418,4 +469,5 @@ if __name__ == "__main__":
     mint_model_case(torch.float32, "tiny_clip_fp32.npz", tower="clip")
     mint_labels_kat()
     mint_posembed_kat()
+    mint_checkpoint()
     print("golden vectors written to", GOLD)

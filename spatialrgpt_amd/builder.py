@@ -47,10 +47,32 @@ def _load_dir(d, prefix, out):
             out[prefix + k] = v
 
 
+def _sub_config(model_path: str, sub: str, nested) -> dict:
+    """A sub-model's config: <ckpt>/<sub>/config.json (what `save_pretrained` of the sub-model writes, llava_arch.py:181-250);
+    the copy nested in the top-level config.json (`llm_cfg` / `vision_tower_cfg` objects, llava_arch.py:201,217) is the
+    fallback when the directory carries weights only."""
+    p = os.path.join(model_path, sub, "config.json")
+    if os.path.exists(p):
+        return _read_json(p)
+    if isinstance(nested, dict):
+        return nested
+    raise ValueError(f"no config for {sub!r} under {model_path}")
+
+
+def _rope(lc: dict):
+    """(theta, linear factor): transformers 4.37.2 stores `rope_theta` + `rope_scaling{type, factor}` (what the reference's
+    context_length_extension writes, language_model/builder.py:31-38); transformers 5 folds both into `rope_parameters`."""
+    rp = lc.get("rope_parameters") or {}
+    theta = lc.get("rope_theta", rp.get("rope_theta", 10000.0))
+    rs = lc.get("rope_scaling") or rp
+    kind = rs.get("type", rs.get("rope_type"))
+    return float(theta), (float(rs.get("factor", 1.0)) if kind == "linear" else 1.0)
+
+
 def config_from_checkpoint(model_path: str) -> SrgptConfig:
     top = _read_json(os.path.join(model_path, "config.json"))
-    lc = _read_json(os.path.join(model_path, "llm", "config.json"))
-    vc = _read_json(os.path.join(model_path, "vision_tower", "config.json"))
+    lc = _sub_config(model_path, "llm", top.get("llm_cfg"))
+    vc = _sub_config(model_path, "vision_tower", top.get("vision_tower_cfg"))
     vc = vc.get("vision_config", vc)
     arch = (vc.get("architectures") or [vc.get("model_type", "")])[0].lower() if (vc.get("architectures") or vc.get("model_type")) else ""
     tname = (arch + " " + str(vc.get("model_type", ""))).lower()
@@ -63,8 +85,7 @@ def config_from_checkpoint(model_path: str) -> SrgptConfig:
     if top.get("mm_projector_cfg", {}).get("mm_projector_type", "mlp_downsample") != "mlp_downsample" \
             if isinstance(top.get("mm_projector_cfg"), dict) else False:
         raise ValueError(f"Unknown projector type: {top['mm_projector_cfg']}")
-    rs = lc.get("rope_scaling") or {}
-    factor = float(rs.get("factor", 1.0)) if rs.get("type", rs.get("rope_type")) == "linear" else 1.0
+    theta, factor = _rope(lc)
     # HF `from_pretrained` gives the LLM `<ckpt>/llm/generation_config.json` as its generation config when the file exists (else the
     # generation fields of llm/config.json); `llm.generate` (llava_llama.py:212) stops on ITS eos ids -- a list for Llama-3
     gp = os.path.join(model_path, "llm", "generation_config.json")
@@ -76,7 +97,7 @@ def config_from_checkpoint(model_path: str) -> SrgptConfig:
         select_feature=top.get("mm_vision_select_feature", "cls_patch") or "cls_patch", tower=tower,
         hidden=lc["hidden_size"], inter=lc["intermediate_size"], layers=lc["num_hidden_layers"],
         heads=lc["num_attention_heads"], kv_heads=lc.get("num_key_value_heads", lc["num_attention_heads"]),
-        vocab=lc["vocab_size"], rms_eps=lc.get("rms_norm_eps", 1e-5), rope_theta=float(lc.get("rope_theta", 10000.0)),
+        vocab=lc["vocab_size"], rms_eps=lc.get("rms_norm_eps", 1e-5), rope_theta=theta,
         rope_factor=factor, max_position_embeddings=int(lc.get("model_max_length") or lc.get("max_position_embeddings", 4096)),
         enable_region=bool(top.get("enable_region", False)), enable_depth=bool(top.get("enable_depth", False)),
         tokenizer_model_max_length=lc.get("tokenizer_model_max_length"),
@@ -108,7 +129,13 @@ def read_checkpoint(model_path: str, vision_resolution: int = -1, interpolate_mo
     cfg = config_from_checkpoint(model_path)
     sd = {}
     _load_dir(os.path.join(model_path, "llm"), "llm.", sd)
-    _load_dir(os.path.join(model_path, "vision_tower"), "vision_tower.vision_tower.", sd)
+    vt = {}
+    _load_dir(os.path.join(model_path, "vision_tower"), "", vt)
+    # transformers 4.37.2 (the reference's pin) writes the tower's keys under `vision_model.`; transformers 5 flattened the
+    # wrapper away (`embeddings.* / encoder.*` at top level) -- the in-memory names here are the 4.37.2 ones
+    for k, v in vt.items():
+        sd["vision_tower.vision_tower." + (k if k.startswith("vision_model.") else "vision_model." + k)] = v
+    del vt
     _load_dir(os.path.join(model_path, "mm_projector"), "mm_projector.", sd)
     if cfg.enable_region:
         _load_dir(os.path.join(model_path, "region_extractor"), "region_extractor.", sd)

@@ -244,3 +244,36 @@ def test_generation_config_eos_list_stops_and_pads_like_hf(tmp_path):
     # sampling path (demo, gradio_web_server_multi.py:202-213): top_k=1 makes it deterministic = greedy; same stop / pad rules
     smp = model.generate(input_ids, do_sample=True, temperature=0.7, top_k=1, max_new_tokens=G, **kw).cpu()
     assert torch.equal(smp, want), (smp, want)
+
+
+def test_reference_written_checkpoint_reproduces_reference_ids_bit_exactly():
+    """tests/golden/ckpt_tiny/ is the output of the REFERENCE's own `save_pretrained` (llava_arch.py:181-250);
+    tests/golden/ckpt_tiny_kat.npz holds the ids the reference's `generate()` produced on that very model.  Loaded through
+    `load_pretrained_model` (fp32 engine) and through the HF-registry route, the engine reproduces them bit for bit."""
+    import numpy as np
+    from transformers import AutoConfig
+
+    import spatialrgpt_amd
+    from spatialrgpt_amd import load_pretrained_model
+    from tests.util import GOLD
+
+    root = os.path.join(GOLD, "ckpt_tiny")
+    z = np.load(os.path.join(GOLD, "ckpt_tiny_kat.npz"))
+    ids = torch.from_numpy(z["input_ids"]).cuda()
+    images = (torch.from_numpy(z["images_q32"].astype(np.float32)) / 32).cuda()
+    depths = (torch.from_numpy(z["depths_q32"].astype(np.float32)) / 32).expand(-1, 3, -1, -1).contiguous().cuda()
+    masks = [torch.from_numpy(z["masks_u8"][i].astype(np.float32)).cuda() for i in range(z["masks_u8"].shape[0])]
+    want = torch.from_numpy(z["new_ids"])
+    tokenizer, model, image_processor, context_len = load_pretrained_model(root, "SpatialRGPT-tiny", dtype=torch.float32)
+    assert model.dtype == torch.float32 and context_len == 2048 and len(tokenizer) == 122
+    assert model.config.eos_token_id == [2, 9]  # llm/generation_config.json as the reference saved it
+    kw = dict(images=images, depths=depths, masks=masks, do_sample=False, max_new_tokens=want.shape[1], use_cache=True,
+              eos_token_id=None, pad_token_id=0, min_new_tokens=want.shape[1])  # the keywords the golden run used
+    got = model.generate(ids, **kw).cpu()
+    assert torch.equal(got, want), (got, want)
+    # builder.py:142-158's own sequence on the same directory (nested sub-configs in the top-level config.json)
+    config = AutoConfig.from_pretrained(root)
+    config.resume_path = root
+    config.model_dtype = "torch.float32"
+    m2 = spatialrgpt_amd.LlavaLlamaModel(config=config, low_cpu_mem_usage=True)
+    assert m2.dtype == torch.float32 and torch.equal(m2.generate(ids, **kw).cpu(), want)

@@ -178,3 +178,52 @@ def test_vision_resolution_position_embedding_resize_matches_reference_kat(tmp_p
     assert proc.size["height"] == res and proc.size["width"] == res
     with pytest.raises(NotImplementedError):
         read_checkpoint(root, vision_resolution=res, interpolate_mode="bicubic")
+
+
+CKPT_TINY = os.path.join(GOLD, "ckpt_tiny")
+
+
+def test_loader_reads_the_checkpoint_the_reference_writer_wrote():
+    """tests/golden/ckpt_tiny/ was written by the REFERENCE's `LlavaLlamaModel.save_pretrained` (llava_arch.py:181-250) run in the
+    build container (oracle/make_golden.py `ckpt`; transformers 5.15 underneath, so the tower's keys are the flattened ones and
+    the LLM config carries `rope_parameters`).  The loader must recover the geometry from the nested top-level config + the
+    sub-model configs, the exact weights (== tests/golden/tiny_fp32.npz, minted from the same reference model), the generation
+    config the reference saved (an EOS list), and a tokenizer whose `tokenizer_image_token` ids equal the reference's."""
+    from spatialrgpt_amd import tokenizer_image_token
+    from spatialrgpt_amd.builder import config_from_checkpoint, load_image_processor, load_tokenizer, read_checkpoint
+
+    top = json.load(open(os.path.join(CKPT_TINY, "config.json")))
+    assert top["architectures"] == ["LlavaLlamaModel"] and isinstance(top["llm_cfg"], dict) and isinstance(top["vision_tower_cfg"], dict)
+    cfg, sd = read_checkpoint(CKPT_TINY)
+    cfgd, dtype, w, inp, ref = load_tiny("tiny_fp32.npz")
+    for k in ("vit_hidden", "vit_inter", "vit_layers", "vit_heads", "image_size", "patch_size", "hidden", "inter", "layers", "heads",
+              "kv_heads", "vocab", "rope_theta", "rms_eps", "select_layer", "select_feature", "enable_region", "enable_depth"):
+        assert getattr(cfg, k) == cfgd[k], k
+    assert cfg.tower == "siglip" and cfg.eos_token_id == [2, 9] and cfg.generation_config["eos_token_id"] == [2, 9]
+    assert all(k in sd for k in w), [k for k in w if k not in sd][:4]
+    assert all(torch.equal(sd[k], w[k]) for k in w)
+    tok = load_tokenizer(CKPT_TINY, cfg, sd)
+    z = np.load(os.path.join(GOLD, "ckpt_tiny_kat.npz"))
+    assert (cfg.mask_token_id, cfg.depth_token_id) == (int(z["mask_token_id"]), int(z["depth_token_id"])) == (120, 121)
+    assert cfg.vocab == 128 and len(tok) == 122  # the saved tokenizer already holds <mask>/<depth>; the table needs no growth
+    got = tokenizer_image_token(bytes(z["prompt"]).decode(), tok, return_tensors="pt")
+    assert got.tolist() == z["prompt_ids"].tolist()
+    proc = load_image_processor(CKPT_TINY, cfg)
+    assert proc.size["height"] == cfg.image_size
+    # a checkpoint whose sub-directories hold weights only: the nested copies in the top-level config are enough
+    import shutil
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        dst = os.path.join(td, "c")
+        shutil.copytree(CKPT_TINY, dst)
+        os.remove(os.path.join(dst, "llm", "config.json"))
+        os.remove(os.path.join(dst, "vision_tower", "config.json"))
+        c2 = config_from_checkpoint(dst)
+        assert (c2.hidden, c2.vit_hidden, c2.rope_theta, c2.vocab) == (cfg.hidden, cfg.vit_hidden, cfg.rope_theta, 128)
+    # the 4.37.2 spelling of the same fields (what a checkpoint published by the reference's authors carries)
+    from spatialrgpt_amd.builder import _rope
+
+    assert _rope({"rope_theta": 10000.0, "rope_scaling": {"type": "linear", "factor": 4.0}}) == (10000.0, 4.0)
+    assert _rope({"rope_parameters": {"rope_theta": 500000.0, "rope_type": "default"}}) == (500000.0, 1.0)
+    assert _rope({}) == (10000.0, 1.0)
