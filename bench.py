@@ -89,6 +89,25 @@ def workload_name(args, cfg, T):
             f"T={T}, greedy {args.max_new_tokens} new tokens")
 
 
+def spliced_len(cfg, prompt_len):
+    """T of the spliced stream: the prompt's ids minus the <image> sentinel plus the projector's tokens -- mlp_downsample halves
+    the tower grid (27 -> 14: 196 tokens for SigLIP-384; 24 -> 12: 144 for CLIP-L/14-336)."""
+    g = (cfg.grid + 1) // 2
+    return prompt_len - 1 + g * g
+
+
+def kernel_source_sha256():
+    """sha256 over the sources of the decode GEMV (gemv.hip, common.h): a PMC summary under profiles/ belongs to ONE kernel source;
+    bench.py only quotes its traffic figure when the hash recorded in it is the hash of the tree that is running."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("gemv.hip", "common.h"):
+        with open(os.path.join(ROOT, "spatialrgpt_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def make_cfg(name):
     from spatialrgpt_amd.config import SrgptConfig
 
@@ -184,9 +203,21 @@ def self_launch(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # poll all ranks: the first one that dies takes the others with it (a survivor would sit in the rendezvous / all_reduce
+    # until the backend's timeout), exit code = the worst rank's
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            r_ = p.poll()
+            if r_ is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(r_))
+            if r_ != 0:
+                for q in live:
+                    q.kill()
     return rc
 
 
@@ -332,7 +363,7 @@ def main():
         alg_bytes = wgu[0].numel() * wgu[0].element_size()  # every weight byte exactly once per launch
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # whole decode phase (graph replays incl. attention + launch gaps), same events technique
-        st, _, _ = eng.prefill(torch.randn((args.batch, 259, cfg.hidden), device=device).to(dtype), max_new=G)
+        st, _, _ = eng.prefill(torch.randn((args.batch, spliced_len(cfg, args.prompt_len), cfg.hidden), device=device).to(dtype), max_new=G)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
@@ -344,12 +375,17 @@ def main():
         # HBM bytes per launch: PMC counters cannot be read from inside this process -- the figure comes from the tracked
         # summary of a separate `rocprofv3 --pmc FETCH_SIZE` pass over this same command (x2 gfx950 correction), and says so
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemv.json")
-        if not os.path.exists(pmc):
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")
-        if args.model == "vila15_8b" and os.path.exists(pmc) and not fp8 and rows == 1:
-            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-            traffic_src = f"static: {os.path.relpath(pmc, ROOT)} (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction; not measured in this run)"
+        pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_gemv.json"))
+        if args.model == "vila15_8b" and pmcs and not fp8 and rows == 1:
+            pmc = os.path.join(ROOT, "profiles", pmcs[-1])
+            rec = json.load(open(pmc))
+            if rec.get("kernel_source_sha256") == kernel_source_sha256():
+                traffic = rec.get("traffic_bytes_per_launch")
+                traffic_src = (f"static: {os.path.relpath(pmc, ROOT)} (separate rocprofv3 --pmc FETCH_SIZE pass over this kernel source, "
+                               f"sha256 {rec['kernel_source_sha256'][:12]}; x2 gfx950 correction; not measured in this run)")
+            else:
+                traffic_src = (f"none: {os.path.relpath(pmc, ROOT)} was recorded for another kernel source (sha256 "
+                               f"{str(rec.get('kernel_source_sha256'))[:12]} != {kernel_source_sha256()[:12]}); re-run scripts/profile_round.sh")
         kname = (("skinny_kernel<swiglu, W8>" if rows > 2 else "gemv_w8_kernel<swiglu>") if fp8 else
                  ("skinny_kernel<swiglu>" if rows > 2 else f"gemv_kernel<bf16,{rows},swiglu>"))
         roof = {"bound": "hbm", "kernel": f"{kname} (decode gate/up projection at {rows} activation row(s), 54% of streamed bytes"
@@ -370,7 +406,7 @@ def main():
         cpu = {"value": round(G / total, 4), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": (f"oracle (CPU restatement of the reference path, bf16, same weights) at FULL depth ({cfg.layers} LLM layers, "
                           f"{cfg.vit_layers_run} ViT layers x2 images) on one request: vision {t['vit_x2']:.2f}s + region/projector/splice "
-                          f"{t['region_proj_splice']:.2f}s + prefill(T={args.prompt_len - 1 + 196}, lm_head on all rows) {t['prefill']:.2f}s "
+                          f"{t['region_proj_splice']:.2f}s + prefill(T={spliced_len(cfg, args.prompt_len)}, lm_head on all rows) {t['prefill']:.2f}s "
                           f"measured once, {g_cpu} of the {G} decode steps measured ({t['decode_step'] * 1e3:.0f} ms/token) and scaled "
                           f"to {G - 1}"),
                "measured_s": {k: round(v, 4) for k, v in t.items()}}
@@ -382,7 +418,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16" if args.weights == "bf16" else "bf16 activations / fp8-e4m3fn LLM weights (W8A16)" if args.weights == "fp8"
                       else "fp8-e4m3fn LLM weights; prefill W8A8 (per-token e4m3 activations, fp8 MFMA), decode W8A16"), "data": "synthetic (seeded random weights of the named architecture; random images/depth/box masks/ids)",
-            "config": {"workload": workload_name(args, cfg, args.prompt_len - 1 + 196),
+            "config": {"workload": workload_name(args, cfg, spliced_len(cfg, args.prompt_len)),
                        "requests_per_step_per_gpu": args.batch, "new_tokens_per_request": G, "parallelism": f"dp{world}",
                        "decode": "hipGraph" if not args.no_graph else "eager", "build_s": round(t_build, 1),
                        "llm_weights": args.weights, "dist": dist_info},

@@ -3,7 +3,7 @@ import json
 import re
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
 g, p = "gpurun_out/" + tag, "profiles/" + tag
 d = json.loads(open(g + "_bench_default.json").read().strip().splitlines()[-1])
 open(p + "_bench.json", "w").write(json.dumps(d, indent=1) + "\n")
@@ -48,8 +48,12 @@ for l in open(g + "_pmc_fetch.txt").read().splitlines():
         gu = fs / nd
 if gu:
     out.append(f"# gate/up GEMV (gemv_kernel<..., true, 2>): {2 * gu / 1024:.1f} MiB per dispatch vs 224.0 MiB of weights (2*14336*4096*2 B): ratio {2 * gu * 1024 / (2 * 14336 * 4096 * 2):.4f} -> every weight byte read once.")
+    sys.path.insert(0, ".")
+    from bench import kernel_source_sha256  # the summary is bound to the kernel source it was measured on (bench.py checks it)
+
     json.dump({"kernel": "gemv_kernel<bf16,1,swiglu>", "fetch_size_kib": round(gu, 1), "correction": 2.0,
-               "traffic_bytes_per_launch": int(round(gu * 2048, -3)), "source": p + "_pmc_fetch.txt"}, open("profiles/" + tag.split("_")[0] + "_pmc_gemv.json", "w"))
+               "traffic_bytes_per_launch": int(round(gu * 2048, -3)), "source": p + "_pmc_fetch.txt",
+               "kernel_source_sha256": kernel_source_sha256()}, open("profiles/" + tag.split("_")[0] + "_pmc_gemv.json", "w"))
 open(p + "_pmc_fetch.txt", "w").write("\n".join(out) + "\n")
 print("composed", p, "| gate/up trace avg", trace_us, "us | bench", d["value"], "tok/s")
 import os

@@ -9,6 +9,8 @@
 //     keys, fused RoPE of the new q/k and cache append.  HBM/latency bound.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -287,6 +289,109 @@ static inline int decode_nsplit(int max_pos, int B, int Hkv) {
   return n;
 }
 
+// ---- the tail both decode kernels share: arrival ticket of the (sequence, kv head) group, merge by the last arriver ----
+// the MFMA kernel (bf16, head_dim 128): a block covers 64 keys (4 waves x 16), so ceil(capacity / 64) splits; at least 4 so that a
+// short cache still spreads over the chip; beyond 64 splits the waves loop (64 keys per block and pass)
+static inline int decode_nsplit_mfma(int max_pos) {
+  const int force = SRGPT_KNOB("SRGPT_DECODE_MIN_SPLITS", 0);  // tuning build: fixed split count
+  int n = cdiv(max_pos, 64);
+  if (n < 4) n = 4;
+  if (force > 0) n = force;
+  if (n > DEC_SPLIT_MAX) n = DEC_SPLIT_MAX;
+  return n;
+}
+static inline bool decode_use_mfma(int dtype_is_bf16, int D, int G) {
+  return dtype_is_bf16 && D == 128 && (G == 1 || G == 2 || G == 4 || G == 8) && SRGPT_KNOB("SRGPT_DECODE_MFMA", 1);
+}
+
+template <typename T, int D, int G, int SCLD>
+__device__ __forceinline__ void decode_ticket_merge(float* __restrict__ wbase, int* __restrict__ ticket, int nsplit,
+                                                    T* __restrict__ outp, float* __restrict__ sc, float* __restrict__ stat_m,
+                                                    float* __restrict__ stat_l, int tid, int lane, int wave, bool first_group,
+                                                    int stamp_base_in) {
+#ifdef SRGPT_TUNING_KNOBS
+  int stamp_base = stamp_base_in;
+#endif
+  // ---- arrival ticket: every storing wave drains its write-through stores, one lane takes the ticket; the block that draws
+  //      the last one merges the nsplit partials of its G query heads (fixed split order: the result does not depend on
+  //      which block came last) and re-arms the ticket for the next launch on this stream ----
+  DEC_STAMP(7);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  DEC_STAMP(8);
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stat_l[0] = (t == nsplit - 1) ? 1.f : 0.f;  // stat_l is free again: broadcast "I am last" through the existing LDS
+  }
+  __syncthreads();
+  DEC_STAMP(9);
+  if (stat_l[0] == 0.f) return;
+#ifdef SRGPT_TUNING_KNOBS
+  if (first_group) stamp_base = 16;
+#endif
+  DEC_STAMP(0);
+  __syncthreads();
+  // The first 16 splits' partials of this thread's pair of output dims AND the per-split statistics are requested back to
+  // back: the merge pays one memory latency.  (G * D / 2 <= 256 * MAXW items; one or two per thread for the shipped shapes.)
+  constexpr int PRE = 16;
+  constexpr int MAXW = (G * (D / 2) + 255) / 256;
+  unsigned long long v[MAXW][PRE];
+#pragma unroll
+  for (int wi = 0; wi < MAXW; ++wi) {
+    const int w = min(tid + 256 * wi, G * (D / 2) - 1);
+    const int gq = w / (D / 2), d = 2 * (w - gq * (D / 2));
+    const float* wp = wbase + (size_t)gq * DEC_SPLIT_MAX * (D + 2) + d;
+#pragma unroll
+    for (int j = 0; j < PRE; ++j)
+      v[wi][j] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)min(j, nsplit - 1) * (D + 2)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // per-head merge weights: wave gq handles head gq (G <= 8 heads over 4 waves), one split per lane (nsplit <= 64)
+  for (int gq = wave; gq < G; gq += 4) {
+    const float* wp = wbase + (size_t)gq * DEC_SPLIT_MAX * (D + 2);
+    const bool ok = lane < nsplit;
+    const int sidx = ok ? lane : nsplit - 1;
+    const unsigned long long ml = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)sidx * (D + 2) + D),
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float ms_raw = __uint_as_float((unsigned)ml), ls_raw = __uint_as_float((unsigned)(ml >> 32));
+    const float ms = ok ? ms_raw : -INFINITY;
+    const float ls = ok ? ls_raw : 0.f;
+    const float M = lanes_max<64>(ms);
+    const float wv = (ms > -INFINITY) ? __expf(ms - M) : 0.f;
+    const float den = lanes_sum<64>(wv * ls);
+    sc[gq * SCLD + lane] = wv;
+    if (lane == 0) stat_m[gq] = den > 0.f ? 1.f / den : 0.f;
+  }
+  DEC_STAMP(1);
+  __syncthreads();
+#pragma unroll
+  for (int wi = 0; wi < MAXW; ++wi) {
+    const int w = tid + 256 * wi;
+    if (w < G * (D / 2)) {
+      const int gq = w / (D / 2), d = 2 * (w - gq * (D / 2));
+      const float* wp = wbase + (size_t)gq * DEC_SPLIT_MAX * (D + 2) + d;
+      float n0 = 0.f, n1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < PRE; ++j)
+        if (j < nsplit) {
+          n0 = fmaf(sc[gq * SCLD + j], __uint_as_float((unsigned)v[wi][j]), n0);
+          n1 = fmaf(sc[gq * SCLD + j], __uint_as_float((unsigned)(v[wi][j] >> 32)), n1);
+        }
+      for (int sp = PRE; sp < nsplit; ++sp) {
+        const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)sp * (D + 2)),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n0 = fmaf(sc[gq * SCLD + sp], __uint_as_float((unsigned)u), n0);
+        n1 = fmaf(sc[gq * SCLD + sp], __uint_as_float((unsigned)(u >> 32)), n1);
+      }
+      T* op = outp + (size_t)gq * D + d;
+      op[0] = from_f<T>(n0 * stat_m[gq]);
+      op[1] = from_f<T>(n1 * stat_m[gq]);
+    }
+  }
+  DEC_STAMP(2);
+  if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename T, int D, int G>
 __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__ qkv, T* __restrict__ kcache,
                                                            T* __restrict__ vcache, const int* __restrict__ pos,
@@ -512,84 +617,250 @@ __global__ __launch_bounds__(256) void decode_split_kernel(const T* __restrict__
   }
   }  // !empty
 
-  // ---- arrival ticket: every storing wave drains its write-through stores, one lane takes the ticket; the block that draws
-  //      the last one merges the nsplit partials of its G query heads (fixed split order: the result does not depend on
-  //      which block came last) and re-arms the ticket for the next launch on this stream ----
-  DEC_STAMP(7);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  DEC_STAMP(8);
-  if (tid == 0) {
-    const int t = __hip_atomic_fetch_add(tickets + (size_t)b * Hkv + hk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    stat_l[0] = (t == nsplit - 1) ? 1.f : 0.f;  // stat_l is free again: broadcast "I am last" through the existing LDS
-  }
-  __syncthreads();
-  DEC_STAMP(9);
-  if (stat_l[0] == 0.f) return;
+  decode_ticket_merge<T, D, G, DEC_CHUNK_MAX>(wbase, tickets + (size_t)b * Hkv + hk, nsplit,
+                                              out + ((size_t)b * Hq + (size_t)hk * G) * D, &sc[0][0], stat_m, stat_l, tid, lane, wave,
+                                              hk == 0 && b == 0,
 #ifdef SRGPT_TUNING_KNOBS
-  if (hk == 0 && b == 0) stamp_base = 16;
+                                              stamp_base
+#else
+                                              -1
+#endif
+  );
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode attention, bf16 / head_dim 128 (every LLM geometry of the reference's recipes): round 3.
+// The VALU kernel above spends ~10k of its ~23k cycles in three dependent-chain phases (scores with a cross-lane reduction per key
+// and head, block-wide statistics, P.V with 32 cross-lane reductions per thread: profiles/r02_decode_attention_stamps.txt).  Here
+//   * scores are ONE chain of four v_mfma_f32_16x16x32_bf16 per wave and 16 keys: A = K rows exactly as they lie in the cache
+//     (lane = key, 16-byte d slices -- loaded straight from global in fragment shape), B = the G roped query heads (columns >= G
+//     zero); the result leaves lane (head, key quad) with its 4 scores -- softmax statistics are two row swaps, no LDS, no barrier;
+//   * P.V runs with lane = a pair of output dims over the wave's 16 keys (V rows as 256-byte wave loads, probabilities broadcast
+//     from LDS): no cross-lane reduction at all;
+//   * the four waves of a block (64 keys) meet once, through LDS, with per-wave (m, l) statistics -- one barrier;
+// a block covers 64 keys (8 splits at <= 512 cached positions instead of 16): half as many partials for the merging block.
+// All K / V row loads of a wave's first key group go out before anything depends on q.  Same partial format, ticket and merge.
+// ------------------------------------------------------------------------------------------------
+constexpr int DM_QLD = 136;  // bf16 row stride of the staged query heads (272 bytes: rows land on different bank groups)
+
+template <int G>
+__global__ __launch_bounds__(256) void decode_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kcache,
+                                                          bf16_t* __restrict__ vcache, const int* __restrict__ pos,
+                                                          const bf16_t* __restrict__ cos_tab, const bf16_t* __restrict__ sin_tab,
+                                                          float* __restrict__ ws, int* __restrict__ tickets,
+                                                          bf16_t* __restrict__ out, int Hq, int Hkv, int max_pos, int nsplit,
+                                                          float scale, int n_attn, DecodePrefetch pf) {
+  typedef bf16_t T;
+  constexpr int D = 128, HALF = 64;
+  __shared__ __attribute__((aligned(16))) bf16_t qs[16 * DM_QLD];  // B operand source: rows = query heads (>= G: zero)
+  __shared__ __attribute__((aligned(16))) bf16_t knew[D], vnew[D];
+  __shared__ __attribute__((aligned(16))) float pw[4][16][G];      // a wave's probabilities [key][head]
+  __shared__ __attribute__((aligned(16))) float accs[4][G][D];     // per-wave P.V
+  __shared__ float wm[4][G], wl[4][G];
+  __shared__ float sc[G][64];                                      // merge weights (decode_ticket_merge)
+  __shared__ float stat_m[G], stat_l[G];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= n_attn) {  // ---- prefetch block (common.h) ----
+    srgpt_prefetch_block(pf, (int)blockIdx.x - n_attn, wave, lane);
+    return;
+  }
+  const int hk = (int)blockIdx.x % Hkv, split = ((int)blockIdx.x / Hkv) % nsplit, b = (int)blockIdx.x / (Hkv * nsplit);
+#ifdef SRGPT_TUNING_KNOBS
+  int stamp_base = blockIdx.x == 0 ? 0 : -1;
 #endif
   DEC_STAMP(0);
-  __syncthreads();
-  // The first 16 splits' partials of this thread's pair of output dims AND the per-split statistics are requested back to
-  // back: the merge pays one memory latency.  (G * D / 2 <= 256 * MAXW items; one or two per thread for the shipped shapes.)
-  constexpr int PRE = 16;
-  constexpr int MAXW = (G * (D / 2) + 255) / 256;
-  unsigned long long v[MAXW][PRE];
+  const int P = pos[b];
+  const int total = P + 1;
+  const int chunk = (total + nsplit - 1) / nsplit;  // key ranges depend on the sequence length only (see decode_split_kernel)
+  const int kbeg = split * chunk, kend = min(kbeg + chunk, total);
+  const T* row = qkv + (size_t)b * (Hq + 2 * Hkv) * D;
+  T* kc = kcache + ((size_t)b * Hkv + hk) * (size_t)max_pos * D;
+  T* vc = vcache + ((size_t)b * Hkv + hk) * (size_t)max_pos * D;
+  const int lq = lane & 15, g4 = lane >> 4;
+  const int lastrow = max(P - 1, 0);  // rows >= P are not in the cache yet (row P is written by the split-0 block of THIS launch)
+
+  // ---- K rows (fragment shape) and V rows (256-byte wave loads) of the wave's first 16-key group: one memory latency ----
+  u32x4 kreg[4];
+  unsigned int vreg[16];
+  auto fetch = [&](int kb) {
+    const T* kr = kc + (size_t)min(kb + lq, lastrow) * D + g4 * 8;
 #pragma unroll
-  for (int wi = 0; wi < MAXW; ++wi) {
-    const int w = min(tid + 256 * wi, G * (D / 2) - 1);
-    const int gq = w / (D / 2), d = 2 * (w - gq * (D / 2));
-    const float* wp = wbase + (size_t)gq * DEC_SPLIT_MAX * (D + 2) + d;
+    for (int j = 0; j < 4; ++j) kreg[j] = *reinterpret_cast<const u32x4*>(kr + 32 * j);
 #pragma unroll
-    for (int j = 0; j < PRE; ++j)
-      v[wi][j] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)min(j, nsplit - 1) * (D + 2)),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // per-head merge weights: wave gq handles head gq (G <= 8 heads over 4 waves), one split per lane (nsplit <= 64)
-  for (int gq = wave; gq < G; gq += 4) {
-    const float* wp = wbase + (size_t)gq * DEC_SPLIT_MAX * (D + 2);
-    const bool ok = lane < nsplit;
-    const int sidx = ok ? lane : nsplit - 1;
-    const unsigned long long ml = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)sidx * (D + 2) + D),
-                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float ms_raw = __uint_as_float((unsigned)ml), ls_raw = __uint_as_float((unsigned)(ml >> 32));
-    const float ms = ok ? ms_raw : -INFINITY;
-    const float ls = ok ? ls_raw : 0.f;
-    const float M = lanes_max<64>(ms);
-    const float wv = (ms > -INFINITY) ? __expf(ms - M) : 0.f;
-    const float den = lanes_sum<64>(wv * ls);
-    sc[gq][lane] = wv;
-    if (lane == 0) stat_m[gq] = den > 0.f ? 1.f / den : 0.f;
-  }
+    for (int i = 0; i < 16; ++i)
+      vreg[i] = *reinterpret_cast<const unsigned int*>(vc + (size_t)min(kb + i, lastrow) * D + 2 * lane);
+  };
+  int kb = kbeg + 16 * wave;
+  fetch(kb);
+
   DEC_STAMP(1);
-  __syncthreads();
+  // ---- rotate q (G heads) and the new k; stage v.  Every global load of this stage is issued before any is consumed ----
+  {
+    constexpr int NITEM = (G + 1) * HALF;
+    constexpr int ITEMS = (NITEM + 255) / 256;
+    float x1v[ITEMS], x2v[ITEMS], cv[ITEMS], sv[ITEMS];
 #pragma unroll
-  for (int wi = 0; wi < MAXW; ++wi) {
-    const int w = tid + 256 * wi;
-    if (w < G * (D / 2)) {
-      const int gq = w / (D / 2), d = 2 * (w - gq * (D / 2));
-      const float* wp = wbase + (size_t)gq * DEC_SPLIT_MAX * (D + 2) + d;
-      float n0 = 0.f, n1 = 0.f;
-#pragma unroll
-      for (int j = 0; j < PRE; ++j)
-        if (j < nsplit) {
-          n0 = fmaf(sc[gq][j], __uint_as_float((unsigned)v[wi][j]), n0);
-          n1 = fmaf(sc[gq][j], __uint_as_float((unsigned)(v[wi][j] >> 32)), n1);
-        }
-      for (int sp = PRE; sp < nsplit; ++sp) {
-        const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)sp * (D + 2)),
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        n0 = fmaf(sc[gq][sp], __uint_as_float((unsigned)u), n0);
-        n1 = fmaf(sc[gq][sp], __uint_as_float((unsigned)(u >> 32)), n1);
-      }
-      T* op = out + ((size_t)b * Hq + (size_t)hk * G + gq) * D + d;
-      op[0] = from_f<T>(n0 * stat_m[gq]);
-      op[1] = from_f<T>(n1 * stat_m[gq]);
+    for (int it = 0; it < ITEMS; ++it) {
+      const int w = (tid + 256 * it) % NITEM;
+      const int hh = w / HALF, i = w - hh * HALF;
+      const T* p = (hh < G) ? row + (size_t)(hk * G + hh) * D : row + (size_t)(Hq + hk) * D;
+      x1v[it] = to_f(p[i]);
+      x2v[it] = to_f(p[i + HALF]);
+      cv[it] = to_f(cos_tab[(size_t)P * HALF + i]);
+      sv[it] = to_f(sin_tab[(size_t)P * HALF + i]);
     }
+    const T vraw = row[(size_t)(Hq + Hkv + hk) * D + (tid % D)];
+    // query rows G .. 15 of the B operand are zero
+    for (int i = tid; i < (16 - G) * (D / 2); i += 256) {
+      const int r = G + i / (D / 2), c = 2 * (i % (D / 2));
+      *reinterpret_cast<unsigned int*>(qs + r * DM_QLD + c) = 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int w0 = tid + 256 * it;
+      if (w0 < NITEM) {
+        const int hh = w0 / HALF, i = w0 - hh * HALF;
+        const T o1 = from_f<T>(rnd<T>(x1v[it] * cv[it]) + rnd<T>(-x2v[it] * sv[it]));
+        const T o2 = from_f<T>(rnd<T>(x2v[it] * cv[it]) + rnd<T>(x1v[it] * sv[it]));
+        if (hh < G) {
+          qs[hh * DM_QLD + i] = o1;
+          qs[hh * DM_QLD + i + HALF] = o2;
+        } else {
+          knew[i] = o1;
+          knew[i + HALF] = o2;
+        }
+      }
+    }
+    if (tid < D) vnew[tid] = vraw;
   }
   DEC_STAMP(2);
-  if (tid == 0) __hip_atomic_store(tickets + (size_t)b * Hkv + hk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  DEC_STAMP(3);
+  if (split == 0) {  // exactly one block per (b, hk) appends; nobody reads position P from the cache
+    if (tid < D / 2) {
+      *reinterpret_cast<unsigned int*>(kc + (size_t)P * D + 2 * tid) = *reinterpret_cast<const unsigned int*>(knew + 2 * tid);
+      *reinterpret_cast<unsigned int*>(vc + (size_t)P * D + 2 * tid) = *reinterpret_cast<const unsigned int*>(vnew + 2 * tid);
+    }
+  }
+  // B operand: lane (head lq, d slice g4) -- the same four fragments for every key group
+  bf16x8 qf[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) qf[j] = *reinterpret_cast<const bf16x8*>(qs + lq * DM_QLD + 32 * j + g4 * 8);
+  u32x4 knf[4];  // the new key in fragment shape (for the lane whose key is P)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) knf[j] = *reinterpret_cast<const u32x4*>(knew + 32 * j + g4 * 8);
+  const unsigned int vnw = *reinterpret_cast<const unsigned int*>(vnew + 2 * lane);
+
+  float m_run = -INFINITY, l_run = 0.f;  // per column (head lq): identical in the four lanes of a column
+  float acc[G][2];
+#pragma unroll
+  for (int h = 0; h < G; ++h) acc[h][0] = acc[h][1] = 0.f;
+
+  for (; kb < kend; kb += 64) {
+    // ---- S^T = K Q^T: lane (head lq, quad g4) ends with the scores of keys kb + 4 g4 + r ----
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u32x4 kv = kreg[j];
+      if (kb + lq == P) kv = knf[j];
+      sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kv), qf[j], sacc, 0, 0, 0);
+    }
+    float sv4[4], mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kb + 4 * g4 + r;
+      sv4[r] = key < kend ? sacc[r] * scale : -INFINITY;
+      mx = fmaxf(mx, sv4[r]);
+    }
+    mx = rows_pair(mx, [](float a, float b2) { return fmaxf(a, b2); });
+    mx = halves_pair(mx, [](float a, float b2) { return fmaxf(a, b2); });
+    const float m_new = fmaxf(m_run, mx);  // kb < kend: at least one valid key, m_new is finite
+    const float alpha = __expf(m_run - m_new);  // first group: exp(-inf) = 0
+    float rs = 0.f;
+    f32x4 pv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pv[r] = __expf(sv4[r] - m_new);
+      rs += pv[r];
+    }
+    rs = rows_pair(rs, [](float a, float b2) { return a + b2; });
+    rs = halves_pair(rs, [](float a, float b2) { return a + b2; });
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+    // probabilities -> LDS [key][head] (a wave's own slab: in-order DS ops of ONE wave, no block barrier)
+    if (lq < G) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[wave][4 * g4 + r][lq] = pv[r];
+    }
+    // the rescale factor of the running P.V is per head: broadcast it the same way
+    if (lq < G && g4 == 0) wm[wave][lq] = alpha;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+      const float a_h = wm[wave][h];
+      acc[h][0] *= a_h;
+      acc[h][1] *= a_h;
+    }
+    // ---- P V: lane = output dims (2 lane, 2 lane + 1) ----
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = kb + i;
+      unsigned int vv = vreg[i];
+      if (key == P) vv = vnw;
+      if (key >= kend) vv = 0u;  // clamped rows may hold anything (0 * NaN)
+      const float v0 = bf16lo(vv), v1 = bf16hi(vv);
+#pragma unroll
+      for (int h = 0; h < G; ++h) {
+        const float ph = pw[wave][i][h];
+        acc[h][0] = fmaf(ph, v0, acc[h][0]);
+        acc[h][1] = fmaf(ph, v1, acc[h][1]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (kb + 64 < kend) fetch(kb + 64);  // contexts beyond 64 keys per split (max_pos > 64 * DEC_SPLIT_MAX never; > 512 here)
+  }
+  DEC_STAMP(4);
+  // ---- the four waves meet: per-wave (m, l) and P.V through LDS ----
+  if (lq < G && g4 == 0) {
+    wm[wave][lq] = m_run;
+    wl[wave][lq] = l_run;
+  }
+#pragma unroll
+  for (int h = 0; h < G; ++h) *reinterpret_cast<f32x2*>(&accs[wave][h][2 * lane]) = f32x2{acc[h][0], acc[h][1]};
+  DEC_STAMP(5);
+  __syncthreads();
+  DEC_STAMP(6);
+  float* wbase = ws + (((size_t)b * Hkv + hk) * G) * (size_t)DEC_SPLIT_MAX * (D + 2);
+  auto publish2 = [&](float* p, float a, float b2) {
+    const unsigned long long u = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b2) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  for (int w = tid; w < G * (D / 2); w += 256) {
+    const int gq = w / (D / 2), d = 2 * (w - gq * (D / 2));
+    const float M = fmaxf(fmaxf(wm[0][gq], wm[1][gq]), fmaxf(wm[2][gq], wm[3][gq]));
+    float n0 = 0.f, n1 = 0.f, L = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) {  // fixed wave order
+      const float e = (wm[wv][gq] > -INFINITY) ? __expf(wm[wv][gq] - M) : 0.f;
+      n0 = fmaf(e, accs[wv][gq][d], n0);
+      n1 = fmaf(e, accs[wv][gq][d + 1], n1);
+      L = fmaf(e, wl[wv][gq], L);
+    }
+    float* wp = wbase + ((size_t)gq * DEC_SPLIT_MAX + split) * (D + 2);
+    publish2(wp + d, n0, n1);  // an empty split publishes the neutral partial (zeros, m = -inf, l = 0)
+    if (d == 0) publish2(wp + D, M, L);
+  }
+  decode_ticket_merge<T, D, G, 64>(wbase, tickets + (size_t)b * Hkv + hk, nsplit, out + ((size_t)b * Hq + (size_t)hk * G) * D,
+                                   &sc[0][0], stat_m, stat_l, tid, lane, wave, hk == 0 && b == 0,
+#ifdef SRGPT_TUNING_KNOBS
+                                   stamp_base
+#else
+                                   -1
+#endif
+  );
 }
 
 template <typename T, int D>
@@ -598,6 +869,21 @@ int launch_decode_d(int G, const void* qkv, void* kc, void* vc, const int* pos, 
                     const DecodePrefetch& pf, hipStream_t s) {
   const int n_attn = Hkv * nsplit * B;
   dim3 grid(n_attn + (pf.base ? pf.nblocks : 0));
+  if constexpr (std::is_same<T, bf16_t>::value && D == 128) {
+    if (decode_use_mfma(1, D, G)) {
+#define LM(GG)                                                                                                              \
+  hipLaunchKernelGGL((decode_mfma_kernel<GG>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, pos, \
+                     (const bf16_t*)ct, (const bf16_t*)st, ws, tickets, (bf16_t*)out, Hq, Hkv, max_pos, nsplit, scale, n_attn, pf)
+      switch (G) {
+        case 1: LM(1); return SRGPT_OK;
+        case 2: LM(2); return SRGPT_OK;
+        case 4: LM(4); return SRGPT_OK;
+        case 8: LM(8); return SRGPT_OK;
+        default: break;
+      }
+#undef LM
+    }
+  }
 #define LD(GG)                                                                                                     \
   hipLaunchKernelGGL((decode_split_kernel<T, D, GG>), grid, dim3(256), 0, s, (const T*)qkv, (T*)kc, (T*)vc, pos, \
                      (const T*)ct, (const T*)st, ws, tickets, (T*)out, Hq, Hkv, max_pos, nsplit, scale, n_attn, pf)
@@ -618,9 +904,10 @@ template <typename T>
 int launch_decode(const void* qkv, void* kc, void* vc, const int* pos, const void* ct, const void* st, void* out,
                   float* ws, int B, int Hq, int Hkv, int D, int max_pos, const DecodePrefetch& pf, hipStream_t s) {
   const int G = Hq / Hkv;
-  const int nsplit = decode_nsplit(max_pos, B, Hkv);
-  // a split's scores live in LDS (sc[G][DEC_CHUNK_MAX]): the longest chunk is ceil(max_pos / nsplit) keys
-  SRGPT_CHECK(cdiv(max_pos, nsplit) <= DEC_CHUNK_MAX, SRGPT_ERR_UNSUPPORTED,
+  const bool mfma = decode_use_mfma(std::is_same<T, bf16_t>::value ? 1 : 0, D, G);
+  const int nsplit = mfma ? decode_nsplit_mfma(max_pos) : decode_nsplit(max_pos, B, Hkv);
+  // VALU kernel: a split's scores live in LDS (sc[G][DEC_CHUNK_MAX]): the longest chunk is ceil(max_pos / nsplit) keys
+  SRGPT_CHECK(mfma || cdiv(max_pos, nsplit) <= DEC_CHUNK_MAX, SRGPT_ERR_UNSUPPORTED,
               "srgpt_decode_attention: max_pos %d exceeds %d cached positions", max_pos, DEC_SPLIT_MAX * DEC_CHUNK_MAX);
   const float scale = 1.0f / sqrtf((float)D);
   int* tickets = reinterpret_cast<int*>(ws + (size_t)B * Hq * DEC_SPLIT_MAX * (D + 2));  // int[B * Hkv] behind the partials

@@ -244,19 +244,33 @@ struct SrgptPrefetch {
   int gemv_grid;         // compute blocks the next GEMV launches
   int rounds;            // how many of a wave's units to pull
   int nblocks;           // prefetch blocks appended to this launch (= gemv_grid)
+  int batch;             // 1-KiB loads a wave keeps in flight (1: one at a time -- the trickle that leaves the host launch's own
+                         // loads alone; 2 / 4 / 8: faster, at the price of queueing in front of them)
 };
 
-__device__ __forceinline__ void srgpt_prefetch_block(const SrgptPrefetch& pf, int p, int wave, int lane) {
+template <int NB>
+__device__ __forceinline__ void srgpt_prefetch_rows(const SrgptPrefetch& pf, int p, int wave, int lane) {
   const int per_row = (int)((pf.prefix_bytes < pf.row_bytes ? (long long)pf.prefix_bytes : pf.row_bytes) >> 10);
   int done = 0;
   for (int u = p * 4 + wave; u < pf.n_units && done < pf.rounds; u += pf.gemv_grid * 4, ++done)
     for (int r = 0; r < pf.unit_rows; ++r) {
       const char* row = pf.base + (size_t)((long long)u * pf.umul + (long long)r * pf.rstride) * pf.row_bytes + lane * 16;
-      for (int c = 0; c < per_row; ++c) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(row + ((size_t)c << 10));
-        asm volatile("" ::"v"(v));  // keep the load; the data is dropped
+      for (int c0 = 0; c0 < per_row; c0 += NB) {
+        u32x4 v[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) v[c] = *reinterpret_cast<const u32x4*>(row + ((size_t)min(c0 + c, per_row - 1) << 10));
+#pragma unroll
+        for (int c = 0; c < NB; ++c) asm volatile("" ::"v"(v[c]));  // keep the loads; the data is dropped
       }
     }
+}
+__device__ __forceinline__ void srgpt_prefetch_block(const SrgptPrefetch& pf, int p, int wave, int lane) {
+  switch (pf.batch) {
+    case 8: srgpt_prefetch_rows<8>(pf, p, wave, lane); break;
+    case 4: srgpt_prefetch_rows<4>(pf, p, wave, lane); break;
+    case 2: srgpt_prefetch_rows<2>(pf, p, wave, lane); break;
+    default: srgpt_prefetch_rows<1>(pf, p, wave, lane); break;
+  }
 }
 
 extern "C" int srgpt_device_cus(void);
@@ -267,7 +281,7 @@ extern "C" int srgpt_device_cus(void);
 // 16-row units, was measured: o_proj +1 % at 8 fp8 rows, -2 % at 4 bf16 rows per decode step, not kept).
 static inline SrgptPrefetch srgpt_prefetch_for_gemv(const void* W, int N, int K, int swiglu, int fp8, int batch, int rounds,
                                                     int prefix_bytes) {
-  SrgptPrefetch pf{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0};
+  SrgptPrefetch pf{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1};
   const long long row_bytes = fp8 ? (long long)K : 2LL * K;
   if (!W || batch > 2 || rounds <= 0 || row_bytes % 1024 != 0 || (fp8 && swiglu)) return pf;
   const int cus = srgpt_device_cus();
@@ -284,5 +298,6 @@ static inline SrgptPrefetch srgpt_prefetch_for_gemv(const void* W, int N, int K,
   pf.gemv_grid = grid;
   pf.rounds = rounds;
   pf.nblocks = grid;
+  pf.batch = SRGPT_KNOB("SRGPT_DECODE_PREFETCH_BATCH", 1);
   return pf;
 }

@@ -2,21 +2,27 @@
 // plus the layout kernels either side of it (projector space-to-depth, adaptive average pool, patch im2col).
 //
 // Masked region pooling is HBM-bound: the refined feature map (108*108 x C bf16 = 26.9 MB at C = 1152) is
-// read exactly once for ALL M masks.  Three deterministic stages (no float atomics):
-//   1. region_weights_kernel : one block per mask; bilinear resample to the feature grid (PyTorch's
-//      upsample_bilinear2d index math, align_corners = False, no antialias), round to the feature dtype,
-//      fixed-order sum, L1 normalise  -> w[M][L] fp32 holding dtype-representable values.
-//   2. region_partial_kernel : grid (row slabs x channel slabs); each thread streams 16-byte channel
-//      chunks of its rows and keeps M x 8 fp32 accumulators; in-block fixed-order reduce.
-//   3. region_final_kernel   : fixed-order sum over slabs, round to dtype.
+// read exactly once for ALL M masks.  Two launches (round 3; three before), no float atomics, every sum in a fixed order:
+//   1. region_resample_kernel : grid (position slabs, masks), one thread per feature position: bilinear resample of the mask
+//      to the feature grid (PyTorch's upsample_bilinear2d index math, align_corners = False, no antialias), rounded to the
+//      feature dtype -> v[M][L]; the block's fixed-order partial sum -> psum[M][slabs].  Also re-arms launch 2's tickets.
+//   2. region_pool_kernel     : grid (row slabs x channel slabs).  Prologue: denominators from psum (fixed order, + 1e-8, the
+//      feature dtype's roundings), the slab's L1-normalised weights rnd(v / denorm) into LDS.  Main loop: every thread
+//      streams 16-byte channel chunks of its rows, 8 independent loads in flight, M x 8 fp32 accumulators; in-block
+//      fixed-order reduce (cross-lane inside the wave, LDS across waves); the slab's partial is published write-through and an
+//      arrival ticket per channel slab drawn: the block that arrives last sums the row slabs' partials IN SLAB ORDER, rounds
+//      and stores (the result does not depend on which block came last).
 #include "common.h"
 
 namespace {
 
-constexpr int RP_ROWS = 128;   // feature rows per block
-constexpr int RP_CHUNKS = 48;  // 16-byte channel chunks per block
-constexpr int RP_RG = 5;       // row groups per block (48 * 5 = 240 of 256 threads)
-constexpr int RP_MAXM = 16;    // masks per launch
+constexpr int RP_CL = 8;                  // 16-byte channel chunks per block (one 128-byte line per row)
+constexpr int RP_RG = 30;                 // row groups per block (8 * 30 = 240 of 256 threads)
+constexpr int RP_RPT = 8;                 // rows per thread: independent 16-byte loads in flight (two batches of 4 for 16 masks)
+constexpr int RP_ROWS = RP_RG * RP_RPT;   // 240 feature rows per block: ~880 blocks at 108 x 108 x 1152 -- several per CU, so
+                                          // one block's reduce / publish tail hides under the others' streaming
+constexpr int RP_POS = 1024;              // positions per block of the resample launch
+constexpr int RP_MAXM = 16;               // masks per launch
 
 struct Idx {
   int i0, i1;
@@ -39,23 +45,26 @@ __device__ __forceinline__ Idx src_index(float rscale, int dst, int n_in) {
 // (mm_utils.py:477-532: cv2.resize(..., INTER_NEAREST), then the processor with rescale 1.0 -> float(uint8)); the bilinear taps
 // read THROUGH the tables, so the nearest resize, the float conversion and the resample are one pass over the raw bytes.
 template <typename T, typename MT, bool RAW>
-__global__ __launch_bounds__(1024) void region_weights_kernel(const MT* __restrict__ masks, float* __restrict__ w,
-                                                              int mh, int mw, int fw, float rscale_h, float rscale_w,
-                                                              const int* __restrict__ ys, const int* __restrict__ xs, int rh,
-                                                              int rw) {
+__global__ __launch_bounds__(RP_POS) void region_resample_kernel(const MT* __restrict__ masks, float* __restrict__ v,
+                                                                 float* __restrict__ psum, int* __restrict__ tickets,
+                                                                 int n_tickets, int mh, int mw, int fw, float rscale_h,
+                                                                 float rscale_w, const int* __restrict__ ys,
+                                                                 const int* __restrict__ xs, int rh, int rw) {
   __shared__ float red[16];
-  const int m = blockIdx.x;
+  const int m = blockIdx.y, slab = blockIdx.x;
   const MT* mk = masks + (size_t)m * (RAW ? (size_t)rh * rw : (size_t)mh * mw);
-  float* wm = w + (size_t)m * fw * fw;
   const int L = fw * fw;
-  float s = 0.f;
+  if (m == 0 && slab == 0)
+    for (int i = threadIdx.x; i < n_tickets; i += blockDim.x) tickets[i] = 0;  // launch 2 runs behind this one on the stream
   auto at = [&](int yy, int xx) -> float {
     if constexpr (RAW)
       return (float)mk[(size_t)ys[yy] * rw + xs[xx]];  // float(uint8), as the processor with rescale_factor 1.0 produces
     else
       return to_f(mk[(size_t)yy * mw + xx]);
   };
-  for (int l = threadIdx.x; l < L; l += blockDim.x) {
+  const int l = slab * RP_POS + threadIdx.x;
+  float val = 0.f;
+  if (l < L) {
     const int oy = l / fw, ox = l - oy * fw;
     const Idx y = src_index(rscale_h, oy, mh), x = src_index(rscale_w, ox, mw);
     const float v00 = at(y.i0, x.i0), v01 = at(y.i0, x.i1);
@@ -63,74 +72,120 @@ __global__ __launch_bounds__(1024) void region_weights_kernel(const MT* __restri
     // explicit fused steps: every instantiation (float / bf16 / raw uint8 masks) rounds the same way, whatever the
     // compiler's contraction choices would have been
     const float top = fmaf(x.l1, v01, x.l0 * v00), bot = fmaf(x.l1, v11, x.l0 * v10);
-    const float v = rnd<T>(fmaf(y.l1, bot, y.l0 * top));  // .to(x.dtype)
-    wm[l] = v;
-    s += v;
+    val = rnd<T>(fmaf(y.l1, bot, y.l0 * top));  // .to(x.dtype)
+    v[(size_t)m * L + l] = val;
   }
-  const float denorm = rnd<T>(rnd<T>(block_sum(s, red)) + 1e-8f);  // mask.sum() + 1e-8 in the feature dtype
-  for (int l = threadIdx.x; l < L; l += blockDim.x) wm[l] = rnd<T>(wm[l] / denorm);
+  const float t = block_sum(val, red);
+  if (threadIdx.x == 0) psum[(size_t)m * gridDim.x + slab] = t;
 }
 
 template <typename T, int MM>
-__global__ __launch_bounds__(256) void region_partial_kernel(const T* __restrict__ feat, const float* __restrict__ w,
-                                                             float* __restrict__ partial, int M, int L, int C) {
+__global__ __launch_bounds__(256, MM <= 8 ? 4 : 2) void region_pool_kernel(const T* __restrict__ feat, const float* __restrict__ v,
+                                                          const float* __restrict__ psum, int n_psum,
+                                                          float* __restrict__ partial, int* __restrict__ tickets,
+                                                          T* __restrict__ out, int M, int L, int C) {
   constexpr int VEC = Vec16<T>::N;
-  __shared__ float ws[MM][RP_ROWS];
-  __shared__ float red[RP_RG][RP_CHUNKS * 8];
-  const int slab = blockIdx.x, l0 = slab * RP_ROWS;
+  constexpr int CW = RP_CL * VEC;  // channels per block
+  constexpr int RP_UN = MM <= 8 ? 8 : 4, RP_NB = RP_RPT / RP_UN;  // 16 masks: 128 accumulators, fewer rows in flight
+  __shared__ float wsm[MM][RP_ROWS];
+  __shared__ float den[MM];
+  __shared__ float red[4][MM][CW];
+  __shared__ int last;
+  const int slab = blockIdx.x, l0 = slab * RP_ROWS, nslab = gridDim.x;
   const int nrows = min(RP_ROWS, L - l0);
-  const int tid = threadIdx.x;
-  for (int i = tid; i < MM * RP_ROWS; i += 256) {
-    const int m = i / RP_ROWS, r = i - m * RP_ROWS;
-    ws[m][r] = (m < M && r < nrows) ? w[(size_t)m * L + l0 + r] : 0.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cl = tid % RP_CL, rg = tid / RP_CL;
+  const int chunk = blockIdx.y * RP_CL + cl;
+  const bool active = rg < RP_RG && chunk * VEC < C;
+  // ---- the feature rows of the first batch go out before the prologue touches anything else (row index clamped, never branched)
+  const T* fbase = feat + (size_t)(active ? chunk : 0) * VEC;
+  Vec16<T> f[RP_UN];
+  auto issue = [&](int batch) {
+#pragma unroll
+    for (int u = 0; u < RP_UN; ++u) {
+      const int r = min(l0 + (batch * RP_UN + u) * RP_RG + min(rg, RP_RG - 1), L - 1);
+      f[u] = *reinterpret_cast<const Vec16<T>*>(fbase + (size_t)r * C);
+    }
+  };
+  issue(0);
+  // ---- prologue: mask.sum() + 1e-8 in the feature dtype (fixed slab order), then the slab's normalised weights ----
+  if (tid < MM) {
+    float sden = 0.f;
+    if (tid < M)
+      for (int i = 0; i < n_psum; ++i) sden += psum[(size_t)tid * n_psum + i];
+    den[tid] = rnd<T>(rnd<T>(sden) + 1e-8f);
   }
   __syncthreads();
-  const int cl = tid % RP_CHUNKS, rg = tid / RP_CHUNKS;
-  const int chunk = blockIdx.y * RP_CHUNKS + cl;
-  const bool active = rg < RP_RG && chunk * VEC < C;
+  for (int i = tid; i < MM * RP_ROWS; i += 256) {
+    const int m = i / RP_ROWS, r = i - m * RP_ROWS;
+    wsm[m][r] = (m < M && r < nrows) ? rnd<T>(v[(size_t)m * L + l0 + r] / den[m]) : 0.f;  // mask / denorm, in the feature dtype
+  }
+  __syncthreads();
   float acc[MM][VEC];
 #pragma unroll
   for (int m = 0; m < MM; ++m)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[m][i] = 0.f;
-  if (active) {
-    for (int r = rg; r < nrows; r += RP_RG) {
-      const Vec16<T> f = *reinterpret_cast<const Vec16<T>*>(feat + (size_t)(l0 + r) * C + (size_t)chunk * VEC);
+#pragma unroll
+  for (int b = 0; b < RP_NB; ++b) {
+#pragma unroll
+    for (int u = 0; u < RP_UN; ++u) {
+      const int r = (b * RP_UN + u) * RP_RG + min(rg, RP_RG - 1);  // rows past the slab's end carry weight 0
 #pragma unroll
       for (int m = 0; m < MM; ++m) {
-        const float wv = ws[m][r];
+        const float wv = wsm[m][r];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[m][i] = fmaf(wv, f.get(i), acc[m][i]);
+        for (int i = 0; i < VEC; ++i) acc[m][i] = fmaf(wv, f[u].get(i), acc[m][i]);
       }
     }
+    if (b + 1 < RP_NB) issue(b + 1);
   }
-  // fixed-order reduce over the row groups, one mask at a time
-  for (int m = 0; m < MM; ++m) {
-    __syncthreads();
-    if (rg < RP_RG)
+  // ---- fixed-order reduce: the 8 row groups of a wave on the VALU (lanes of equal chunk: stride 8), the waves through LDS ----
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) red[rg][cl * VEC + i] = acc[m][i];
-    __syncthreads();
-    if (m < M)
-      for (int j = tid; j < RP_CHUNKS * VEC; j += 256) {
-        const int c = blockIdx.y * RP_CHUNKS * VEC + j;
-        if (c < C) {
-          float t = 0.f;
+  for (int m = 0; m < MM; ++m)
 #pragma unroll
-          for (int g = 0; g < RP_RG; ++g) t += red[g][j];
-          partial[((size_t)slab * M + m) * C + c] = t;
-        }
+    for (int i = 0; i < VEC; ++i) {
+      const float a = (rg < RP_RG) ? acc[m][i] : 0.f;
+      const float t = strided_sum<RP_CL>(a);
+      if (lane < RP_CL) red[wave][m][lane * VEC + i] = t;
+    }
+  __syncthreads();
+  const int c0 = blockIdx.y * CW;
+  for (int j = tid; j < M * CW; j += 256) {
+    const int m = j / CW, c = j - m * CW;
+    if (c0 + c < C) {
+      const float t = ((red[0][m][c] + red[1][m][c]) + red[2][m][c]) + red[3][m][c];
+      // write-through: whichever block of this channel slab arrives last reads every slab's partial
+      __hip_atomic_store(partial + ((size_t)slab * M + m) * C + c0 + c, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // ---- arrival ticket of the channel slab; the last arriver sums the row slabs in slab order and stores ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(tickets + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (t == nslab - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last) return;
+  for (int j = tid; j < M * CW; j += 256) {
+    const int m = j / CW, c = j - m * CW;
+    if (c0 + c < C) {
+      // slab order, 16 loads in flight at a time (a chain of dependent L2-bypassing loads cost ~1 us per slab)
+      float t = 0.f;
+      for (int s0 = 0; s0 < nslab; s0 += 16) {
+        float pv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          pv[q] = __hip_atomic_load(partial + ((size_t)min(s0 + q, nslab - 1) * M + m) * C + c0 + c, __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += (s0 + q < nslab) ? pv[q] : 0.f;
       }
+      out[(size_t)m * C + c0 + c] = from_f<T>(t);
+    }
   }
-}
-
-template <typename T>
-__global__ void region_final_kernel(const float* __restrict__ partial, T* __restrict__ out, int nslab, int MC) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= MC) return;
-  float t = 0.f;
-  for (int s = 0; s < nslab; ++s) t += partial[(size_t)s * MC + i];
-  out[i] = from_f<T>(t);
+  if (tid == 0) __hip_atomic_store(tickets + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // AdaptiveAvgPool2d(out_w) on a channels-last [n, in_w, in_w, C] map -> [n, out_w*out_w, C]
@@ -218,10 +273,28 @@ __global__ void vit_assemble_cls_kernel(const T* __restrict__ patches, const T* 
 
 }  // namespace
 
+// workspace layout (floats): v [M, L] | psum [M, ceil(L / 1024)] | partial [row slabs, M, C] | tickets (ints) [channel slabs]
+struct RegionWs {
+  size_t v, psum, partial, tickets, total;
+  int n_psum, nslab, ncslab_max;
+};
+static RegionWs region_ws(int M, int fw, int C) {
+  RegionWs r;
+  const size_t L = (size_t)fw * fw;
+  r.n_psum = (int)((L + RP_POS - 1) / RP_POS);
+  r.nslab = (int)((L + RP_ROWS - 1) / RP_ROWS);
+  r.ncslab_max = (C / 4 + RP_CL - 1) / RP_CL;  // fp32 features: 4 channels per 16-byte chunk (bf16 needs half as many)
+  r.v = 0;
+  r.psum = r.v + (size_t)M * L;
+  r.partial = r.psum + (size_t)M * r.n_psum;
+  r.tickets = r.partial + (size_t)r.nslab * M * C;
+  r.total = r.tickets + (size_t)r.ncslab_max;
+  return r;
+}
+
 extern "C" int64_t srgpt_region_pool_ws_floats(int M, int fw, int C) {
-  const int64_t L = (int64_t)fw * fw;
-  const int64_t nslab = (L + RP_ROWS - 1) / RP_ROWS;
-  return (int64_t)M * L + nslab * M * C;
+  if (M <= 0 || fw <= 0 || C <= 0) return -1;
+  return (int64_t)region_ws(M, fw, C).total;
 }
 
 static int region_pool_impl(const void* feat, const void* masks, void* out, float* ws, int M, int mh, int mw, int fw, int C,
@@ -236,33 +309,33 @@ static int region_pool_impl(const void* feat, const void* masks, void* out, floa
   SRGPT_CHECK(C % vec == 0, SRGPT_ERR_ARG, "srgpt_region_pool: C=%d must be a multiple of %d", C, vec);
   SRGPT_CHECK(dtype == SRGPT_BF16 || dtype == SRGPT_F32, SRGPT_ERR_ARG, "srgpt_region_pool: bad dtype");
   hipStream_t s = as_stream(stream);
-  const int L = fw * fw, nslab = cdiv(L, RP_ROWS);
-  float* w = ws;
-  float* partial = ws + (size_t)M * L;
-  dim3 pgrid(nslab, cdiv(C / vec, RP_CHUNKS));
-#define RW(TT, MT, RAWV)                                                                                                   \
-  hipLaunchKernelGGL((region_weights_kernel<TT, MT, RAWV>), dim3(M), dim3(1024), 0, s, (const MT*)masks, w, mh, mw, fw,    \
-                     rscale_h, rscale_w, ys, xs, rh, rw)
+  const int L = fw * fw;
+  const RegionWs lay = region_ws(M, fw, C);
+  float* v = ws + lay.v;
+  float* psum = ws + lay.psum;
+  float* partial = ws + lay.partial;
+  int* tickets = reinterpret_cast<int*>(ws + lay.tickets);
+  const int ncslab = cdiv(C / vec, RP_CL);
+  dim3 rgrid(lay.n_psum, M), pgrid(lay.nslab, ncslab);
+#define RW(TT, MT, RAWV)                                                                                                       \
+  hipLaunchKernelGGL((region_resample_kernel<TT, MT, RAWV>), rgrid, dim3(RP_POS), 0, s, (const MT*)masks, v, psum, tickets,    \
+                     lay.ncslab_max, mh, mw, fw, rscale_h, rscale_w, ys, xs, rh, rw)
+#define RP(TT, MMV)                                                                                                    \
+  hipLaunchKernelGGL((region_pool_kernel<TT, MMV>), pgrid, dim3(256), 0, s, (const TT*)feat, v, psum, lay.n_psum, partial, \
+                     tickets, (TT*)out, M, L, C)
   if (dtype == SRGPT_BF16) {
     if (raw) RW(bf16_t, unsigned char, true);
     else if (mask_dtype == SRGPT_BF16) RW(bf16_t, bf16_t, false);
     else RW(bf16_t, float, false);
-    if (M <= 8)
-      hipLaunchKernelGGL((region_partial_kernel<bf16_t, 8>), pgrid, dim3(256), 0, s, (const bf16_t*)feat, w, partial, M, L, C);
-    else
-      hipLaunchKernelGGL((region_partial_kernel<bf16_t, 16>), pgrid, dim3(256), 0, s, (const bf16_t*)feat, w, partial, M, L, C);
-    hipLaunchKernelGGL(region_final_kernel<bf16_t>, dim3(cdiv(M * C, 256)), dim3(256), 0, s, partial, (bf16_t*)out, nslab, M * C);
+    if (M <= 8) RP(bf16_t, 8); else RP(bf16_t, 16);
   } else {
     if (raw) RW(float, unsigned char, true);
     else if (mask_dtype == SRGPT_BF16) RW(float, bf16_t, false);
     else RW(float, float, false);
-    if (M <= 8)
-      hipLaunchKernelGGL((region_partial_kernel<float, 8>), pgrid, dim3(256), 0, s, (const float*)feat, w, partial, M, L, C);
-    else
-      hipLaunchKernelGGL((region_partial_kernel<float, 16>), pgrid, dim3(256), 0, s, (const float*)feat, w, partial, M, L, C);
-    hipLaunchKernelGGL(region_final_kernel<float>, dim3(cdiv(M * C, 256)), dim3(256), 0, s, partial, (float*)out, nslab, M * C);
+    if (M <= 8) RP(float, 8); else RP(float, 16);
   }
 #undef RW
+#undef RP
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }

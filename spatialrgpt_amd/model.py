@@ -232,8 +232,15 @@ class LlavaLlamaModel:
         return self.llm
 
     def get_lm_head(self):
+        """the lm_head weight [vocab, hidden] (llava_arch.py accessors).  With fp8 LLM weights the bf16 matrix does not exist in HBM
+        (the fp8 bytes are the only copy): it is rebuilt ONCE on first use (1 GB at 128k x 4096) and kept -- callers that poll the
+        accessor must not allocate a fresh gigabyte per call."""
         w = self.engine.w
-        return w.lm_head if w.lm_head is not None else w.dequantised("lm_head")
+        if w.lm_head is not None:
+            return w.lm_head
+        if getattr(self, "_lm_head_dequantised", None) is None:
+            self._lm_head_dequantised = w.dequantised("lm_head")
+        return self._lm_head_dequantised
 
     def get_vision_tower(self):
         return self.vision_tower

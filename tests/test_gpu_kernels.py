@@ -327,13 +327,18 @@ def test_attention_packed_qkv_and_kvlen():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("B,Hq,Hkv,D,P", [(1, 32, 8, 128, 300), (2, 4, 2, 16, 0), (1, 8, 8, 64, 17), (1, 20, 20, 128, 700),
-                                          (3, 8, 1, 32, 129)])
-def test_rope_append_and_decode_attention(dtype, B, Hq, Hkv, D, P):
+@pytest.mark.parametrize("B,Hq,Hkv,D,P,max_pos", [
+    (1, 32, 8, 128, 300, 1024), (2, 4, 2, 16, 0, 1024), (1, 8, 8, 64, 17, 1024), (1, 20, 20, 128, 700, 1024), (3, 8, 1, 32, 129, 1024),
+    # head_dim 128 in bf16 = the MFMA decode kernel (16-key fragments, 64 keys per block): empty cache, a single cached key, the
+    # 16- / 64-key group edges, every GQA ratio it is instantiated for, a batch, the benchmark's cache (512: 8 splits), and a cache
+    # beyond 64 x 64 positions where every wave walks more than one key group (online rescale of the running P.V)
+    (1, 4, 4, 128, 0, 512), (1, 4, 4, 128, 1, 512), (2, 8, 4, 128, 15, 512), (1, 8, 4, 128, 16, 512), (1, 32, 8, 128, 63, 512),
+    (1, 32, 8, 128, 64, 512), (3, 32, 8, 128, 259, 512), (1, 16, 2, 128, 386, 512), (1, 32, 8, 128, 511, 512),
+    (1, 8, 2, 128, 5000, 8192), (2, 4, 4, 128, 8000, 8192)])
+def test_rope_append_and_decode_attention(dtype, B, Hq, Hkv, D, P, max_pos):
     """prefill RoPE+append of P tokens, then one decode step; both against the oracle's rotary + softmax."""
     from oracle import srgpt_oracle as so
     ops, L = _ops()
-    max_pos = 1024
     QW = (Hq + 2 * Hkv) * D
     cfg = so.SrgptConfig(hidden=Hq * D, heads=Hq, kv_heads=Hkv, rope_theta=10000.0)
     from spatialrgpt_amd.weights import rope_tables
