@@ -90,7 +90,11 @@ int srgpt_gemm_w8(const void* A, const void* W8, const float* wscale, const void
  * srgpt_gemm_w8a8: C[M,N] = ( (A8[M,K] @ W8[N,K]^T) * ascale[m] * wscale[n] + bias[n] ) + residual[M,N], fp32 accumulation of
  *   exact e4m3 x e4m3 products, bias / residual / C bf16 (C fp32 if out_f32) with srgpt_gemm's rounding points (the product is
  *   rounded to bf16 before the residual is added): the GEMM of the dequantised operands up to the order of the fp32 sum.  K % 128 == 0, K >= 256, lda % 16 == 0, 16-byte aligned operands; anything else
- *   returns SRGPT_ERR_UNSUPPORTED (no fallback).  ws: optional fp32 split-K workspace (srgpt_gemm_ws_bytes). */
+ *   returns SRGPT_ERR_UNSUPPORTED (no fallback).  ws: optional fp32 split-K workspace (srgpt_gemm_ws_bytes).
+ *   Scales: srgpt_quant_rows_e4m3 and the weight quantiser produce POWERS OF TWO, for which scaling commutes exactly with the
+ *   fp32 sums; arbitrary fp32 scales are accepted, but the split-K path then scales the per-split slabs by ascale before the
+ *   reduction and the un-split path after the whole sum -- results stay deterministic for a given (shape, device, ws_bytes),
+ *   yet differ by fp32 roundings between the two paths.  Callers that need path-independent bits pass power-of-two scales. */
 int srgpt_quant_rows_e4m3(const void* x, void* q, float* scale, int M, int K, int ldx, srgpt_stream_t stream);
 int srgpt_gemm_w8a8(const void* A8, const float* ascale, const void* W8, const float* wscale, const void* bias,
                     const void* residual, void* C, int M, int N, int K, int lda, int ldc, int out_f32, void* ws,

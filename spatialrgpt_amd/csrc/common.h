@@ -244,6 +244,7 @@ struct SrgptPrefetch {
   int gemv_grid;         // compute blocks the next GEMV launches
   int rounds;            // how many of a wave's units to pull
   int nblocks;           // prefetch blocks appended to this launch (= gemv_grid)
+  int n_rows;            // rows of the matrix: the row index is clamped (fp8 column pairs of an odd N would touch row N)
   int batch;             // 1-KiB loads a wave keeps in flight (1: one at a time -- the trickle that leaves the host launch's own
                          // loads alone; 2 / 4 / 8: faster, at the price of queueing in front of them)
 };
@@ -254,7 +255,8 @@ __device__ __forceinline__ void srgpt_prefetch_rows(const SrgptPrefetch& pf, int
   int done = 0;
   for (int u = p * 4 + wave; u < pf.n_units && done < pf.rounds; u += pf.gemv_grid * 4, ++done)
     for (int r = 0; r < pf.unit_rows; ++r) {
-      const char* row = pf.base + (size_t)((long long)u * pf.umul + (long long)r * pf.rstride) * pf.row_bytes + lane * 16;
+      const long long ri = min((long long)u * pf.umul + (long long)r * pf.rstride, (long long)pf.n_rows - 1);
+      const char* row = pf.base + (size_t)ri * pf.row_bytes + lane * 16;
       for (int c0 = 0; c0 < per_row; c0 += NB) {
         u32x4 v[NB];
 #pragma unroll
@@ -281,7 +283,7 @@ extern "C" int srgpt_device_cus(void);
 // 16-row units, was measured: o_proj +1 % at 8 fp8 rows, -2 % at 4 bf16 rows per decode step, not kept).
 static inline SrgptPrefetch srgpt_prefetch_for_gemv(const void* W, int N, int K, int swiglu, int fp8, int batch, int rounds,
                                                     int prefix_bytes) {
-  SrgptPrefetch pf{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1};
+  SrgptPrefetch pf{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1, 1};
   const long long row_bytes = fp8 ? (long long)K : 2LL * K;
   if (!W || batch > 2 || rounds <= 0 || row_bytes % 1024 != 0 || (fp8 && swiglu)) return pf;
   const int cus = srgpt_device_cus();
@@ -298,6 +300,7 @@ static inline SrgptPrefetch srgpt_prefetch_for_gemv(const void* W, int N, int K,
   pf.gemv_grid = grid;
   pf.rounds = rounds;
   pf.nblocks = grid;
-  pf.batch = SRGPT_KNOB("SRGPT_DECODE_PREFETCH_BATCH", 1);
+  pf.n_rows = swiglu ? 2 * N : N;
+  pf.batch = SRGPT_KNOB("SRGPT_DECODE_PREFETCH_BATCH", 2);  // measured 1 / 2 / 4 / 8: 3.016 / 2.948 / 2.986 / 3.000 ms per token (profiles/r03_decode_attention.txt)
   return pf;
 }

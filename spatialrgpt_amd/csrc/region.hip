@@ -89,13 +89,16 @@ __global__ __launch_bounds__(256, MM <= 8 ? 4 : 2) void region_pool_kernel(const
   constexpr int RP_UN = MM <= 8 ? 8 : 4, RP_NB = RP_RPT / RP_UN;  // 16 masks: 128 accumulators, fewer rows in flight
   __shared__ float wsm[MM][RP_ROWS];
   __shared__ float den[MM];
+  __shared__ float psl[MM][32];
   __shared__ float red[4][MM][CW];
   __shared__ int last;
-  const int slab = blockIdx.x, l0 = slab * RP_ROWS, nslab = gridDim.x;
+  // channel slab = the FAST grid index: the blocks that run together cover whole feature rows (contiguous 2304-byte rows, open
+  // DRAM pages used in full) instead of one 128-byte line out of every row
+  const int slab = blockIdx.y, l0 = slab * RP_ROWS, nslab = gridDim.y, cslab = blockIdx.x;
   const int nrows = min(RP_ROWS, L - l0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cl = tid % RP_CL, rg = tid / RP_CL;
-  const int chunk = blockIdx.y * RP_CL + cl;
+  const int chunk = cslab * RP_CL + cl;
   const bool active = rg < RP_RG && chunk * VEC < C;
   // ---- the feature rows of the first batch go out before the prologue touches anything else (row index clamped, never branched)
   const T* fbase = feat + (size_t)(active ? chunk : 0) * VEC;
@@ -109,12 +112,22 @@ __global__ __launch_bounds__(256, MM <= 8 ? 4 : 2) void region_pool_kernel(const
   };
   issue(0);
   // ---- prologue: mask.sum() + 1e-8 in the feature dtype (fixed slab order), then the slab's normalised weights ----
-  if (tid < MM) {
-    float sden = 0.f;
-    if (tid < M)
-      for (int i = 0; i < n_psum; ++i) sden += psum[(size_t)tid * n_psum + i];
-    den[tid] = rnd<T>(rnd<T>(sden) + 1e-8f);
+  // (the resample launch's per-slab sums are fetched by 32 threads per mask at once and added in slab order from LDS: a chain of
+  //  n_psum dependent loads in one thread was ~6 us of every block's prologue)
+  float sden = 0.f;
+  for (int i0 = 0; i0 < n_psum; i0 += 32) {
+    for (int idx = tid; idx < MM * 32; idx += 256) {
+      const int m = idx >> 5, i = i0 + (idx & 31);
+      psl[m][idx & 31] = (m < M && i < n_psum) ? psum[(size_t)m * n_psum + i] : 0.f;
+    }
+    __syncthreads();
+    if (tid < MM) {
+      const int n = min(32, n_psum - i0);
+      for (int i = 0; i < n; ++i) sden += psl[tid][i];
+    }
+    __syncthreads();
   }
+  if (tid < MM) den[tid] = rnd<T>(rnd<T>(sden) + 1e-8f);
   __syncthreads();
   for (int i = tid; i < MM * RP_ROWS; i += 256) {
     const int m = i / RP_ROWS, r = i - m * RP_ROWS;
@@ -150,42 +163,53 @@ __global__ __launch_bounds__(256, MM <= 8 ? 4 : 2) void region_pool_kernel(const
       if (lane < RP_CL) red[wave][m][lane * VEC + i] = t;
     }
   __syncthreads();
-  const int c0 = blockIdx.y * CW;
-  for (int j = tid; j < M * CW; j += 256) {
-    const int m = j / CW, c = j - m * CW;
-    if (c0 + c < C) {
-      const float t = ((red[0][m][c] + red[1][m][c]) + red[2][m][c]) + red[3][m][c];
-      // write-through: whichever block of this channel slab arrives last reads every slab's partial
-      __hip_atomic_store(partial + ((size_t)slab * M + m) * C + c0 + c, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int c0 = cslab * CW;
+  // partials go out WRITE-THROUGH in 16-byte pieces (sc1 buffer stores: a 4-byte write-through store is one fabric write each,
+  // ~6x the time per byte) -- whichever block of this channel slab arrives last reads every slab's partial with sc1 loads
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(partial, 0, (int)((size_t)nslab * M * C * sizeof(float)), 0x00020000);
+  constexpr int CW4 = CW / 4;
+  for (int j = tid; j < M * CW4; j += 256) {
+    const int m = j / CW4, c = 4 * (j - m * CW4);
+    if (c0 + c < C) {  // C % 4 == 0: a group of 4 channels is entirely in or out
+      u32x4 t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        t[q] = __float_as_uint(((red[0][m][c + q] + red[1][m][c + q]) + red[2][m][c + q]) + red[3][m][c + q]);
+      __builtin_amdgcn_raw_buffer_store_b128(t, prs, (int)((((size_t)slab * M + m) * C + c0 + c) * sizeof(float)), 0, 16);
     }
   }
   // ---- arrival ticket of the channel slab; the last arriver sums the row slabs in slab order and stores ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    const int t = __hip_atomic_fetch_add(tickets + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int t = __hip_atomic_fetch_add(tickets + cslab, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = (t == nslab - 1) ? 1 : 0;
   }
   __syncthreads();
   if (!last) return;
-  for (int j = tid; j < M * CW; j += 256) {
-    const int m = j / CW, c = j - m * CW;
+  for (int j = tid; j < M * CW4; j += 256) {
+    const int m = j / CW4, c = 4 * (j - m * CW4);
     if (c0 + c < C) {
       // slab order, 16 loads in flight at a time (a chain of dependent L2-bypassing loads cost ~1 us per slab)
-      float t = 0.f;
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
       for (int s0 = 0; s0 < nslab; s0 += 16) {
-        float pv[16];
+        u32x4 pv[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-          pv[q] = __hip_atomic_load(partial + ((size_t)min(s0 + q, nslab - 1) * M + m) * C + c0 + c, __ATOMIC_RELAXED,
-                                    __HIP_MEMORY_SCOPE_AGENT);
+          pv[q] = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)((((size_t)min(s0 + q, nslab - 1) * M + m) * C + c0 + c) * sizeof(float)),
+                                                        0, 16);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t += (s0 + q < nslab) ? pv[q] : 0.f;
+        for (int q = 0; q < 16; ++q)
+          if (s0 + q < nslab) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] += __uint_as_float(pv[q][e]);
+          }
       }
-      out[(size_t)m * C + c0 + c] = from_f<T>(t);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[(size_t)m * C + c0 + c + e] = from_f<T>(t[e]);
     }
   }
-  if (tid == 0) __hip_atomic_store(tickets + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(tickets + cslab, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // AdaptiveAvgPool2d(out_w) on a channels-last [n, in_w, in_w, C] map -> [n, out_w*out_w, C]
@@ -286,7 +310,7 @@ static RegionWs region_ws(int M, int fw, int C) {
   r.ncslab_max = (C / 4 + RP_CL - 1) / RP_CL;  // fp32 features: 4 channels per 16-byte chunk (bf16 needs half as many)
   r.v = 0;
   r.psum = r.v + (size_t)M * L;
-  r.partial = r.psum + (size_t)M * r.n_psum;
+  r.partial = (r.psum + (size_t)M * r.n_psum + 3) & ~(size_t)3;  // 16-byte pieces
   r.tickets = r.partial + (size_t)r.nslab * M * C;
   r.total = r.tickets + (size_t)r.ncslab_max;
   return r;
@@ -316,7 +340,7 @@ static int region_pool_impl(const void* feat, const void* masks, void* out, floa
   float* partial = ws + lay.partial;
   int* tickets = reinterpret_cast<int*>(ws + lay.tickets);
   const int ncslab = cdiv(C / vec, RP_CL);
-  dim3 rgrid(lay.n_psum, M), pgrid(lay.nslab, ncslab);
+  dim3 rgrid(lay.n_psum, M), pgrid(ncslab, lay.nslab);
 #define RW(TT, MT, RAWV)                                                                                                       \
   hipLaunchKernelGGL((region_resample_kernel<TT, MT, RAWV>), rgrid, dim3(RP_POS), 0, s, (const MT*)masks, v, psum, tickets,    \
                      lay.ncslab_max, mh, mw, fw, rscale_h, rscale_w, ys, xs, rh, rw)

@@ -42,7 +42,7 @@ FLOOR_STEPS = 6        # decode steps of the fp32 noise-floor run (the floor is 
 FLOOR_ROWS = 2         # batch rows of the fp32 noise-floor run
 MARGIN_OVER_FLOOR = 10.0
 LOGIT_MAX_CAP, LOGIT_RMS_CAP = 0.15, 2.5e-2
-THREADS = 32
+THREADS = 16  # torch CPU bf16 matmuls are fastest at 16 threads on the 256-core bench host (scripts/cpu_probe.py)
 
 
 class _Bundle:
