@@ -18,11 +18,12 @@ namespace {
 
 constexpr int RP_CL = 8;                  // 16-byte channel chunks per block (one 128-byte line per row)
 constexpr int RP_RG = 30;                 // row groups per block (8 * 30 = 240 of 256 threads)
-constexpr int RP_RPT = 8;                 // rows per thread: independent 16-byte loads in flight (two batches of 4 for 16 masks)
-constexpr int RP_ROWS = RP_RG * RP_RPT;   // 240 feature rows per block: ~880 blocks at 108 x 108 x 1152 -- several per CU, so
-                                          // one block's reduce / publish tail hides under the others' streaming
+constexpr int RP_RPT = 10;                // rows per thread: independent 16-byte loads in flight
+constexpr int RP_ROWS = RP_RG * RP_RPT;   // 300 feature rows per block: 39 x 18 = 702 blocks at 108 x 108 x 1152 -- all resident at
+                                          // 3 blocks per CU (168 registers: at 128 the accumulators spilled and the reduce crawled)
 constexpr int RP_POS = 1024;              // positions per block of the resample launch
 constexpr int RP_MAXM = 16;               // masks per launch
+constexpr int RP_FB = 16;                 // partials the last arriver keeps in flight (25 cost registers: 3 blocks per CU instead of 4)
 
 struct Idx {
   int i0, i1;
@@ -79,18 +80,30 @@ __global__ __launch_bounds__(RP_POS) void region_resample_kernel(const MT* __res
   if (threadIdx.x == 0) psum[(size_t)m * gridDim.x + slab] = t;
 }
 
+#ifdef SRGPT_TUNING_KNOBS
+// phase stamps (tuning build; scripts/ubench_region_stamps.py): block (0, 0) -> slots 0..15, the last arriver of channel slab 0 -> 16..
+__device__ unsigned long long srgpt_region_stamps[32];
+#define RP_STAMP(i) do { if (stamp_base >= 0 && threadIdx.x == 0) srgpt_region_stamps[stamp_base + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RP_STAMP(i) do { } while (0)
+#endif
+
 template <typename T, int MM>
-__global__ __launch_bounds__(256, MM <= 8 ? 4 : 2) void region_pool_kernel(const T* __restrict__ feat, const float* __restrict__ v,
+__global__ __launch_bounds__(256, MM <= 8 ? 3 : 2) void region_pool_kernel(const T* __restrict__ feat, const float* __restrict__ v,
                                                           const float* __restrict__ psum, int n_psum,
                                                           float* __restrict__ partial, int* __restrict__ tickets,
                                                           T* __restrict__ out, int M, int L, int C) {
   constexpr int VEC = Vec16<T>::N;
   constexpr int CW = RP_CL * VEC;  // channels per block
-  constexpr int RP_UN = MM <= 8 ? 8 : 4, RP_NB = RP_RPT / RP_UN;  // 16 masks: 128 accumulators, fewer rows in flight
-  __shared__ float wsm[MM][RP_ROWS];
+  constexpr int RP_UN = MM <= 8 ? RP_RPT : RP_RPT / 2, RP_NB = RP_RPT / RP_UN;  // 16 masks: 128 accumulators, two batches of 5 rows
+  // one LDS array, two lives: the slab's weights [MM][RP_ROWS] during the FMAs, then the reduce staging [16][MM * VEC][RP_CL]
+  constexpr int LDS_BIG = (MM * RP_ROWS > 16 * MM * VEC * RP_CL) ? MM * RP_ROWS : 16 * MM * VEC * RP_CL;
+  __shared__ float lds_big[LDS_BIG];
+  float (*wsm)[RP_ROWS] = reinterpret_cast<float (*)[RP_ROWS]>(lds_big);
+  float* rstage = lds_big;
   __shared__ float den[MM];
   __shared__ float psl[MM][32];
-  __shared__ float red[4][MM][CW];
+  __shared__ float red[MM][CW];
   __shared__ int last;
   // channel slab = the FAST grid index: the blocks that run together cover whole feature rows (contiguous 2304-byte rows, open
   // DRAM pages used in full) instead of one 128-byte line out of every row
@@ -100,6 +113,10 @@ __global__ __launch_bounds__(256, MM <= 8 ? 4 : 2) void region_pool_kernel(const
   const int cl = tid % RP_CL, rg = tid / RP_CL;
   const int chunk = cslab * RP_CL + cl;
   const bool active = rg < RP_RG && chunk * VEC < C;
+#ifdef SRGPT_TUNING_KNOBS
+  int stamp_base = (blockIdx.x == 0 && blockIdx.y == 0) ? 0 : -1;
+#endif
+  RP_STAMP(0);
   // ---- the feature rows of the first batch go out before the prologue touches anything else (row index clamped, never branched)
   const T* fbase = feat + (size_t)(active ? chunk : 0) * VEC;
   Vec16<T> f[RP_UN];
@@ -111,6 +128,7 @@ __global__ __launch_bounds__(256, MM <= 8 ? 4 : 2) void region_pool_kernel(const
     }
   };
   issue(0);
+  RP_STAMP(1);
   // ---- prologue: mask.sum() + 1e-8 in the feature dtype (fixed slab order), then the slab's normalised weights ----
   // (the resample launch's per-slab sums are fetched by 32 threads per mask at once and added in slab order from LDS: a chain of
   //  n_psum dependent loads in one thread was ~6 us of every block's prologue)
@@ -129,11 +147,27 @@ __global__ __launch_bounds__(256, MM <= 8 ? 4 : 2) void region_pool_kernel(const
   }
   if (tid < MM) den[tid] = rnd<T>(rnd<T>(sden) + 1e-8f);
   __syncthreads();
-  for (int i = tid; i < MM * RP_ROWS; i += 256) {
-    const int m = i / RP_ROWS, r = i - m * RP_ROWS;
-    wsm[m][r] = (m < M && r < nrows) ? rnd<T>(v[(size_t)m * L + l0 + r] / den[m]) : 0.f;  // mask / denorm, in the feature dtype
+  RP_STAMP(2);
+  {  // mask / denorm in the feature dtype; the thread's v values are requested together (clamped, unconditional), then divided
+    constexpr int NW = (MM * RP_ROWS + 255) / 256;
+    float vv[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int i = min(tid + 256 * q, MM * RP_ROWS - 1);
+      const int m = i / RP_ROWS, r = i - m * RP_ROWS;
+      vv[q] = v[(size_t)min(m, M - 1) * L + min(l0 + r, L - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int i = tid + 256 * q;
+      if (i < MM * RP_ROWS) {
+        const int m = i / RP_ROWS, r = i - m * RP_ROWS;
+        wsm[m][r] = (m < M && r < nrows) ? rnd<T>(vv[q] / den[m]) : 0.f;
+      }
+    }
   }
   __syncthreads();
+  RP_STAMP(3);
   float acc[MM][VEC];
 #pragma unroll
   for (int m = 0; m < MM; ++m)
@@ -153,16 +187,33 @@ __global__ __launch_bounds__(256, MM <= 8 ? 4 : 2) void region_pool_kernel(const
     }
     if (b + 1 < RP_NB) issue(b + 1);
   }
-  // ---- fixed-order reduce: the 8 row groups of a wave on the VALU (lanes of equal chunk: stride 8), the waves through LDS ----
+  RP_STAMP(4);
+  // ---- fixed-order reduce over the block's 30 row groups: the two row groups of a 16-lane row on the VALU (one DPP rotate), the
+  //      16 (wave, row) partials through LDS in ONE round -- the staging array takes over the weights' LDS (dead by now).
+  //      (The same sums as cross-lane v_permlane swaps took 12k cycles for 64 values; two masks per LDS round 6.4k.)
+  constexpr int NVAL = MM * VEC;                 // values per thread
+  __syncthreads();  // every wave is done reading the weights: the array becomes the reduce staging
+  {
+    const int row16 = lane >> 4, l16 = lane & 15;
 #pragma unroll
-  for (int m = 0; m < MM; ++m)
+    for (int m = 0; m < MM; ++m)
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const float a = (rg < RP_RG) ? acc[m][i] : 0.f;
-      const float t = strided_sum<RP_CL>(a);
-      if (lane < RP_CL) red[wave][m][lane * VEC + i] = t;
-    }
+      for (int i = 0; i < VEC; ++i) {
+        float a = (rg < RP_RG) ? acc[m][i] : 0.f;
+        a += dpp_mov<0x128>(a);  // row_ror:8: lanes l and l + 8 of a 16-lane row = the same channel chunk, two row groups
+        if (l16 < RP_CL) rstage[((wave * 4 + row16) * NVAL + m * VEC + i) * RP_CL + l16] = a;
+      }
+  }
   __syncthreads();
+  for (int o = tid; o < NVAL * RP_CL; o += 256) {
+    const int j = o / RP_CL, c8 = o - j * RP_CL;  // value j = (mask j / VEC, element j % VEC) of channel chunk c8
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += rstage[(q * NVAL + j) * RP_CL + c8];  // fixed (wave, row) order
+    red[j / VEC][c8 * VEC + (j % VEC)] = t;
+  }
+  __syncthreads();
+  RP_STAMP(5);
   const int c0 = cslab * CW;
   // partials go out WRITE-THROUGH in 16-byte pieces (sc1 buffer stores: a 4-byte write-through store is one fabric write each,
   // ~6x the time per byte) -- whichever block of this channel slab arrives last reads every slab's partial with sc1 loads
@@ -174,32 +225,39 @@ __global__ __launch_bounds__(256, MM <= 8 ? 4 : 2) void region_pool_kernel(const
       u32x4 t;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        t[q] = __float_as_uint(((red[0][m][c + q] + red[1][m][c + q]) + red[2][m][c + q]) + red[3][m][c + q]);
+        t[q] = __float_as_uint(red[m][c + q]);
       __builtin_amdgcn_raw_buffer_store_b128(t, prs, (int)((((size_t)slab * M + m) * C + c0 + c) * sizeof(float)), 0, 16);
     }
   }
   // ---- arrival ticket of the channel slab; the last arriver sums the row slabs in slab order and stores ----
+  RP_STAMP(6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  RP_STAMP(7);
   if (tid == 0) {
     const int t = __hip_atomic_fetch_add(tickets + cslab, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = (t == nslab - 1) ? 1 : 0;
   }
   __syncthreads();
+  RP_STAMP(8);
   if (!last) return;
+#ifdef SRGPT_TUNING_KNOBS
+  if (cslab == 0) stamp_base = 16;
+#endif
+  RP_STAMP(0);
   for (int j = tid; j < M * CW4; j += 256) {
     const int m = j / CW4, c = 4 * (j - m * CW4);
     if (c0 + c < C) {
-      // slab order, 16 loads in flight at a time (a chain of dependent L2-bypassing loads cost ~1 us per slab)
+      // slab order, RP_FB loads in flight at a time (a chain of dependent L2-bypassing loads cost ~1 us per slab)
       float t[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int s0 = 0; s0 < nslab; s0 += 16) {
-        u32x4 pv[16];
+      for (int s0 = 0; s0 < nslab; s0 += RP_FB) {
+        u32x4 pv[RP_FB];
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
+        for (int q = 0; q < RP_FB; ++q)
           pv[q] = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)((((size_t)min(s0 + q, nslab - 1) * M + m) * C + c0 + c) * sizeof(float)),
                                                         0, 16);
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
+        for (int q = 0; q < RP_FB; ++q)
           if (s0 + q < nslab) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) t[e] += __uint_as_float(pv[q][e]);
@@ -209,6 +267,7 @@ __global__ __launch_bounds__(256, MM <= 8 ? 4 : 2) void region_pool_kernel(const
       for (int e = 0; e < 4; ++e) out[(size_t)m * C + c0 + c + e] = from_f<T>(t[e]);
     }
   }
+  RP_STAMP(1);
   if (tid == 0) __hip_atomic_store(tickets + cslab, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -315,6 +374,12 @@ static RegionWs region_ws(int M, int fw, int C) {
   r.total = r.tickets + (size_t)r.ncslab_max;
   return r;
 }
+
+#ifdef SRGPT_TUNING_KNOBS
+extern "C" int srgpt_region_debug_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(srgpt_region_stamps), sizeof(unsigned long long) * (n < 32 ? n : 32));
+}
+#endif
 
 extern "C" int64_t srgpt_region_pool_ws_floats(int M, int fw, int C) {
   if (M <= 0 || fw <= 0 || C <= 0) return -1;

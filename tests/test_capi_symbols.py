@@ -79,6 +79,6 @@ def test_argument_validation_without_gpu():
     assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
     rc = lib.srgpt_gemm_w8(16, 16, 16, None, None, 16, 4, 4, 72, 64, 4, 0, 0, None, 0, None)  # lda < K
     assert rc == _lib.ERR_ARG and b"lda" in lib.srgpt_last_error()
-    # v [M, L] + psum [M, ceil(L / 1024)] + partials [ceil(L / 240) row slabs, M, C] + one ticket per channel slab (fp32 worst case)
-    assert lib.srgpt_region_pool_ws_floats(8, 108, 1152) == 8 * 11664 + 8 * 12 + 49 * 8 * 1152 + 36
+    # v [M, L] + psum [M, ceil(L / 1024)] + partials [ceil(L / 300) row slabs, M, C] + one ticket per channel slab (fp32 worst case)
+    assert lib.srgpt_region_pool_ws_floats(8, 108, 1152) == 8 * 11664 + 8 * 12 + 39 * 8 * 1152 + 36
     assert lib.srgpt_gemm_ws_bytes(259, 4096) == 8 * 259 * 4096 * 4
