@@ -345,10 +345,10 @@ int srgpt_llm_decode_sync_state(const srgpt_llm_weights* w, const srgpt_llm_stat
 /* first token after prefill: argmax(st->logits) -> tok / out_ids[:,0] / step=1 */
 int srgpt_llm_sample_first(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream);
 
-/* hipGraph capture of one decode step (replayed per token; removes per-launch host cost).  A replay continues from the token the
- * step before it (srgpt_llm_decode_step, srgpt_llm_sample_first or the previous replay) picked: that step already left the token's
- * embedding row in the residual-stream workspace, so the captured step does not embed st->tok again -- to feed a token of your
- * own, set st->tok and call srgpt_llm_decode_step. */
+/* hipGraph capture of one decode step (replayed per token; removes per-launch host cost).  A replay continues from st->tok: normally
+ * the token the step before it (srgpt_llm_decode_step, srgpt_llm_sample_first or the previous replay) picked, whose embedding row
+ * that step already left in the residual-stream workspace; the captured step's first node compares st->tok with the token that row
+ * belongs to and re-embeds when the caller wrote a token of its own into st->tok between replays (ids outside the table are ignored). */
 typedef struct srgpt_graph srgpt_graph;
 int srgpt_llm_decode_graph_create(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream,
                                   srgpt_graph** out);

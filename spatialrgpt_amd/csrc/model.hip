@@ -55,6 +55,7 @@ struct LlmWs {
   size_t gws_bytes;
   float* amax_v;  // [batch, ARGMAX_BLOCKS] partial maxima
   int* amax_i;    // [batch, ARGMAX_BLOCKS] their indices
+  int64_t* tok_emb;  // [batch] the token whose embedding row currently sits in xd (-1: none)
   void* a8;       // fp8_act: the e4m3 bytes of the current GEMM input [rows, max K]
   float* a8s;     // fp8_act: their per-row scales [rows]
   size_t total;
@@ -82,6 +83,7 @@ LlmWs carve_llm(const srgpt_llm_weights* w, int batch, int max_tokens, void* ws)
   l.gws = c.take(l.gws_bytes);
   l.amax_v = reinterpret_cast<float*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
   l.amax_i = reinterpret_cast<int*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
+  l.tok_emb = reinterpret_cast<int64_t*>(c.take((size_t)batch * 8));
   l.a8 = nullptr;
   l.a8s = nullptr;
   if (w->fp8_act) {
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __rest
 constexpr int ADVANCE_MAXB = 256;
 __global__ void advance_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int nb, int64_t* tok,
                                int64_t* out_ids, int* pos, int* step, int B, int max_new, int bump_pos,
-                               const unsigned char* __restrict__ embed, unsigned char* __restrict__ xd, int row_bytes) {
+                               const unsigned char* __restrict__ embed, unsigned char* __restrict__ xd, int row_bytes,
+                               int64_t* __restrict__ tok_emb) {
   __shared__ int picked[ADVANCE_MAXB];
   const int s = *step;
   const int lane = threadIdx.x & 63;
@@ -175,7 +178,10 @@ __global__ void advance_kernel(const float* __restrict__ pv, const int* __restri
     if (lane == 0) {
       const int64_t t = bi == 0x7fffffff ? 0 : bi;
       tok[b] = t;
-      if (embed && b < ADVANCE_MAXB) picked[b] = (int)t;
+      if (embed && b < ADVANCE_MAXB) {
+        picked[b] = (int)t;
+        tok_emb[b] = t;  // the row written below belongs to this token (embed_sync_kernel checks it)
+      }
       if (s < max_new) out_ids[(size_t)b * max_new + s] = t;
       if (bump_pos) pos[b] += 1;
     }
@@ -192,6 +198,24 @@ __global__ void advance_kernel(const float* __restrict__ pv, const int* __restri
   }
 }
 
+// First node of the CAPTURED decode step: xd must hold the embedding rows of st->tok.  Normally advance_kernel of the step before
+// left exactly those rows (tok_emb == tok: B compares, nothing copied); a caller that wrote its own token into st->tok between
+// replays -- valid under ABI 1/2, silently ignored in ABI 3 -- gets its row re-embedded here.
+__global__ void embed_sync_kernel(const int64_t* __restrict__ tok, int64_t* __restrict__ tok_emb,
+                                  const unsigned char* __restrict__ embed, unsigned char* __restrict__ xd, int B, int row_bytes,
+                                  int64_t vocab) {
+  const int per_row = row_bytes >> 4;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const int64_t t = tok[b];
+    if (t == tok_emb[b] || t < 0 || t >= vocab) continue;  // uniform per block
+    for (int c = threadIdx.x; c < per_row; c += blockDim.x)
+      *reinterpret_cast<u32x4*>(xd + (size_t)b * row_bytes + (size_t)c * 16) =
+          *reinterpret_cast<const u32x4*>(embed + (size_t)t * row_bytes + (size_t)c * 16);
+    __syncthreads();
+    if (threadIdx.x == 0) tok_emb[b] = t;
+  }
+}
+
 // the next step's embedding rows can come from advance_kernel when they are whole 16-byte chunks and the batch fits its LDS list
 static inline bool advance_embeds(const srgpt_llm_weights* w, const srgpt_llm_state* st) {
   return st->batch <= ADVANCE_MAXB && ((size_t)w->hidden * dtype_size(w->dtype)) % 16 == 0;
@@ -203,7 +227,7 @@ static int greedy_pick(const srgpt_llm_weights* w, srgpt_llm_state* st, const Ll
   hipLaunchKernelGGL(argmax_partial_kernel, dim3(ARGMAX_BLOCKS, B), dim3(256), 0, s, st->logits, d.amax_v, d.amax_i, w->vocab);
   hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(256), 0, s, d.amax_v, d.amax_i, ARGMAX_BLOCKS, st->tok, st->out_ids,
                      st->pos, st->step, B, st->max_new, bump_pos, emb ? reinterpret_cast<const unsigned char*>(w->embed) : nullptr,
-                     reinterpret_cast<unsigned char*>(d.xd), (int)((size_t)w->hidden * dtype_size(w->dtype)));
+                     reinterpret_cast<unsigned char*>(d.xd), (int)((size_t)w->hidden * dtype_size(w->dtype)), d.tok_emb);
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }
@@ -319,6 +343,8 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
     size_t sync_bytes = 0;
     void* sync = srgpt_decode_attn_sync_words(l.dws, B, Hq, D, &sync_bytes);
     SRGPT_HIP_TRY(hipMemsetAsync(sync, 0, sync_bytes, s), "srgpt_llm_prefill: re-arming the decode tickets");
+    // no embedding row is in place for the new sequences (-1 matches no token id)
+    SRGPT_HIP_TRY(hipMemsetAsync(l.tok_emb, 0xFF, (size_t)B * sizeof(int64_t), s), "srgpt_llm_prefill: resetting the embedded-token record");
   }
   if (hipMemcpyAsync(l.x, inputs_embeds, hid_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
     srgpt_set_error("srgpt_llm_prefill: memcpy failed");
@@ -430,7 +456,14 @@ static int decode_step_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, srg
   hipStream_t s = as_stream(stream);
   const LlmWs d = carve_llm(w, B, st->ws_tokens, st->ws);  // same carve as prefill (sized by ws_tokens)
   const size_t layer_kv = (size_t)B * Hkv * st->max_pos * D * es;
-  if (embed_first) SRGPT_TRY(srgpt_embed_rows(w->embed, st->tok, d.xd, B, Hd, dt, stream));
+  if (embed_first) {
+    SRGPT_TRY(srgpt_embed_rows(w->embed, st->tok, d.xd, B, Hd, dt, stream));
+  } else {  // captured step: one tiny launch that copies nothing unless the caller changed st->tok behind the graph's back
+    hipLaunchKernelGGL(embed_sync_kernel, dim3(B < 64 ? B : 64), dim3(256), 0, s, st->tok, d.tok_emb,
+                       reinterpret_cast<const unsigned char*>(w->embed), reinterpret_cast<unsigned char*>(d.xd), B, (int)((size_t)Hd * es),
+                       (int64_t)w->vocab);
+    SRGPT_LAUNCH_CHECK();
+  }
   // fp8 copies present -> the decode step streams them (W8A16, half the bytes per token)
   const bool w8 = w->wqkv8 != nullptr;
   if (w8)

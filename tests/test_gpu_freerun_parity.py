@@ -3,9 +3,10 @@
 
   configs[1]  VILA1.5-8B geometry, bs = 1, bf16                       (the headline line)
   configs[2]  the same, 4 distinct requests per GPU, bf16              (256^2 GEMM prefill, skinny decode, batched split attention)
+  configs[3]  Llama-2-7B geometry (MHA), 16 regions, 512-id prompt (T = 707), bs = 1, bf16
   configs[4]  fp8 (e4m3) LLM weights, 8 distinct requests per GPU: W8A16 (default) and the opt-in W8A8 prefill
 
-all at FULL depth (32 LLM layers / 26 ViT layers), K = 8 regions, 64-id prompts (T = 259), G = 128 new tokens, through
+all at FULL depth (32 LLM layers / 26 ViT layers), K = 8 regions and 64-id prompts (T = 259) unless stated, G = 128 new tokens, through
 `model.generate` -- i.e. the graph-captured decode loop the benchmark times.
 
 Random N(0, 0.02) weights cannot show free-running id parity: the oracle's own bf16-vs-fp32 noise floor flips its argmax at 16 % of
@@ -48,13 +49,13 @@ THREADS = 16  # torch CPU bf16 matmuls are fastest at 16 threads on the 256-core
 class _Bundle:
     """one set of peaked weights on the GPU + its host copies for the checker (bf16 values; fp32 copy made on demand)"""
 
-    def __init__(self, fmt):
+    def __init__(self, fmt, geom="vila15_8b"):
         from oracle import srgpt_oracle as so
         from spatialrgpt_amd.config import SrgptConfig
         from spatialrgpt_amd.weights import synth_state_dict
 
         self.so = so
-        self.cfg = SrgptConfig.vila15_8b()
+        self.cfg = getattr(SrgptConfig, geom)()
         self.ocfg = so.SrgptConfig(**{k: v for k, v in self.cfg.to_dict().items() if k in so.SrgptConfig.__dataclass_fields__})
         t0 = time.perf_counter()
         sd = synth_state_dict(self.cfg, seed=0, dtype=torch.bfloat16, device=DEV)
@@ -87,16 +88,16 @@ class _Bundle:
 _BUNDLE = {}
 
 
-def _bundle(fmt):
+def _bundle(fmt, geom="vila15_8b"):
     """one bundle alive at a time (16 GB of bf16 + 32 GB of fp32 host copies each)"""
-    if fmt not in _BUNDLE:
+    if (fmt, geom) not in _BUNDLE:
         _BUNDLE.clear()
         import gc
 
         gc.collect()
         torch.cuda.empty_cache()
-        _BUNDLE[fmt] = _Bundle(fmt)
-    return _BUNDLE[fmt]
+        _BUNDLE[(fmt, geom)] = _Bundle(fmt, geom)
+    return _BUNDLE[(fmt, geom)]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -106,11 +107,11 @@ def _drop_bundles():
     torch.cuda.empty_cache()
 
 
-def _run(bundle, tag, batch, llm_weight_format, act_quant=False):
+def _run(bundle, tag, batch, llm_weight_format, act_quant=False, regions=8, prompt_len=64):
     so, cfg, ocfg = bundle.so, bundle.cfg, bundle.ocfg
     dtype = torch.bfloat16
     torch.set_num_threads(min(THREADS, os.cpu_count() or 1))
-    ids, images, depths, masks = so.synth_inputs(ocfg, batch=batch, regions=8, prompt_len=64, seed=2, dtype=dtype)
+    ids, images, depths, masks = so.synth_inputs(ocfg, batch=batch, regions=regions, prompt_len=prompt_len, seed=2, dtype=dtype)
     aq = so.fp8_rowwise_fake_quant if act_quant else None
     t0 = time.perf_counter()
     ref_ids, st = so.generate(bundle.w_cpu, ocfg, ids, images, depths, masks, max_new_tokens=G, return_stages=True, model_dtype=dtype,
@@ -214,6 +215,12 @@ def test_config1_bs1_bf16_128_free_running_ids_bit_identical():
 
 def test_config2_bs4_bf16_128_free_running_ids_bit_identical():
     _run(_bundle("native"), "config2_bs4_bf16", 4, "native")
+
+
+def test_config3_llama2_7b_16_regions_512_id_prompt_128_free_running_ids_bit_identical():
+    """configs[3]: Llama-2-7B geometry (MHA 32/32, inter 11008, vocab 32002), 16 regions, 512-id prompt -> T = 707; contexts 707 .. 834
+    (14 splits of the MFMA decode attention at G = 1, the cache crosses its 768-row granule)."""
+    _run(_bundle("native", "llama2_7b"), "config3_llama2_7b", 1, "native", regions=16, prompt_len=512)
 
 
 def test_config4_bs8_fp8_w8a16_128_free_running_ids_bit_identical():

@@ -368,3 +368,48 @@ def test_incremental_forward_with_cached_state_equals_generate():
     assert torch.equal(torch.stack(got, 1), want)
     with pytest.raises(NotImplementedError):
         model(input_ids=d["input_ids"], past_key_values=st, attention_mask=am)  # only single-token steps over a cache
+
+
+def test_graph_replay_honours_a_token_written_into_state_between_replays():
+    """the captured decode step does not embed st->tok itself (the advance kernel of the step before leaves the picked
+    token's embedding row in place).  A caller that writes a token of its own into st->tok between replays -- valid under ABI 1/2 --
+    must still get THAT token's step: the graph's first node compares st->tok with the token the row in place belongs to and
+    re-embeds on a mismatch.  Checked against the public (always embedding) step on an independent state, fp32, bit for bit."""
+    import ctypes as C
+
+    from spatialrgpt_amd import _lib as L
+    from spatialrgpt_amd import ops
+
+    model, cfg, dtype, w, inp, ref = _engine("tiny_fp32.npz")
+    eng = model.engine
+    emb = eng.prepare_inputs(inp["input_ids"].to(DEV), inp["images"].to(DEV), inp["depths"].to(DEV), [m.to(DEV) for m in inp["masks"]])[0]
+    lib = L.load()
+    # path A: graph replays, with a foreign token injected before the second replay
+    eng.stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(eng.stream):
+        st, _, _ = eng.prefill(emb, max_new=8, fresh_state=True)
+        L.check(lib.srgpt_llm_sample_first(C.byref(eng.w.llm), C.byref(st.c), ops._stream()))
+        g = st.ensure_graph()
+        L.check(lib.srgpt_graph_launch(g, 1, ops._stream()))
+        picked = int(st.tok[0])
+        foreign = (picked + 7) % 100 + 3
+        st.tok.fill_(foreign)
+        L.check(lib.srgpt_graph_launch(g, 1, ops._stream()))
+        torch.cuda.synchronize()
+        a_logits, a_tok = st.logits.clone(), int(st.tok[0])
+    # path B: the same two steps through the public step (embeds st->tok every time) on an independent state
+    st2, _, _ = eng.prefill(emb, max_new=8, fresh_state=True)
+    L.check(lib.srgpt_llm_sample_first(C.byref(eng.w.llm), C.byref(st2.c), ops._stream()))
+    L.check(lib.srgpt_llm_decode_step(C.byref(eng.w.llm), C.byref(st2.c), ops._stream()))
+    assert int(st2.tok[0]) == picked
+    st2.tok.fill_(foreign)
+    L.check(lib.srgpt_llm_decode_step(C.byref(eng.w.llm), C.byref(st2.c), ops._stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(a_logits, st2.logits) and a_tok == int(st2.tok[0])
+    # and the foreign token really changed the step (otherwise the test proves nothing)
+    st3, _, _ = eng.prefill(emb, max_new=8, fresh_state=True)
+    L.check(lib.srgpt_llm_sample_first(C.byref(eng.w.llm), C.byref(st3.c), ops._stream()))
+    L.check(lib.srgpt_llm_decode_step(C.byref(eng.w.llm), C.byref(st3.c), ops._stream()))
+    L.check(lib.srgpt_llm_decode_step(C.byref(eng.w.llm), C.byref(st3.c), ops._stream()))
+    torch.cuda.synchronize()
+    assert not torch.equal(st3.logits, a_logits)
