@@ -9,6 +9,12 @@ int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const
                               const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D, int max_pos, int dtype,
                               const void* next_w, int next_n, int next_k, int next_fp8, srgpt_stream_t stream);  // attn.hip
 void* srgpt_decode_attn_sync_words(float* ws, int B, int Hq, int D, size_t* bytes);  // attn.hip
+#ifdef SRGPT_TUNING_KNOBS  // experiment (round 3, tuning build only): the persistent GEMV chain, chain.hip
+int srgpt_gemv_chain(const void* const* W, const void* const* norm_w, const void* const* xin, void* const* xout,
+                     const void* const* resid, const int* N, const int* K, const int* swiglu, int nph, float eps, void* bar,
+                     srgpt_stream_t stream);
+#endif
+static inline int srgpt_gemv_chain_bar_words() { return 288; }  // its grid-barrier words live in the workspace of both builds
 
 namespace {
 
@@ -56,6 +62,7 @@ struct LlmWs {
   float* amax_v;  // [batch, ARGMAX_BLOCKS] partial maxima
   int* amax_i;    // [batch, ARGMAX_BLOCKS] their indices
   int64_t* tok_emb;  // [batch] the token whose embedding row currently sits in xd (-1: none)
+  unsigned int* chain_bar;  // grid-barrier words of the persistent GEMV chain (zero between launches)
   void* a8;       // fp8_act: the e4m3 bytes of the current GEMM input [rows, max K]
   float* a8s;     // fp8_act: their per-row scales [rows]
   size_t total;
@@ -84,6 +91,7 @@ LlmWs carve_llm(const srgpt_llm_weights* w, int batch, int max_tokens, void* ws)
   l.amax_v = reinterpret_cast<float*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
   l.amax_i = reinterpret_cast<int*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
   l.tok_emb = reinterpret_cast<int64_t*>(c.take((size_t)batch * 8));
+  l.chain_bar = reinterpret_cast<unsigned int*>(c.take((size_t)srgpt_gemv_chain_bar_words() * 4));
   l.a8 = nullptr;
   l.a8s = nullptr;
   if (w->fp8_act) {
@@ -345,6 +353,7 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
     SRGPT_HIP_TRY(hipMemsetAsync(sync, 0, sync_bytes, s), "srgpt_llm_prefill: re-arming the decode tickets");
     // no embedding row is in place for the new sequences (-1 matches no token id)
     SRGPT_HIP_TRY(hipMemsetAsync(l.tok_emb, 0xFF, (size_t)B * sizeof(int64_t), s), "srgpt_llm_prefill: resetting the embedded-token record");
+    SRGPT_HIP_TRY(hipMemsetAsync(l.chain_bar, 0, (size_t)srgpt_gemv_chain_bar_words() * 4, s), "srgpt_llm_prefill: re-arming the chain barrier");
   }
   if (hipMemcpyAsync(l.x, inputs_embeds, hid_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
     srgpt_set_error("srgpt_llm_prefill: memcpy failed");
@@ -475,16 +484,40 @@ static int decode_step_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, srg
     if (w8) return srgpt_gemv_w8(x, W8p, sc, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, stream);
     return srgpt_gemv(x, Wd, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, dt, stream);
   };
+  // batch 1, bf16: the four GEMVs between two attention launches (o_proj, gate/up, down, the next layer's qkv) run as ONE persistent
+  // launch whose loader streams the next phase's weights across every dependency edge (chain.hip); bit-identical to the launches
+  // (experiment, tuning build only -- bit-identical, 3.52 ms per token against 2.96 for the launches: profiles/r03_gemv_chain.txt)
+  const bool chain = SRGPT_KNOB("SRGPT_DECODE_CHAIN", 0) && !w8 && dt == SRGPT_BF16 && B == 1;
+  bool qkv_done = false;
   for (int i = 0; i < w->layers; ++i) {
     char* kc = reinterpret_cast<char*>(st->kcache) + (size_t)i * layer_kv;
     char* vc = reinterpret_cast<char*>(st->vcache) + (size_t)i * layer_kv;
-    SRGPT_TRY(mv(d.xd, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, w->attn_norm[i], nullptr,
-                 d.qkvd, QW, Hd, 0, 0));
+    if (!qkv_done)
+      SRGPT_TRY(mv(d.xd, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, w->attn_norm[i], nullptr,
+                   d.qkvd, QW, Hd, 0, 0));
+    qkv_done = false;
     // the attention launch also pulls o_proj's weights into L2 (HBM is idle while it runs).  Round 3 built the next step -- o_proj
     // itself inside this launch, weights in registers, agent-scope hand-off -- bit-exact and 3 us per layer SLOWER
     // (profiles/r03_fused_attention_oproj.txt)
     SRGPT_TRY(srgpt_decode_attention_pf(d.qkvd, kc, vc, st->pos, w->rope_cos, w->rope_sin, d.attnd, d.dws, B, Hq, Hkv, D,
                                         st->max_pos, dt, w8 ? w->wo8[i] : w->wo[i], Hd, Hq * D, w8 ? 1 : 0, stream));
+#ifdef SRGPT_TUNING_KNOBS
+    if (chain) {
+      const bool next = i + 1 < w->layers;
+      const void* cW[4] = {w->wo[i], w->wgu[i], w->wdown[i], next ? w->wqkv[i + 1] : nullptr};
+      const void* cN[4] = {nullptr, w->mlp_norm[i], nullptr, next ? w->attn_norm[i + 1] : nullptr};
+      const void* cX[4] = {d.attnd, d.xd, d.actd, d.xd};
+      void* cO[4] = {d.xd, d.actd, d.xd, d.qkvd};
+      const void* cR[4] = {d.xd, nullptr, d.xd, nullptr};
+      const int cNn[4] = {Hd, I, Hd, QW}, cK[4] = {Hq * D, Hd, I, Hd}, cS[4] = {0, 1, 0, 0};
+      const int rc = srgpt_gemv_chain(cW, cN, cX, cO, cR, cNn, cK, cS, next ? 4 : 3, w->rms_eps, d.chain_bar, stream);
+      if (rc == SRGPT_OK) {
+        qkv_done = next;
+        continue;
+      }
+      if (rc != SRGPT_ERR_UNSUPPORTED) return rc;
+    }
+#endif
     SRGPT_TRY(mv(d.attnd, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, nullptr, d.xd, d.xd, Hd,
                  Hq * D, 0, 0));
     SRGPT_TRY(mv(d.xd, w->wgu[i], w8 ? w->wgu8[i] : nullptr, w8 ? w->wgu_scale[i] : nullptr, w->mlp_norm[i], nullptr,
@@ -514,6 +547,13 @@ extern "C" int srgpt_llm_decode_sync_state(const srgpt_llm_weights* w, const srg
   const size_t n = host.size();
   for (size_t i = 0; i < n; ++i)
     SRGPT_CHECK(host[i] == 0, SRGPT_ERR_STATE, "decode step: arrival ticket %zu of %zu is %d between steps (expected 0)", i, n, host[i]);
+  // the persistent GEMV chain's grid-barrier words: re-armed by the last block of every launch; word 273 = a bounded spin expired
+  std::vector<unsigned int> bw((size_t)srgpt_gemv_chain_bar_words());
+  SRGPT_HIP_TRY(hipMemcpyAsync(bw.data(), d.chain_bar, bw.size() * 4, hipMemcpyDeviceToHost, as_stream(stream)), "srgpt_llm_decode_sync_state: copy");
+  SRGPT_HIP_TRY(hipStreamSynchronize(as_stream(stream)), "srgpt_llm_decode_sync_state: synchronize");
+  SRGPT_CHECK(bw[273] == 0, SRGPT_ERR_STATE, "decode step: a bounded wait of the persistent GEMV chain expired");
+  for (size_t i = 0; i < bw.size(); ++i)
+    SRGPT_CHECK(bw[i] == 0, SRGPT_ERR_STATE, "decode step: chain barrier word %zu is %u between steps (expected 0)", i, bw[i]);
   return SRGPT_OK;
 }
 
