@@ -308,21 +308,32 @@ class SrgptEngine:
         dev = self.device
         out = (torch.zeros if ragged else torch.empty)((B * T, H), device=dev, dtype=self.dtype)
 
-        def place(src2d, src_rows, dst_rows):
-            if not dst_rows:
+        # ONE host -> device copy carries every index list of the splice (token ids, and the source / destination rows of the text,
+        # image, <mask> and <depth> placements); the kernels below take views of it
+        lists = [ids_tok, list(range(len(ids_tok))), rows_tok, img_src, img_dst, m_src, m_dst, d_src, d_dst]
+        flat = torch.tensor([v for l_ in lists for v in l_], dtype=torch.int64)
+        flat_dev = flat.to(dev)
+        idx32 = flat_dev.to(torch.int32)
+        offs, o = [], 0
+        for l_ in lists:
+            offs.append((o, o + len(l_)))
+            o += len(l_)
+
+        def place(src2d, which_src, which_dst):
+            (a0, a1), (b0, b1) = offs[which_src], offs[which_dst]
+            if b1 == b0:
                 return
-            ops.scatter_rows(src2d.contiguous(), torch.tensor(dst_rows, device=dev, dtype=torch.int32), out,
-                             src_idx=torch.tensor(src_rows, device=dev, dtype=torch.int32))
+            ops.scatter_rows(src2d.contiguous(), idx32[b0:b1], out, src_idx=idx32[a0:a1])
 
         if ids_tok:
             self._check_ids(ids_tok)
-            emb = ops.embed_rows(self.w.embed, torch.tensor(ids_tok, device=dev, dtype=torch.int64))
-            place(emb, list(range(len(ids_tok))), rows_tok)
-        place(image_features.reshape(-1, H), img_src, img_dst)
+            emb = ops.embed_rows(self.w.embed, flat_dev[offs[0][0]:offs[0][1]])
+            place(emb, 1, 2)
+        place(image_features.reshape(-1, H), 3, 4)
         if m_dst:
-            place(torch.cat([e for e in mask_embeds if e is not None], 0), m_src, m_dst)
+            place(torch.cat([e for e in mask_embeds if e is not None], 0), 5, 6)
         if d_dst:
-            place(torch.cat([e for e in depth_embeds if e is not None], 0), d_src, d_dst)
+            place(torch.cat([e for e in depth_embeds if e is not None], 0), 7, 8)
         am_out = None
         if attention_mask is not None:
             am = torch.zeros((B, T), dtype=torch.bool)
