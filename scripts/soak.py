@@ -4,6 +4,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
+from spatialrgpt_amd import _lib
+if os.environ.get("SRGPT_LIB"):  # a tuning build: the SRGPT_* knobs select kernel variants
+    _lib.LIB_PATH = os.path.abspath(os.environ["SRGPT_LIB"])
 from spatialrgpt_amd.config import SrgptConfig
 from spatialrgpt_amd.model import LlavaLlamaModel
 from spatialrgpt_amd.weights import synth_state_dict
@@ -23,6 +26,7 @@ for i in range(8):
     reqs = [bench.synth_request(cfg, 4 + (i % 3), P, 10 * i + b, dev, torch.bfloat16) for b in range(B)]
     cases.append((torch.cat([r[0] for r in reqs], 0), torch.cat([r[1] for r in reqs], 0), torch.cat([r[2] for r in reqs], 0), [r[3][0] for r in reqs], G))
 ref = {}
+nbad = 0
 t0 = time.time()
 n = 0
 order = torch.randint(0, len(cases), (int(sys.argv[2]) if len(sys.argv) > 2 else 60,), generator=g).tolist()
@@ -31,7 +35,15 @@ for k, ci in enumerate(order):
     out = model.generate(ids, images=im, depths=dp, masks=mk, do_sample=False, max_new_tokens=G, eos_token_id=None).cpu()
     n += 1
     if ci in ref:
-        assert torch.equal(out, ref[ci]), f"call {k}: case {ci} (batch {ids.shape[0]}) differs from its first run"
+        if not torch.equal(out, ref[ci]):
+            bad = (out != ref[ci]).nonzero()
+            print(f"call {k}: case {ci} (batch {ids.shape[0]}) differs from its first run: first at (row, step) {bad[0].tolist()}, "
+                  f"{int((out != ref[ci]).sum())} of {out.numel()} ids")
+            nbad += 1
+            if nbad >= 3:
+                raise SystemExit("soak FAILED")
     else:
         ref[ci] = out
+if nbad:
+    raise SystemExit("soak FAILED")
 print(f"soak ok: {n} calls, {len(ref)} distinct cases, weights={fmt}, {time.time() - t0:.1f} s")

@@ -290,12 +290,13 @@ static inline int decode_nsplit(int max_pos, int B, int Hkv) {
 }
 
 // ---- the tail both decode kernels share: arrival ticket of the (sequence, kv head) group, merge by the last arriver ----
-// the MFMA kernel (bf16, head_dim 128): a block covers 64 keys (4 waves x 16), so ceil(capacity / 64) splits; at least 4 so that a
-// short cache still spreads over the chip; beyond 64 splits the waves loop (64 keys per block and pass)
+// the MFMA kernel (bf16, head_dim 128): a block owns a FIXED range of 64 keys (4 waves x 16), so ceil(capacity / 64) blocks per
+// (sequence, kv head) -- those past the sequence end publish neutral partials; beyond 64 splits the ranges grow in steps of 64 keys
+// and the waves loop
 static inline int decode_nsplit_mfma(int max_pos) {
   const int force = SRGPT_KNOB("SRGPT_DECODE_MIN_SPLITS", 0);  // tuning build: fixed split count
   int n = cdiv(max_pos, 64);
-  if (n < 4) n = 4;
+  if (n < 1) n = 1;
   if (force > 0) n = force;
   if (n > DEC_SPLIT_MAX) n = DEC_SPLIT_MAX;
   return n;
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(256) void decode_mfma_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ cos_tab, const bf16_t* __restrict__ sin_tab,
                                                           float* __restrict__ ws, int* __restrict__ tickets,
                                                           bf16_t* __restrict__ out, int Hq, int Hkv, int max_pos, int nsplit,
-                                                          float scale, int n_attn, DecodePrefetch pf) {
+                                                          int kpb, float scale, int n_attn, DecodePrefetch pf) {
   typedef bf16_t T;
   constexpr int D = 128, HALF = 64;
   __shared__ __attribute__((aligned(16))) bf16_t qs[16 * DM_QLD];  // B operand source: rows = query heads (>= G: zero)
@@ -672,8 +673,11 @@ __global__ __launch_bounds__(256) void decode_mfma_kernel(const bf16_t* __restri
   DEC_STAMP(0);
   const int P = pos[b];
   const int total = P + 1;
-  const int chunk = (total + nsplit - 1) / nsplit;  // key ranges depend on the sequence length only (see decode_split_kernel)
-  const int kbeg = split * chunk, kend = min(kbeg + chunk, total);
+  // FIXED key ranges: block `split` owns keys [split * kpb, (split + 1) * kpb), kpb = 64 for caches up to 4096 positions -- the
+  // partition, hence the summation order and the bits, depend on the sequence length only, never on how large a cache the caller
+  // happened to allocate (a pooled state serves requests of different sizes: scripts/soak.py caught exactly that); splits past the
+  // sequence publish the neutral partial, which the merge adds as exact zeros
+  const int kbeg = split * kpb, kend = min(kbeg + kpb, total);
   const T* row = qkv + (size_t)b * (Hq + 2 * Hkv) * D;
   T* kc = kcache + ((size_t)b * Hkv + hk) * (size_t)max_pos * D;
   T* vc = vcache + ((size_t)b * Hkv + hk) * (size_t)max_pos * D;
@@ -871,9 +875,10 @@ int launch_decode_d(int G, const void* qkv, void* kc, void* vc, const int* pos, 
   dim3 grid(n_attn + (pf.base ? pf.nblocks : 0));
   if constexpr (std::is_same<T, bf16_t>::value && D == 128) {
     if (decode_use_mfma(1, D, G)) {
+      const int kpb = cdiv(cdiv(max_pos, nsplit), 64) * 64;  // 64 keys per block up to 64 x 64 cached positions
 #define LM(GG)                                                                                                              \
   hipLaunchKernelGGL((decode_mfma_kernel<GG>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, pos, \
-                     (const bf16_t*)ct, (const bf16_t*)st, ws, tickets, (bf16_t*)out, Hq, Hkv, max_pos, nsplit, scale, n_attn, pf)
+                     (const bf16_t*)ct, (const bf16_t*)st, ws, tickets, (bf16_t*)out, Hq, Hkv, max_pos, nsplit, kpb, scale, n_attn, pf)
       switch (G) {
         case 1: LM(1); return SRGPT_OK;
         case 2: LM(2); return SRGPT_OK;

@@ -525,3 +525,28 @@ def test_decode_step_equals_per_op_composition_bit_for_bit(geom):
     assert torch.equal(st.kcache[:, :, :, :T0 + G], kc[:, :, :, :T0 + G])
     # the arrival tickets of the decode attention are re-armed (zero) between steps
     assert L.load().srgpt_llm_decode_sync_state(C.byref(w.llm), C.byref(st.c), ops._stream()) == 0, L.last_error()
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,P", [(1, 32, 8, 300), (2, 8, 8, 77), (1, 20, 20, 700)])
+def test_decode_attention_bits_do_not_depend_on_cache_capacity(B, Hq, Hkv, P):
+    """A pooled decode state serves requests of different sizes, so the same sequence may meet caches of different capacities: the
+    attention output must be bit-identical whatever `max_pos` is (the key partition depends on the sequence length only).
+    scripts/soak.py caught the first MFMA decode kernel splitting keys by capacity."""
+    from spatialrgpt_amd.config import SrgptConfig as PC
+    from spatialrgpt_amd.weights import rope_tables
+    ops, L = _ops()
+    D, dtype = 128, torch.bfloat16
+    QW = (Hq + 2 * Hkv) * D
+    outs = []
+    for max_pos in (768, 1024, 2048, 4096):
+        cos_t, sin_t = rope_tables(PC(hidden=Hq * D, heads=Hq, kv_heads=Hkv, rope_theta=10000.0), max_pos, dtype, DEV)
+        kc = torch.zeros((B, Hkv, max_pos, D), device=DEV, dtype=dtype)
+        vc = torch.zeros_like(kc)
+        allq = _rand((B, P + 1, QW), dtype, 24).to(DEV)
+        ops.rope_kv_append(allq[:, :P].contiguous(), kc, vc, cos_t, sin_t, B, P, Hq, Hkv, D)
+        kc[:, :, P + 1:] = 7.0  # whatever lies beyond the sequence must not matter
+        vc[:, :, P + 1:] = -3.0
+        posd = torch.full((B,), P, dtype=torch.int32, device=DEV)
+        outs.append(ops.decode_attention(allq[:, P].contiguous(), kc, vc, posd, cos_t, sin_t, Hq, Hkv, D))
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
