@@ -157,7 +157,10 @@ int srgpt_rope_kv_append(void* qkv, void* kcache, void* vcache, const int* pos0,
  *   qkv [B, (Hq+2Hkv)*D] raw projections of the new token; pos (device int[B]) = tokens already cached.
  *   ws: fp32 workspace of srgpt_decode_attn_ws_floats(B,Hq,D) floats: per-split partials followed by one arrival ticket per
  *   (sequence, kv head).  The tickets must be ZERO before the first launch (zero the workspace once when it is allocated);
- *   every launch leaves them zero again.  One kernel: the split that arrives last merges the partials.  out [B, Hq*D]. */
+ *   every launch leaves them zero again.  One kernel: the split that arrives last merges the partials.  out [B, Hq*D].
+ *   The key ranges of the splits depend on pos only -- for caches of up to 4096 positions (2048 from two sequences up on the VALU
+ *   kernel) the output bits do NOT depend on max_pos (a pooled cache may be larger than the request needs); larger caches change
+ *   the split count.  bf16 with D = 128 runs on the matrix pipe (fixed 64-key ranges), everything else on the VALU kernel. */
 int64_t srgpt_decode_attn_ws_floats(int B, int Hq, int D);
 int srgpt_decode_attention(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
                            const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D,
@@ -172,7 +175,9 @@ int srgpt_decode_attention(const void* qkv, void* kcache, void* vcache, const in
  *   rscale_h/w = (float)(1.0 / scale_factor) as ATen's upsample kernel receives it (host computes
  *   scale_factor = sqrt(L / (mh*mw)) in double like base_extractor.py:53-54); M <= 16 per call.
  *   mask_dtype: storage type of `masks` (SRGPT_F32 or SRGPT_BF16) -- the reference does mask.float().
- *   ws: fp32 workspace of srgpt_region_pool_ws_floats(M, fw, C) floats.
+ *   ws: fp32 workspace of srgpt_region_pool_ws_floats(M, fw, C) floats (resampled masks, per-slab sums and partials, arrival
+ *   tickets -- it need not be initialised: the first of the two launches re-arms the tickets).  Two launches, no float atomics:
+ *   every sum runs in a fixed order, so the result does not depend on scheduling.
  * srgpt_avgpool: AdaptiveAvgPool2d(out_w) on a channels-last map (base_extractor.py:123,145).
  * srgpt_s2d: DownSampleBlock (multimodal_projector/base_projector.py:32-52) -- zero-pad to even, 2x2
  *   space-to-depth in the reference's (column-major block) order; [n, g*g, C] -> [n, ceil(g/2)^2, 4C].
