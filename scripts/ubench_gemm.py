@@ -11,6 +11,8 @@ dev = "cuda"
 shapes = [("llm qkv", 259, 6144, 4096), ("llm o", 259, 4096, 4096), ("llm gate/up", 259, 28672, 4096), ("llm down", 259, 4096, 14336),
           ("vit qkv", 1458, 3456, 1152), ("vit out", 1458, 1152, 1152), ("vit fc1", 1458, 4304, 1152), ("vit fc2", 1458, 1152, 4304),
           ("proj 1", 196, 4096, 4608), ("deconv1", 729, 4608, 1152), ("deconv2", 2916, 4608, 1152), ("sq 4096", 4096, 4096, 4096)]
+if len(sys.argv) > 1:  # shapes from the command line: name:M:N:K ...
+    shapes = [(a.split(":")[0], *map(int, a.split(":")[1:])) for a in sys.argv[1:]]
 side = torch.cuda.Stream()
 tot = 0.0
 for name, M, N, K in shapes:

@@ -38,6 +38,48 @@ __global__ __launch_bounds__(256, 2) void kfrag(const u4* __restrict__ W, const 
   }
 }
 
+
+// fp8 weights, fragment-shaped: lane l reads 16 bytes W8[row0 + (l & 15)][64 s + 16 (l >> 4) .. +16] (16 rows x 64 B per instruction),
+// widened in registers to the bf16 fragments of two k steps -- no LDS on the weight side
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+template <int DEPTH>
+__global__ __launch_bounds__(256, 2) void kfrag8(const u4* __restrict__ W, const u4* __restrict__ x, float* __restrict__ out, int N, int K16) {
+  __shared__ u4 xs[512];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < 512; c += 256) xs[c] = x[c];
+  __syncthreads();
+  const int r = lane & 15, g = lane >> 4;
+  const int nsteps = K16 / 4;  // 64-byte steps per row
+  for (int unit = blockIdx.x * 4 + wave; unit * 16 < N; unit += gridDim.x * 4) {
+    f4v acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    const u4* p = W + (size_t)(unit * 16 + r) * K16 + g;
+    for (int s0 = 0; s0 < nsteps; s0 += DEPTH) {
+      u4 w[DEPTH];
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) w[j] = __builtin_nontemporal_load(p + (s0 + j) * 4);
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        const u4 xv = xs[((s0 + j) * 8 + g) & 511], xv2 = xs[((s0 + j) * 8 + 4 + g) & 511];
+        u4 lo, hi;
+        lo[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[j][0], 1.0f, false));
+        lo[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[j][0], 1.0f, true));
+        lo[2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[j][1], 1.0f, false));
+        lo[3] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[j][1], 1.0f, true));
+        hi[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[j][2], 1.0f, false));
+        hi[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[j][2], 1.0f, true));
+        hi[2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[j][3], 1.0f, false));
+        hi[3] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[j][3], 1.0f, true));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, lo), __builtin_bit_cast(bf16x8, xv), acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, hi), __builtin_bit_cast(bf16x8, xv2), acc2, 0, 0, 0);
+      }
+    }
+    if (r == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[unit * 16 + g * 4 + q] = acc[q] + acc2[q];
+    }
+  }
+}
+
 template <int V, int DEPTH>
 __global__ __launch_bounds__(256, 2) void k(const u4* __restrict__ W, const u4* __restrict__ x, float* __restrict__ out, int N, int K16) {
   __shared__ u4 xs[2048];
@@ -116,6 +158,25 @@ int runfrag(const char* name, hipStream_t s, std::vector<u4*>& Ws, u4* x, float*
   return 0;
 }
 
+
+template <int DEPTH>
+int runfrag8(const char* name, hipStream_t s, std::vector<u4*>& Ws, u4* x, float* out, int N, int K, int grid) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipGraph_t g; hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  // the bf16 buffers hold N x K x 2 bytes: read as fp8 matrices of 2N rows (same bytes per launch as the bf16 variants)
+  for (auto W : Ws) hipLaunchKernelGGL((kfrag8<DEPTH>), dim3(grid), dim3(256), 0, s, W, x, out, 2 * N, K / 16);
+  CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  float ms = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  const double us = ms * 1e3 / Ws.size(), mb = (double)N * K * 2 / 1e6;
+  printf("  %-44s %7.2f us  (%.2f TB/s; fixed vs 7.05 TB/s %5.2f us)\n", name, us, mb / us, us - mb / 7.05);
+  return 0;
+}
+
 template <int V, int DEPTH>
 int run(const char* name, hipStream_t s, std::vector<u4*>& Ws, u4* x, float* out, int N, int K) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -152,6 +213,11 @@ int main() {
     run<4, 4>("V4 depth 4", s, Ws, x, out, N, K);
     runfrag<8>("MFMA 16x16x32, fragment-shaped loads, depth 8", s, Ws, x, out, N, K);
     runfrag<16>("MFMA 16x16x32, fragment-shaped loads, depth 16", s, Ws, x, out, N, K);
+    float* out2; CK(hipMalloc(&out2, 2 * N * 4));
+    runfrag8<4>("fp8 fragment loads (16 B/lane), depth 4, 512 blocks", s, Ws, x, out2, N, K, 512);
+    runfrag8<8>("fp8 fragment loads, depth 8, 512 blocks", s, Ws, x, out2, N, K, 512);
+    runfrag8<8>("fp8 fragment loads, depth 8, 768 blocks", s, Ws, x, out2, N, K, 768);
+    runfrag8<16>("fp8 fragment loads, depth 16, 512 blocks", s, Ws, x, out2, N, K, 512);
     for (auto W : Ws) CK(hipFree(W));
   }
   return 0;

@@ -52,6 +52,9 @@ constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumu
 #ifndef SRGPT_SKINNY_DEPTH
 #define SRGPT_SKINNY_DEPTH 2           // register ring depth of weight stages (tuning builds override)
 #endif
+#ifndef SRGPT_SKINNY_DEPTH_W8
+#define SRGPT_SKINNY_DEPTH_W8 2        // the same for fp8 weights (a stage is half the registers and half the bytes in flight)
+#endif
 #ifndef SRGPT_SKINNY_PRE
 #define SRGPT_SKINNY_PRE 1            // first weight stage of a block requested before its RMSNorm statistics are reduced
 #endif
@@ -136,22 +139,29 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   };
 
   // weight stage of sub-unit su of (pass, slice): 8 loads, each 2 rows x 512 contiguous bytes (fp8: 2 rows x 256 bytes)
-  // Every load inside the K loop is issued UNCONDITIONALLY (`ok` false: all lanes re-read the unit's first 16 bytes, one cached
-  // line): behind a branch the compiler cannot count the loads in flight, waits for vmcnt(0) in front of the LDS writes and so
-  // drains the prefetched stage every step -- one full memory latency per stage, which is what bounded this kernel before.
+  // Every load inside the K loop is issued UNCONDITIONALLY: behind a branch the compiler cannot count the loads in flight, waits
+  // for vmcnt(0) in front of the LDS writes and so drains the prefetched stage every step -- one full memory latency per stage,
+  // which is what bounded this kernel before.  The loads are BUFFER loads on a descriptor of the tile's valid rows: what must not
+  // be fetched (a stage past the wave's last slice, rows past the tile's last one, k past K) is pushed out of the descriptor's
+  // range and comes back as zeros without a memory access -- no per-load select, and the per-lane part of the address is eight
+  // kernel-constant offsets (row 2j + lrow, chunk lchunk) plus one slice offset per stage: 12 VALU per stage where the
+  // flat-address form spent 45 (the ISA of round 2's kernel: 126 v_cndmask + 104 shifts / adds per 8 stages).
+  unsigned wrow_off[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wrow_off[j] = ((unsigned)(2 * j + lrow) * (unsigned)K + (unsigned)lchunk * WEPL) * WEB;
+  constexpr unsigned W_OUT_OF_RANGE = 0x10000000u;  // > any descriptor range (16 rows x K x 2 bytes), no 32-bit wrap when added
   auto issue_w = [&](WReg* w, int pass, int sl, int su, bool ok) {
     const int cb = c0 + (pass * MAXU + su / R) * 16;  // first column of the tile
-    // uniform 64-bit base of the tile's first row + a 32-bit per-lane offset.  The per-lane part is made opaque per call:
-    // left visible, LICM hoists the 8 x MAXSU row products out of the K loop and holds them in ~64 VGPRs.
     const unsigned char* base = reinterpret_cast<const unsigned char*>(Wv) + ((size_t)cb + (size_t)(su % R) * N) * K * WEB;
-    const int rmax = c0 + cwb - 1 - cb;  // last valid row of the tile (>= 15 except in the block's last tile)
-    int kg = min(sl * SK + lchunk * WEPL, K - WEPL);
-    asm volatile("" : "+v"(kg));
+    const int nrow = min(c0 + cwb - cb, 16);  // valid rows of the tile (16 except in the block's last tile)
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, nrow > 0 ? nrow * K * WEB : 0, 0x00020000);
+    // slice offset; lanes whose k lies past K (last slice of a K that is no multiple of 256) leave the range too
+    const unsigned so = (ok ? (unsigned)(sl * SK) * WEB : W_OUT_OF_RANGE) + (sl * SK + lchunk * WEPL < K ? 0u : W_OUT_OF_RANGE);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      // rows past the tile's last one are not fetched either (their outputs are never stored)
-      const unsigned off = (ok && 2 * j + lrow <= rmax) ? ((unsigned)(2 * j + lrow) * (unsigned)K + (unsigned)kg) * WEB : 0u;
-      w[j] = __builtin_nontemporal_load(reinterpret_cast<const WReg*>(base + off));
+      if constexpr (W8) w[j] = __builtin_bit_cast(WReg, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(wrow_off[j] + so), 0, 2));
+      else w[j] = __builtin_bit_cast(WReg, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(wrow_off[j] + so), 0, 2));  // aux 2 = nt
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   SK_STAMP(0);
   load_x(wave);
 
-  constexpr int DEPTH = SRGPT_SKINNY_DEPTH;
+  constexpr int DEPTH = W8 ? SRGPT_SKINNY_DEPTH_W8 : SRGPT_SKINNY_DEPTH;
   // measured per decode step (profiles/r02_skinny_ab.txt, section 6): 5-8 rows bf16 -1.8 %, 3-4 rows bf16 +-0, fp8 +0.8..1 % -> bf16 only;
   // 16 staged rows: the registers are not there
   constexpr bool PRE = SRGPT_SKINNY_PRE != 0 && !W8 && NI == 4;
@@ -273,9 +283,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
       issue_w(wb[f % DEPTH], pass, wave + NW * (f / NSU), f % NSU, f / NSU < cnt);
     if (pass == 0) SK_STAMP(1);
     // one slice (h-th of the trip that starts at slice index i): NSU stages
+    // activation fragments of a slice held across its sub-units where the registers are there (fp8 weights: the stage ring is
+    // half as wide; bf16 weights: the 4-row variant only)
+    constexpr bool XREUSE = NSU >= 2 && (W8 ? NI <= 4 : NI == 2);
     auto slice = [&](int i, auto h_c) {
       constexpr int h = decltype(h_c)::value;
       const int sl = wave + NW * (i + h);
+      bf16x8 xall[XREUSE ? NS : 1];
       {
 #pragma unroll
           for (int su = 0; su < NSU; ++su) {
@@ -293,6 +307,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
             // accumulators.  Left to the compiler the unrolled loop became read -> wait -> MFMA per k step on ONE accumulator: a
             // full LDS latency per step, ~1.5k cycles per stage and sub-unit -- the kernel was bound by that, not by HBM.
             const int xrow = lane & (2 * NI - 1);  // rows past the staged ones alias valid rows: their outputs are never stored
+            if constexpr (XREUSE) {
+              // the activation fragments of the slice are the same for all of its sub-units: read once, kept in registers
+              if (su == 0) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) xall[s] = *reinterpret_cast<const bf16x8*>(xst + xrow * XROWB + (4 * s + (lane >> 4)) * 16);
+              }
+            }
 #pragma unroll
             for (int s0 = 0; s0 < NS; s0 += FS) {
               bf16x8 xf[FS];
@@ -300,7 +321,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
 #pragma unroll
               for (int t = 0; t < FS; ++t) {
                 const int s = s0 + t;
-                xf[t] = *reinterpret_cast<const bf16x8*>(xst + xrow * XROWB + (4 * s + (lane >> 4)) * 16);
+                if constexpr (XREUSE) xf[t] = xall[s];
+                else xf[t] = *reinterpret_cast<const bf16x8*>(xst + xrow * XROWB + (4 * s + (lane >> 4)) * 16);
                 wfr[t] = *reinterpret_cast<const bf16x8*>(wst + (lane & 15) * WROWB + (4 * s + (lane >> 4)) * 16);
               }
               __builtin_amdgcn_sched_barrier(0);
