@@ -55,6 +55,9 @@ constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumu
 #ifndef SRGPT_SKINNY_DEPTH_W8
 #define SRGPT_SKINNY_DEPTH_W8 2        // the same for fp8 weights (a stage is half the registers and half the bytes in flight)
 #endif
+#ifndef SRGPT_SKINNY_XREUSE
+#define SRGPT_SKINNY_XREUSE 1          // activation fragments of a slice kept in registers across its sub-units
+#endif
 #ifndef SRGPT_SKINNY_PRE
 #define SRGPT_SKINNY_PRE 1            // first weight stage of a block requested before its RMSNorm statistics are reduced
 #endif
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     // one slice (h-th of the trip that starts at slice index i): NSU stages
     // activation fragments of a slice held across its sub-units where the registers are there (fp8 weights: the stage ring is
     // half as wide; bf16 weights: the 4-row variant only)
-    constexpr bool XREUSE = NSU >= 2 && (W8 ? NI <= 4 : NI == 2);
+    constexpr bool XREUSE = SRGPT_SKINNY_XREUSE != 0 && NSU >= 2 && (W8 ? NI <= 4 : NI == 2);
     auto slice = [&](int i, auto h_c) {
       constexpr int h = decltype(h_c)::value;
       const int sl = wave + NW * (i + h);
