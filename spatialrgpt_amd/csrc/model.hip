@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __rest
 // stage 2 + bookkeeping: one wave per batch row merges the partials -> tok / out_ids[:, step] / pos / step, and (embed != NULL)
 // the embedding rows of the picked tokens go straight into the residual-stream buffer of the next step (one launch fewer per token)
 constexpr int ADVANCE_MAXB = 256;
-__global__ void advance_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int nb, int64_t* tok,
+__global__ __launch_bounds__(1024) void advance_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int nb, int64_t* tok,
                                int64_t* out_ids, int* pos, int* step, int B, int max_new, int bump_pos,
                                const unsigned char* __restrict__ embed, unsigned char* __restrict__ xd, int row_bytes,
                                int64_t* __restrict__ tok_emb) {
@@ -197,11 +197,26 @@ __global__ void advance_kernel(const float* __restrict__ pv, const int* __restri
   __syncthreads();
   if (threadIdx.x == 0) *step = s + 1;
   if (embed) {
+    // the rows of the picked tokens, four independent 16-byte loads in flight per thread (one at a time, a dependent load -> store
+    // chain per chunk, this copy was 8 of the kernel's 13 us at 8 sequences)
     const int per_row = row_bytes >> 4;  // 16-byte chunks per embedding row
-    for (int i = threadIdx.x; i < B * per_row; i += blockDim.x) {
-      const int b = i / per_row, c = i - b * per_row;
-      *reinterpret_cast<u32x4*>(xd + (size_t)b * row_bytes + (size_t)c * 16) =
-          *reinterpret_cast<const u32x4*>(embed + (size_t)picked[b] * row_bytes + (size_t)c * 16);
+    const int total = B * per_row, nt = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 4 * nt) {
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + u * nt, total - 1);
+        const int b = i / per_row, c = i - b * per_row;
+        v[u] = *reinterpret_cast<const u32x4*>(embed + (size_t)picked[b] * row_bytes + (size_t)c * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * nt;
+        if (i < total) {
+          const int b = i / per_row, c = i - b * per_row;
+          *reinterpret_cast<u32x4*>(xd + (size_t)b * row_bytes + (size_t)c * 16) = v[u];
+        }
+      }
     }
   }
 }
@@ -233,7 +248,7 @@ static int greedy_pick(const srgpt_llm_weights* w, srgpt_llm_state* st, const Ll
   const int B = st->batch;
   const bool emb = advance_embeds(w, st);
   hipLaunchKernelGGL(argmax_partial_kernel, dim3(ARGMAX_BLOCKS, B), dim3(256), 0, s, st->logits, d.amax_v, d.amax_i, w->vocab);
-  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(256), 0, s, d.amax_v, d.amax_i, ARGMAX_BLOCKS, st->tok, st->out_ids,
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(B > 4 ? 1024 : 256), 0, s, d.amax_v, d.amax_i, ARGMAX_BLOCKS, st->tok, st->out_ids,
                      st->pos, st->step, B, st->max_new, bump_pos, emb ? reinterpret_cast<const unsigned char*>(w->embed) : nullptr,
                      reinterpret_cast<unsigned char*>(d.xd), (int)((size_t)w->hidden * dtype_size(w->dtype)), d.tok_emb);
   SRGPT_LAUNCH_CHECK();
