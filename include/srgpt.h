@@ -96,6 +96,14 @@ int srgpt_gemm_w8(const void* A, const void* W8, const float* wscale, const void
  *   reduction and the un-split path after the whole sum -- results stay deterministic for a given (shape, device, ws_bytes),
  *   yet differ by fp32 roundings between the two paths.  Callers that need path-independent bits pass power-of-two scales. */
 int srgpt_quant_rows_e4m3(const void* x, void* q, float* scale, int M, int K, int ldx, srgpt_stream_t stream);
+/* ABI 5: the same quantisation with the producer of the rows fused in -- what the W8A8 prefill runs, so the bf16 intermediate is
+ * neither written nor read.  Bit-identical to srgpt_rmsnorm / srgpt_silu_mul followed by srgpt_quant_rows_e4m3 (tested); K (inter)
+ * up to 16384 columns, else SRGPT_ERR_UNSUPPORTED.
+ *   _rmsnorm: rows of LlamaRMSNorm(x; norm_w, eps) (modeling_llama.py:61-75), x [M, K] bf16 with row stride ldx
+ *   _swiglu:  rows of silu(gate) * up (LlamaMLP.forward, modeling_llama.py:194-223) of gate_up [M, 2 * inter] = [gate | up] */
+int srgpt_quant_rows_e4m3_rmsnorm(const void* x, const void* norm_w, float eps, void* q, float* scale, int M, int K, int ldx,
+                                  srgpt_stream_t stream);
+int srgpt_quant_rows_e4m3_swiglu(const void* gate_up, void* q, float* scale, int M, int inter, srgpt_stream_t stream);
 int srgpt_gemm_w8a8(const void* A8, const float* ascale, const void* W8, const float* wscale, const void* bias,
                     const void* residual, void* C, int M, int N, int K, int lda, int ldc, int out_f32, void* ws,
                     int64_t ws_bytes, srgpt_stream_t stream);

@@ -56,7 +56,7 @@ class LlmState(C.Structure):
     ]
 
 
-ABI_VERSION = 4  # include/srgpt.h; bumped with every export / layout change
+ABI_VERSION = 5  # include/srgpt.h; bumped with every export / layout change
 
 _SIGNATURES = {
     "srgpt_last_error": (C.c_char_p, []),
@@ -66,6 +66,8 @@ _SIGNATURES = {
     "srgpt_gemm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
     "srgpt_gemm_w8": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp]),
     "srgpt_quant_rows_e4m3": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "srgpt_quant_rows_e4m3_rmsnorm": (i32, [vp, vp, f32, vp, vp, i32, i32, i32, vp]),
+    "srgpt_quant_rows_e4m3_swiglu": (i32, [vp, vp, vp, i32, i32, vp]),
     "srgpt_gemm_w8a8": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp]),
     "srgpt_gemv": (i32, [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "srgpt_gemv_w8": (i32, [vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]),

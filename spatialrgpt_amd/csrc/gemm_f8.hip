@@ -334,6 +334,103 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const bf16_t* __restric
   }
 }
 
+// The same quantisation with the PRODUCER of the rows fused in (W8A8 prefill: the RMSNorm in front of q/k/v and gate/up, the
+// SwiGLU in front of down_proj), so the bf16 intermediate is neither written nor read: MODE 1 = LlamaRMSNorm (rmsnorm_kernel's
+// arithmetic: the same per-thread chunk order and block reduction for the mean of squares, weight * (x * r).to(bf16)),
+// MODE 2 = silu_mul_kernel's bf16(bf16(silu(gate)) * up) on a [gate | up] row.  The produced row lives in registers (a thread
+// owns chunks tid, tid + 256, ... : NV of them), its maximum and its codes come from there -- bit-identical to the two launches.
+template <int MODE, int NV>
+__global__ __launch_bounds__(256) void quant_rows_fused_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ nw,
+                                                               float eps, unsigned char* __restrict__ q, float* __restrict__ scale,
+                                                               int K) {
+  __shared__ float red[16];
+  __shared__ float redm[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const bf16x8* xr = reinterpret_cast<const bf16x8*>(x + (size_t)row * ldx);
+  const int nc = K >> 3;
+  bf16x8 val[NV];
+  if (MODE == 1) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = tid + 256 * v;
+      if (c < nc) {
+        val[v] = xr[c];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += (float)val[v][i] * (float)val[v][i];
+      }
+    }
+    const float r = rsqrtf(block_sum(s, red) / (float)K + eps);
+    const bf16x8* gr = reinterpret_cast<const bf16x8*>(nw);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = tid + 256 * v;
+      if (c < nc) {
+        const bf16x8 g = gr[c];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) val[v][i] = (bf16_t)((float)g[i] * rnd<bf16_t>((float)val[v][i] * r));
+      }
+    }
+  } else {
+    const bf16x8* ur = reinterpret_cast<const bf16x8*>(x + (size_t)row * ldx + K);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = tid + 256 * v;
+      if (c < nc) {
+        const bf16x8 g = xr[c], u = ur[c];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) val[v][i] = (bf16_t)(rnd<bf16_t>(silu((float)g[i])) * (float)u[i]);
+      }
+    }
+  }
+  float amax = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+    if (tid + 256 * v < nc) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf((float)val[v][i]));
+    }
+  amax = wave_max(amax);
+  if ((tid & 63) == 0) redm[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  int ex;
+  const float mant = frexpf(fmaxf(amax, 0x1p-100f), &ex);
+  const int k = ex - 9 + (mant > 0.875f ? 1 : 0);
+  const float inv = ldexpf(1.f, -k);
+  if (tid == 0) scale[row] = ldexpf(1.f, k);
+  u32x2* qr = reinterpret_cast<u32x2*>(q + (size_t)row * K);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = tid + 256 * v;
+    if (c < nc) {
+      int lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)val[v][0] * inv, (float)val[v][1] * inv, lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)val[v][2] * inv, (float)val[v][3] * inv, lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)val[v][4] * inv, (float)val[v][5] * inv, hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)val[v][6] * inv, (float)val[v][7] * inv, hi, true);
+      qr[c] = u32x2{(unsigned int)lo, (unsigned int)hi};
+    }
+  }
+}
+
+template <int MODE>
+int launch_quant_fused(const void* x, int ldx, const void* nw, float eps, void* q, float* scale, int M, int K, hipStream_t s) {
+  const int nv = (K / 8 + 255) / 256;  // chunks per thread
+#define SRGPT_QF(NV) hipLaunchKernelGGL((quant_rows_fused_kernel<MODE, NV>), dim3(M), dim3(256), 0, s, (const bf16_t*)x, ldx, \
+                                        (const bf16_t*)nw, eps, (unsigned char*)q, scale, K)
+  if (nv <= 2) SRGPT_QF(2);
+  else if (nv <= 4) SRGPT_QF(4);
+  else if (nv <= 8) SRGPT_QF(8);
+  else {
+    srgpt_set_error("fused row quantisation: K=%d exceeds 16384 columns", K);
+    return SRGPT_ERR_UNSUPPORTED;
+  }
+#undef SRGPT_QF
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -347,6 +444,23 @@ int srgpt_quant_rows_e4m3(const void* x, void* q, float* scale, int M, int K, in
                      K);
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
+}
+
+int srgpt_quant_rows_e4m3_rmsnorm(const void* x, const void* norm_w, float eps, void* q, float* scale, int M, int K, int ldx,
+                                  srgpt_stream_t stream) {
+  SRGPT_CHECK(x && norm_w && q && scale, SRGPT_ERR_ARG, "srgpt_quant_rows_e4m3_rmsnorm: null pointer");
+  SRGPT_CHECK(M > 0 && K > 0 && ldx >= K, SRGPT_ERR_ARG, "srgpt_quant_rows_e4m3_rmsnorm: bad shape M=%d K=%d ldx=%d", M, K, ldx);
+  SRGPT_CHECK(K % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)norm_w % 16) == 0 && ((uintptr_t)q % 8) == 0,
+              SRGPT_ERR_UNSUPPORTED, "srgpt_quant_rows_e4m3_rmsnorm: K and ldx must be multiples of 8 and the rows 16-byte aligned");
+  return launch_quant_fused<1>(x, ldx, norm_w, eps, q, scale, M, K, as_stream(stream));
+}
+
+int srgpt_quant_rows_e4m3_swiglu(const void* gate_up, void* q, float* scale, int M, int inter, srgpt_stream_t stream) {
+  SRGPT_CHECK(gate_up && q && scale, SRGPT_ERR_ARG, "srgpt_quant_rows_e4m3_swiglu: null pointer");
+  SRGPT_CHECK(M > 0 && inter > 0, SRGPT_ERR_ARG, "srgpt_quant_rows_e4m3_swiglu: bad shape M=%d inter=%d", M, inter);
+  SRGPT_CHECK(inter % 8 == 0 && ((uintptr_t)gate_up % 16) == 0 && ((uintptr_t)q % 8) == 0, SRGPT_ERR_UNSUPPORTED,
+              "srgpt_quant_rows_e4m3_swiglu: inter must be a multiple of 8 and the rows 16-byte aligned");
+  return launch_quant_fused<2>(gate_up, 2 * inter, nullptr, 0.f, q, scale, M, inter, as_stream(stream));
 }
 
 // C = ((A8 @ W8^T) * ascale[m] * wscale[n] + bias[n]) + residual in bf16 (or fp32 if out_f32), no activation (the LLM's Linears

@@ -61,6 +61,9 @@ constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumu
 #ifndef SRGPT_SKINNY_PRE
 #define SRGPT_SKINNY_PRE 1            // first weight stage of a block requested before its RMSNorm statistics are reduced
 #endif
+#ifndef SRGPT_SKINNY_PRE_W8
+#define SRGPT_SKINNY_PRE_W8 0         // the same with fp8 weights (measured slower in round 2; re-measured in round 3, see profiles/)
+#endif
 #ifndef SRGPT_SKINNY_FS
 #define SRGPT_SKINNY_FS 4              // MFMA k steps per fragment batch (8 LDS reads in flight per batch)
 #endif
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   constexpr int DEPTH = W8 ? SRGPT_SKINNY_DEPTH_W8 : SRGPT_SKINNY_DEPTH;
   // measured per decode step (profiles/r02_skinny_ab.txt, section 6): 5-8 rows bf16 -1.8 %, 3-4 rows bf16 +-0, fp8 +0.8..1 % -> bf16 only;
   // 16 staged rows: the registers are not there
-  constexpr bool PRE = SRGPT_SKINNY_PRE != 0 && !W8 && NI == 4;
+  constexpr bool PRE = (W8 ? SRGPT_SKINNY_PRE_W8 != 0 : SRGPT_SKINNY_PRE != 0) && NI == 4;
 
   // ---- RMSNorm statistics of every batch row (LlamaRMSNorm: fp32 mean of squares over K) ----
   // `between` runs once, after the statistics' first batch of loads has been issued and before it is reduced

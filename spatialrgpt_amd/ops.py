@@ -152,6 +152,30 @@ def quant_rows_e4m3(x):
     return q, sc
 
 
+def quant_rows_e4m3_rmsnorm(x, norm_w, eps):
+    """quant_rows_e4m3(rmsnorm(x, norm_w, eps)) in one launch (bit-identical to the two; the W8A8 prefill's form)."""
+    _dev(x, norm_w)
+    if x.dtype != torch.bfloat16 or norm_w.dtype != torch.bfloat16 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("quant_rows_e4m3_rmsnorm: x must be a bf16 matrix with contiguous rows, norm_w bf16")
+    M, K = x.shape
+    q = torch.empty((M, K), device=x.device, dtype=torch.uint8)
+    sc = torch.empty((M,), device=x.device, dtype=torch.float32)
+    L.check(L.load().srgpt_quant_rows_e4m3_rmsnorm(_p(x), _p(norm_w), float(eps), _p(q), _p(sc), M, K, x.stride(0), _stream()))
+    return q, sc
+
+
+def quant_rows_e4m3_swiglu(gate_up):
+    """quant_rows_e4m3(silu_mul(gate_up)) in one launch: gate_up [M, 2 * inter] = [gate | up], contiguous."""
+    _dev(gate_up)
+    if gate_up.dtype != torch.bfloat16 or gate_up.dim() != 2 or not gate_up.is_contiguous() or gate_up.shape[1] % 2:
+        raise ValueError("quant_rows_e4m3_swiglu: gate_up must be a contiguous bf16 [M, 2 * inter] matrix")
+    M, inter = gate_up.shape[0], gate_up.shape[1] // 2
+    q = torch.empty((M, inter), device=gate_up.device, dtype=torch.uint8)
+    sc = torch.empty((M,), device=gate_up.device, dtype=torch.float32)
+    L.check(L.load().srgpt_quant_rows_e4m3_swiglu(_p(gate_up), _p(q), _p(sc), M, inter, _stream()))
+    return q, sc
+
+
 def gemm_w8a8(a8, ascale, w8, wscale, bias=None, residual=None, out=None, out_f32=False):
     """((fp8(a8) @ fp8(w8).T) * ascale[:,None] * wscale[None,:] + bias) + residual on the fp8 matrix pipe: a8 uint8 [M,K],
     w8 uint8 [N,K] (OCP e4m3fn), ascale fp32 [M], wscale fp32 [N]; bias / residual / out bf16 (out fp32 if out_f32)."""

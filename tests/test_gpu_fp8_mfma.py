@@ -52,6 +52,41 @@ def test_quant_rows_e4m3_equals_host_rule():
     assert torch.equal(q2.cpu(), q_ref) and torch.equal(sc2.cpu(), sc_ref), "strided rows"
 
 
+@pytest.mark.parametrize("M,K", [(5, 64), (77, 640), (259, 4096), (33, 2560), (3, 16384)])
+def test_quant_rows_fused_rmsnorm_is_the_two_launches_bit_for_bit(M, K):
+    """srgpt_quant_rows_e4m3_rmsnorm (what the W8A8 prefill runs) == srgpt_rmsnorm then srgpt_quant_rows_e4m3: codes and
+    scales identical, incl. a row of zeros, an outlier column, a strided input, and one to eight chunks per thread."""
+    ops, _ = _ops()
+    x = _acts(M, K, 21).to(DEV)
+    x[0] = 0
+    g = (1.0 + 0.1 * torch.randn(K, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16).to(DEV)
+    q_ref, sc_ref = ops.quant_rows_e4m3(ops.rmsnorm(x, g, 1e-5))
+    q, sc = ops.quant_rows_e4m3_rmsnorm(x, g, 1e-5)
+    assert torch.equal(sc, sc_ref), "row scales"
+    assert torch.equal(q, q_ref), f"{int((q != q_ref).sum())}/{q.numel()} codes differ"
+    wide = torch.full((M, K + 64), 1e4, device=DEV, dtype=torch.bfloat16)
+    wide[:, :K] = x
+    q2, sc2 = ops.quant_rows_e4m3_rmsnorm(wide[:, :K], g, 1e-5)
+    assert torch.equal(q2, q_ref) and torch.equal(sc2, sc_ref), "strided rows"
+
+
+@pytest.mark.parametrize("M,inter", [(5, 48), (77, 640), (259, 14336), (33, 11008), (9, 6912)])
+def test_quant_rows_fused_swiglu_is_the_two_launches_bit_for_bit(M, inter):
+    """srgpt_quant_rows_e4m3_swiglu == srgpt_silu_mul then srgpt_quant_rows_e4m3 on [gate | up] rows."""
+    ops, _ = _ops()
+    gu = _acts(M, 2 * inter, 22).to(DEV)
+    gu[1] = 0
+    q_ref, sc_ref = ops.quant_rows_e4m3(ops.silu_mul(gu))
+    q, sc = ops.quant_rows_e4m3_swiglu(gu)
+    assert torch.equal(sc, sc_ref), "row scales"
+    assert torch.equal(q, q_ref), f"{int((q != q_ref).sum())}/{q.numel()} codes differ"
+
+
+def test_quant_rows_fused_rejects_rows_wider_than_its_register_tile():
+    ops, _ = _ops()
+    with pytest.raises(NotImplementedError):
+        ops.quant_rows_e4m3_swiglu(torch.zeros((2, 2 * 16392), device=DEV, dtype=torch.bfloat16))
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (77, 333, 384), (259, 6144, 4096), (300, 520, 1408), (2072, 1024, 512),
                                    (513, 4096, 14336)])
 def test_gemm_w8a8_equals_gemm_of_dequantised_operands(M, N, K):
