@@ -331,8 +331,8 @@ def main():
     eng = model.engine
     roof = None
     if rank == 0:
-        # the product as the timed workload launches it: one activation row per request of the batch (1-2 rows: the VALU GEMV,
-        # 3+ rows: the MFMA skinny kernel)
+        # the product as the timed workload launches it: one activation row per request of the batch (one row: the VALU GEMV,
+        # 2+ rows: the MFMA skinny kernel)
         rows = args.batch
         x = torch.randn((rows, cfg.hidden), device=device).to(dtype)
         outb = torch.empty((args.batch, cfg.inter), device=device, dtype=dtype)
@@ -386,8 +386,8 @@ def main():
             else:
                 traffic_src = (f"none: {os.path.relpath(pmc, ROOT)} was recorded for another kernel source (sha256 "
                                f"{str(rec.get('kernel_source_sha256'))[:12]} != {kernel_source_sha256()[:12]}); re-run scripts/profile_round.sh")
-        kname = (("skinny_kernel<swiglu, W8>" if rows > 2 else "gemv_w8_kernel<swiglu>") if fp8 else
-                 ("skinny_kernel<swiglu>" if rows > 2 else f"gemv_kernel<bf16,{rows},swiglu>"))
+        kname = (("skinny_kernel<swiglu, W8>" if rows > 1 else "gemv_w8_kernel<swiglu>") if fp8 else
+                 ("skinny_kernel<swiglu>" if rows > 1 else f"gemv_kernel<bf16,{rows},swiglu>"))
         roof = {"bound": "hbm", "kernel": f"{kname} (decode gate/up projection at {rows} activation row(s), 54% of streamed bytes"
                                           + (", fp8 weights)" if fp8 else ")"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -944,7 +944,7 @@ extern "C" int64_t srgpt_decode_attn_ws_floats(int B, int Hq, int D) {
 }
 
 // internal entry (model.hip): decode attention + L2 prefetch of the weight matrix the next GEMV streams.
-// next_w = NULL -> no prefetch.  batch > 2 goes through the skinny kernel: no prefetch there (measured, common.h).
+// next_w = NULL -> no prefetch.  batch > 1 goes through the skinny kernel: no prefetch there (measured, common.h).
 int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
                               const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D, int max_pos, int dtype,
                               const void* next_w, int next_n, int next_k, int next_fp8, srgpt_stream_t stream) {

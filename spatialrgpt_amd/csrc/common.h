@@ -278,14 +278,15 @@ __device__ __forceinline__ void srgpt_prefetch_block(const SrgptPrefetch& pf, in
 extern "C" int srgpt_device_cus(void);
 
 // descriptor for "the next launch is the batch-`batch` decode GEMV over W [N (2N if swiglu), K]" (bf16 rows, or fp8 bytes).
-// Mirrors the grid / unit mapping of gemv.hip's and gemv_w8.hip's launchers for batch <= 2 (the VALU kernels); anything else
-// gets no prefetch: fp8 SwiGLU units of four rows, and 3+ rows (the skinny kernel -- its mapping, 4-row groups of block p's
-// 16-row units, was measured: o_proj +1 % at 8 fp8 rows, -2 % at 4 bf16 rows per decode step, not kept).
+// Mirrors the grid / unit mapping of gemv.hip's and gemv_w8.hip's launchers for one row (the VALU kernels); anything else
+// gets no prefetch: fp8 SwiGLU units of four rows, and 2+ rows (the skinny kernel -- its mapping, 4-row groups of block p's
+// 16-row units, was measured: o_proj +1 % at 8 fp8 rows, -2 % at 4 bf16 rows per decode step, not kept; at 2 rows, which moved
+// to the skinny kernel in round 3, the VALU mapping's prefetch costs 1.6 % per step: profiles/r03_skinny_min_batch.txt).
 static inline SrgptPrefetch srgpt_prefetch_for_gemv(const void* W, int N, int K, int swiglu, int fp8, int batch, int rounds,
                                                     int prefix_bytes) {
   SrgptPrefetch pf{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1, 1};
   const long long row_bytes = fp8 ? (long long)K : 2LL * K;
-  if (!W || batch > 2 || rounds <= 0 || row_bytes % 1024 != 0 || (fp8 && swiglu)) return pf;
+  if (!W || batch > 1 || rounds <= 0 || row_bytes % 1024 != 0 || (fp8 && swiglu)) return pf;
   const int cus = srgpt_device_cus();
   const int per_cu = (size_t)batch * K * 2 > 70 * 1024 ? 1 : 2;
   pf.base = reinterpret_cast<const char*>(W);

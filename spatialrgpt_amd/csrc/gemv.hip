@@ -1,4 +1,4 @@
-// Decode-path weight-streaming GEMV (batch <= 4 rows; more rows -> skinny.hip): out[b, n] = W[n, :] . x[b, :]   (HBM-bound)
+// Decode-path weight-streaming GEMV (bf16: one row, fp32: up to 4; more rows -> skinny.hip): out[b, n] = W[n, :] . x[b, :]   (HBM-bound)
 //
 // Roofline: every weight byte is read exactly once per token (non-temporal 16-byte loads, one 1 KiB
 // wave-instruction per row chunk); x lives in LDS; fp32 accumulate on the VALU (24 lane-ops per 16 B --
@@ -486,7 +486,7 @@ int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, con
 template <typename T>
 int dispatch_b(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
                int batch, int N, int K, int swiglu, int out_f32, hipStream_t s) {
-  const int skinny_min = SRGPT_KNOB("SRGPT_SKINNY_MIN_BATCH", 3);  // measured: VALU wins at 1-2 rows, MFMA from 3
+  const int skinny_min = SRGPT_KNOB("SRGPT_SKINNY_MIN_BATCH", 2);  // measured (round 3, profiles/r03_skinny_min_batch.txt): VALU wins at 1 row, MFMA from 2
   if (batch > 4 || (sizeof(T) == 2 && batch >= skinny_min)) {
     // bf16: rows go through the MFMA skinny kernel 16 at a time (skinny.hip); fp32 (parity dtype of the tiny models):
     // 4 rows at a time through the VALU kernel.  Each chunk streams the weights once.

@@ -1,4 +1,4 @@
-// Batched decode-path weight-streaming product for 3..16 rows: out[b, n] = W[n, :] . x[b, :]   (bf16, HBM-bound)
+// Batched decode-path weight-streaming product for 2..16 rows: out[b, n] = W[n, :] . x[b, :]   (bf16, HBM-bound)
 //
 // Same contract and fusions as the GEMV (gemv.hip: RMSNorm prologue, SwiGLU epilogue, residual add, fp32 logits), but
 // above 4 rows the VALU formulation runs out of issue slots and LDS bandwidth (B LDS reads + 8 B FMAs per 16 weight
@@ -493,8 +493,8 @@ extern "C" int srgpt_gemv_w8(const void* x, const void* W8, const float* wscale,
   SRGPT_CHECK(K % 8 == 0, SRGPT_ERR_ARG, "srgpt_gemv_w8: K=%d must be a multiple of 8", K);
   SRGPT_CHECK(!(swiglu && (residual || out_f32)), SRGPT_ERR_ARG, "srgpt_gemv_w8: swiglu excludes residual/out_f32");
   hipStream_t s = as_stream(stream);
-  const int valu_max = SRGPT_KNOB("SRGPT_W8_VALU_MAX_BATCH", 2);  // tuning knob
-  if (batch <= valu_max && batch <= 2 && K % 16 == 0)  // 1-2 rows: VALU kernel (gemv_w8.hip), like the bf16 path
+  const int valu_max = SRGPT_KNOB("SRGPT_W8_VALU_MAX_BATCH", 1);  // tuning knob; 2 rows: the MFMA kernel is 7 % faster per step (round 3)
+  if (batch <= valu_max && batch <= 2 && K % 16 == 0)  // one row: VALU kernel (gemv_w8.hip), like the bf16 path
     return srgpt_gemv_w8_valu(x, W8, wscale, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, s);
   const size_t on = out_f32 ? sizeof(float) : 2;
   for (int b0 = 0; b0 < batch; b0 += 16) {
