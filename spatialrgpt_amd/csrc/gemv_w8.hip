@@ -279,7 +279,7 @@ int launch_gemv_w8(const void* x, const void* W, const float* wscale, const void
 
 }  // namespace
 
-// host entry used by srgpt_gemv_w8 (skinny.hip) for 1-2 rows; K must be a multiple of 16 here
+// host entry used by srgpt_gemv_w8 (skinny.hip) for one row (two under the tuning knob); K must be a multiple of 16 here
 int srgpt_gemv_w8_valu(const void* x, const void* W8, const float* wscale, const void* norm_w, float eps,
                        const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32, hipStream_t s) {
   if (batch == 1) return launch_gemv_w8<1>(x, W8, wscale, norm_w, eps, residual, out, N, K, swiglu, out_f32, s);
