@@ -187,9 +187,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     else return r;
   };
 
-  const int cnt = wave < nsl ? (nsl - wave + NW - 1) / NW : 0;  // slices of this wave
+  // A wave's K slices are ONE contiguous range of the rows (round 3): interleaved over the waves (wave, wave + NW, ...: the first
+  // version) every 512-byte piece of a weight row was fetched by a different wave at a different time -- the same DRAM pages
+  // opened again and again; contiguous ranges stream 5 - 6 % faster at 4 / 8 bf16 rows, 2.5 % at 8 fp8 rows
+  // (profiles/r03_skinny_contig.txt).  -DSRGPT_SKINNY_CONTIG=0 restores the interleaved split (tuning builds).
+#ifndef SRGPT_SKINNY_CONTIG
+#define SRGPT_SKINNY_CONTIG 1
+#endif
+#if SRGPT_SKINNY_CONTIG
+  const int per_wave = (nsl + NW - 1) / NW, first_sl = wave * per_wave;
+  const int cnt = max(0, min(per_wave, nsl - first_sl));  // slices of this wave: [first_sl, first_sl + cnt)
+  auto sl_of = [&](int i) { return first_sl + i; };
+#else
+  const int cnt = wave < nsl ? (nsl - wave + NW - 1) / NW : 0;  // slices of this wave: wave, wave + NW, ...
+  auto sl_of = [&](int i) { return wave + NW * i; };
+#endif
   SK_STAMP(0);
-  load_x(wave);
+  load_x(sl_of(0));
 
   constexpr int DEPTH = W8 ? SRGPT_SKINNY_DEPTH_W8 : SRGPT_SKINNY_DEPTH;
   // measured per decode step (profiles/r02_skinny_ab.txt, section 6): 5-8 rows bf16 -1.8 %, 3-4 rows bf16 +-0, fp8 +0.8..1 % -> bf16 only;
@@ -282,11 +296,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     }
     // pass 0: the first weight stage goes out behind the statistics' own loads (in-order return: the reduction waits for its
     // activations only), so its HBM latency overlaps the reduction and the two block barriers -- as in the GEMV's prologue
-    if (PRE && pass == 0 && do_norm) rms_stats([&]() { issue_w(wb[0], 0, wave, 0, cnt > 0); });
-    else issue_w(wb[0], pass, wave, 0, cnt > 0);
+    if (PRE && pass == 0 && do_norm) rms_stats([&]() { issue_w(wb[0], 0, sl_of(0), 0, cnt > 0); });
+    else issue_w(wb[0], pass, sl_of(0), 0, cnt > 0);
 #pragma unroll
     for (int f = 1; f < DEPTH - 1; ++f)
-      issue_w(wb[f % DEPTH], pass, wave + NW * (f / NSU), f % NSU, f / NSU < cnt);
+      issue_w(wb[f % DEPTH], pass, sl_of(f / NSU), f % NSU, f / NSU < cnt);
     if (pass == 0) SK_STAMP(1);
     // one slice (h-th of the trip that starts at slice index i): NSU stages
     // activation fragments of a slice held across its sub-units where the registers are there (fp8 weights: the stage ring is
@@ -294,17 +308,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     constexpr bool XREUSE = SRGPT_SKINNY_XREUSE != 0 && NSU >= 2 && (W8 ? NI <= 4 : NI == 2);
     auto slice = [&](int i, auto h_c) {
       constexpr int h = decltype(h_c)::value;
-      const int sl = wave + NW * (i + h);
+      const int sl = sl_of(i + h);
       bf16x8 xall[XREUSE ? NS : 1];
       {
 #pragma unroll
           for (int su = 0; su < NSU; ++su) {
             const int cur = (h * NSU + su) % DEPTH;
             const int fn = h * NSU + su + DEPTH - 1;  // stage to prefetch, relative to this trip
-            issue_w(wb[fn % DEPTH], pass, wave + NW * (i + fn / NSU), fn % NSU, i + fn / NSU < cnt);
+            issue_w(wb[fn % DEPTH], pass, sl_of(i + fn / NSU), fn % NSU, i + fn / NSU < cnt);
             if (su == 0) {
               stage_x(sl, true);
-              load_x(i + h + 1 < cnt ? sl + NW : wave);  // next slice, or the first one of the next pass
+              load_x(i + h + 1 < cnt ? sl_of(i + h + 1) : sl_of(0));  // next slice, or the first one of the next pass
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(wst + (2 * j + lrow) * WROWB + lchunk * 16) = staged(wb[cur][j]);
