@@ -141,6 +141,48 @@ __global__ void fill_random(unsigned* p, size_t n, unsigned seed) {
   }
 }
 
+
+// GEMM-shaped weight streaming: a block owns 128 rows and walks K in 64-element steps; one wave-instruction = 8 rows x 128 B
+// (MODE 0: row-major [N][K], what the LDS-DMA GEMMs read) or 1 KiB contiguous (MODE 1: the same bytes pre-tiled [N/128][K/64][128][64]).
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void ktile(const u4* __restrict__ W, float* __restrict__ out, int N, int K) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nk = K / 64, per = nk / gridDim.y, kt0 = blockIdx.y * per;
+  const char* base = reinterpret_cast<const char*>(W);
+  unsigned acc = 0;
+  for (int kt = kt0; kt < kt0 + per; kt += 2) {
+    u4 v[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        size_t off;
+        if (MODE == 0) off = ((size_t)(blockIdx.x * 128 + (wave * 4 + i) * 8 + (lane >> 3)) * K + (size_t)(kt + h) * 64) * 2 + (lane & 7) * 16;
+        else off = ((size_t)blockIdx.x * nk + (kt + h)) * 16384 + (size_t)(wave * 4 + i) * 1024 + lane * 16;
+        v[h * 4 + i] = *reinterpret_cast<const u4*>(base + off);
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc ^= v[j][0] ^ v[j][3];
+  }
+  if (acc == 0x12345u) out[0] = 1.f;
+}
+template <int MODE>
+int runtile(const char* name, hipStream_t s, std::vector<u4*>& Ws, float* out, int N, int K, int splits) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipGraph_t g; hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  for (auto W : Ws) hipLaunchKernelGGL((ktile<MODE>), dim3(N / 128, splits), dim3(256), 0, s, W, out, N, K);
+  CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  float ms = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  const double us = ms * 1e3 / Ws.size(), mb = (double)N * K * 2 / 1e6;
+  printf("  %-58s %7.2f us  (%.2f TB/s)\n", name, us, mb / us);
+  return 0;
+}
+
 template <int DEPTH>
 int runfrag(const char* name, hipStream_t s, std::vector<u4*>& Ws, u4* x, float* out, int N, int K) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -213,6 +255,10 @@ int main() {
     run<4, 4>("V4 depth 4", s, Ws, x, out, N, K);
     runfrag<8>("MFMA 16x16x32, fragment-shaped loads, depth 8", s, Ws, x, out, N, K);
     runfrag<16>("MFMA 16x16x32, fragment-shaped loads, depth 16", s, Ws, x, out, N, K);
+    runtile<0>("GEMM-shaped, row-major: 8 rows x 128 B per instr, 8 K splits", s, Ws, out, N, K, 8);
+    runtile<1>("GEMM-shaped, pre-tiled: 1 KiB contiguous per instr, 8 K splits", s, Ws, out, N, K, 8);
+    runtile<0>("GEMM-shaped, row-major, 2 K splits", s, Ws, out, N, K, 2);
+    runtile<1>("GEMM-shaped, pre-tiled, 2 K splits", s, Ws, out, N, K, 2);
     float* out2; CK(hipMalloc(&out2, 2 * N * 4));
     runfrag8<4>("fp8 fragment loads (16 B/lane), depth 4, 512 blocks", s, Ws, x, out2, N, K, 512);
     runfrag8<8>("fp8 fragment loads, depth 8, 512 blocks", s, Ws, x, out2, N, K, 512);
