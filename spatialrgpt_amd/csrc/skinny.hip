@@ -17,9 +17,10 @@
 // partial: its missing rows are not loaded); cw = ceil(N / blocks) makes every CU stream the same number of weight rows
 // (6144 q/k/v columns = 24 per CU, 14336 gate/up pairs = 56 -- whole 16-column units left a quarter of the CUs with half the
 // work).  A tile is one sub-unit (SwiGLU: the 16 gate rows + the 16 matching up rows = 2 sub-units); up to 4 sub-units per
-// pass keep their 16x16 fp32 accumulators in registers (2 x 4 VGPRs each).  The waves of a block split K in interleaved 256-wide
-// slices, so every block uses all its waves even when it owns a single tile (o_proj / down_proj); their partial sums are added
-// in a fixed order through LDS at the end of the pass (deterministic).
+// pass keep their 16x16 fp32 accumulators in registers (2 x 4 VGPRs each).  The waves of a block split K into one contiguous
+// range of 256-wide slices each (round 3; interleaved slices before: see SRGPT_SKINNY_CONTIG below), so every block uses all its
+// waves even when it owns a single tile (o_proj / down_proj); their partial sums are added in a fixed order through LDS at the end
+// of the pass (deterministic).
 //
 // The K loop is written for counted waits: every load in it is issued unconditionally, so the compiler can leave the
 // prefetched stage in flight across the LDS writes (a branch around a load makes it wait for vmcnt(0) -- the prefetch was being
