@@ -352,8 +352,9 @@ int srgpt_llm_prefill_ragged(const srgpt_llm_weights* w, srgpt_llm_state* st, co
 /* One greedy decode step, entirely device-side: embeds st->tok, runs the layers against the cache,
  * argmax -> st->tok, st->out_ids[:, *step], ++pos, ++*step.  No host sync. */
 int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream);
-/* Health check of the decode step's in-launch hand-off (synchronises `stream`): 0 when every arrival ticket of the decode
- * attention in st->ws is re-armed (zero); SRGPT_ERR_STATE otherwise (srgpt_last_error says which). */
+/* Health check of the decode steps since the last prefill (synchronises `stream` once): 0 when every arrival ticket of the decode
+ * attention in st->ws is re-armed (zero) and no captured step met a caller-written token id outside the embedding table;
+ * SRGPT_ERR_STATE otherwise (srgpt_last_error says which). */
 int srgpt_llm_decode_sync_state(const srgpt_llm_weights* w, const srgpt_llm_state* st, srgpt_stream_t stream);
 /* first token after prefill: argmax(st->logits) -> tok / out_ids[:,0] / step=1 */
 int srgpt_llm_sample_first(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream);
@@ -361,7 +362,8 @@ int srgpt_llm_sample_first(const srgpt_llm_weights* w, srgpt_llm_state* st, srgp
 /* hipGraph capture of one decode step (replayed per token; removes per-launch host cost).  A replay continues from st->tok: normally
  * the token the step before it (srgpt_llm_decode_step, srgpt_llm_sample_first or the previous replay) picked, whose embedding row
  * that step already left in the residual-stream workspace; the captured step's first node compares st->tok with the token that row
- * belongs to and re-embeds when the caller wrote a token of its own into st->tok between replays (ids outside the table are ignored). */
+ * belongs to and re-embeds when the caller wrote a token of its own into st->tok between replays; an id outside the table cannot be
+ * embedded -- the step then runs on the previous row and raises a sticky error that srgpt_llm_decode_sync_state reports. */
 typedef struct srgpt_graph srgpt_graph;
 int srgpt_llm_decode_graph_create(const srgpt_llm_weights* w, srgpt_llm_state* st, srgpt_stream_t stream,
                                   srgpt_graph** out);

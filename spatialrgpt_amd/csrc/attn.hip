@@ -291,7 +291,7 @@ static inline int decode_nsplit(int max_pos, int B, int Hkv) {
 
 // ---- the tail both decode kernels share: arrival ticket of the (sequence, kv head) group, merge by the last arriver ----
 // the MFMA kernel (bf16, head_dim 128): a block owns a FIXED range of 64 keys (4 waves x 16), so ceil(capacity / 64) blocks per
-// (sequence, kv head) -- those past the sequence end publish neutral partials; beyond 64 splits the ranges grow in steps of 64 keys
+// (sequence, kv head) -- those past the sequence end leave at once and the merge skips them; beyond 64 splits the ranges grow in steps of 64 keys
 // and the waves loop
 static inline int decode_nsplit_mfma(int max_pos) {
   const int force = SRGPT_KNOB("SRGPT_DECODE_MIN_SPLITS", 0);  // tuning build: fixed split count
@@ -378,11 +378,20 @@ __device__ __forceinline__ void decode_ticket_merge(float* __restrict__ wbase, i
           n0 = fmaf(sc[gq * SCLD + j], __uint_as_float((unsigned)v[wi][j]), n0);
           n1 = fmaf(sc[gq * SCLD + j], __uint_as_float((unsigned)(v[wi][j] >> 32)), n1);
         }
-      for (int sp = PRE; sp < nsplit; ++sp) {
-        const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)sp * (D + 2)),
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        n0 = fmaf(sc[gq * SCLD + sp], __uint_as_float((unsigned)u), n0);
-        n1 = fmaf(sc[gq * SCLD + sp], __uint_as_float((unsigned)(u >> 32)), n1);
+      // long contexts (> 16 live splits = > 1024 keys on the MFMA kernel): the remaining partials in batches of 16 loads in flight,
+      // consumed in split order -- the same fma chain as one load at a time (48 dependent L2 round trips at 4096 keys before)
+      for (int s0 = PRE; s0 < nsplit; s0 += PRE) {
+        unsigned long long u[PRE];
+#pragma unroll
+        for (int j = 0; j < PRE; ++j)
+          u[j] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(wp + (size_t)min(s0 + j, nsplit - 1) * (D + 2)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < PRE; ++j)
+          if (s0 + j < nsplit) {
+            n0 = fmaf(sc[gq * SCLD + s0 + j], __uint_as_float((unsigned)u[j]), n0);
+            n1 = fmaf(sc[gq * SCLD + s0 + j], __uint_as_float((unsigned)(u[j] >> 32)), n1);
+          }
       }
       T* op = outp + (size_t)gq * D + d;
       op[0] = from_f<T>(n0 * stat_m[gq]);
@@ -678,6 +687,12 @@ __global__ __launch_bounds__(256) void decode_mfma_kernel(const bf16_t* __restri
   // happened to allocate (a pooled state serves requests of different sizes: scripts/soak.py caught exactly that); splits past the
   // sequence publish the neutral partial, which the merge adds as exact zeros
   const int kbeg = split * kpb, kend = min(kbeg + kpb, total);
+  // Only the first ceil(total / kpb) splits own keys.  The blocks behind them leave at once -- no fetch, no RoPE, no partial, no
+  // ticket: a state pooled for a long request (or max_length = 4096 out of a generation_config.json) costs a short request nothing
+  // (ADVICE r3).  The merge covers the `nlive` partials only; the neutral partials the dead splits used to publish entered it as
+  // exact zeros (weight exp(-inf) = 0), so the bits are the ones of the all-splits merge and stay independent of the capacity.
+  const int nlive = min(nsplit, (total + kpb - 1) / kpb);
+  if (split >= nlive) return;  // uniform per block
   const T* row = qkv + (size_t)b * (Hq + 2 * Hkv) * D;
   T* kc = kcache + ((size_t)b * Hkv + hk) * (size_t)max_pos * D;
   T* vc = vcache + ((size_t)b * Hkv + hk) * (size_t)max_pos * D;
@@ -854,10 +869,10 @@ __global__ __launch_bounds__(256) void decode_mfma_kernel(const bf16_t* __restri
       L = fmaf(e, wl[wv][gq], L);
     }
     float* wp = wbase + ((size_t)gq * DEC_SPLIT_MAX + split) * (D + 2);
-    publish2(wp + d, n0, n1);  // an empty split publishes the neutral partial (zeros, m = -inf, l = 0)
+    publish2(wp + d, n0, n1);
     if (d == 0) publish2(wp + D, M, L);
   }
-  decode_ticket_merge<T, D, G, 64>(wbase, tickets + (size_t)b * Hkv + hk, nsplit, out + ((size_t)b * Hq + (size_t)hk * G) * D,
+  decode_ticket_merge<T, D, G, 64>(wbase, tickets + (size_t)b * Hkv + hk, nlive, out + ((size_t)b * Hq + (size_t)hk * G) * D,
                                    &sc[0][0], stat_m, stat_l, tid, lane, wave, hk == 0 && b == 0,
 #ifdef SRGPT_TUNING_KNOBS
                                    stamp_base

@@ -9,13 +9,6 @@ int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const
                               const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D, int max_pos, int dtype,
                               const void* next_w, int next_n, int next_k, int next_fp8, srgpt_stream_t stream);  // attn.hip
 void* srgpt_decode_attn_sync_words(float* ws, int B, int Hq, int D, size_t* bytes);  // attn.hip
-#ifdef SRGPT_TUNING_KNOBS  // experiment (round 3, tuning build only): the persistent GEMV chain, chain.hip
-int srgpt_gemv_chain(const void* const* W, const void* const* norm_w, const void* const* xin, void* const* xout,
-                     const void* const* resid, const int* N, const int* K, const int* swiglu, int nph, float eps, void* bar,
-                     srgpt_stream_t stream);
-#endif
-static inline int srgpt_gemv_chain_bar_words() { return 288; }  // its grid-barrier words live in the workspace of both builds
-
 namespace {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -62,7 +55,7 @@ struct LlmWs {
   float* amax_v;  // [batch, ARGMAX_BLOCKS] partial maxima
   int* amax_i;    // [batch, ARGMAX_BLOCKS] their indices
   int64_t* tok_emb;  // [batch] the token whose embedding row currently sits in xd (-1: none)
-  unsigned int* chain_bar;  // grid-barrier words of the persistent GEMV chain (zero between launches)
+  int* err;          // sticky error word of the decode step (bit 0: a caller-written st->tok outside the table), read by srgpt_llm_decode_sync_state
   void* a8;       // fp8_act: the e4m3 bytes of the current GEMM input [rows, max K]
   float* a8s;     // fp8_act: their per-row scales [rows]
   size_t total;
@@ -91,7 +84,7 @@ LlmWs carve_llm(const srgpt_llm_weights* w, int batch, int max_tokens, void* ws)
   l.amax_v = reinterpret_cast<float*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
   l.amax_i = reinterpret_cast<int*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
   l.tok_emb = reinterpret_cast<int64_t*>(c.take((size_t)batch * 8));
-  l.chain_bar = reinterpret_cast<unsigned int*>(c.take((size_t)srgpt_gemv_chain_bar_words() * 4));
+  l.err = reinterpret_cast<int*>(c.take(sizeof(int)));
   l.a8 = nullptr;
   l.a8s = nullptr;
   if (w->fp8_act) {
@@ -223,20 +216,33 @@ __global__ __launch_bounds__(1024) void advance_kernel(const float* __restrict__
 
 // First node of the CAPTURED decode step: xd must hold the embedding rows of st->tok.  Normally advance_kernel of the step before
 // left exactly those rows (tok_emb == tok: B compares, nothing copied); a caller that wrote its own token into st->tok between
-// replays -- valid under ABI 1/2, silently ignored in ABI 3 -- gets its row re-embedded here.
+// replays -- valid under ABI 1/2, silently ignored in ABI 3 -- gets its row re-embedded here.  A caller-written id
+// outside the table cannot be embedded: the step would run on the previous token's row and return plausible ids, so it sets a
+// sticky error bit that srgpt_llm_decode_sync_state reports.
 __global__ void embed_sync_kernel(const int64_t* __restrict__ tok, int64_t* __restrict__ tok_emb,
                                   const unsigned char* __restrict__ embed, unsigned char* __restrict__ xd, int B, int row_bytes,
-                                  int64_t vocab) {
+                                  int64_t vocab, int* __restrict__ err) {
   const int per_row = row_bytes >> 4;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const int64_t t = tok[b];
-    if (t == tok_emb[b] || t < 0 || t >= vocab) continue;  // uniform per block
+    if (t == tok_emb[b]) continue;  // uniform per block
+    if (t < 0 || t >= vocab) {
+      if (threadIdx.x == 0) atomicOr(err, 1);
+      continue;
+    }
     for (int c = threadIdx.x; c < per_row; c += blockDim.x)
       *reinterpret_cast<u32x4*>(xd + (size_t)b * row_bytes + (size_t)c * 16) =
           *reinterpret_cast<const u32x4*>(embed + (size_t)t * row_bytes + (size_t)c * 16);
     __syncthreads();
     if (threadIdx.x == 0) tok_emb[b] = t;
   }
+}
+
+// the eager step embeds st->tok itself (srgpt_embed_rows): record whose rows are in place, so that the invariant "xd holds the
+// rows of tok_emb" does not depend on a greedy_pick always following
+__global__ void record_embedded_kernel(const int64_t* __restrict__ tok, int64_t* __restrict__ tok_emb, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) tok_emb[b] = tok[b];
 }
 
 // the next step's embedding rows can come from advance_kernel when they are whole 16-byte chunks and the batch fits its LDS list
@@ -368,7 +374,7 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
     SRGPT_HIP_TRY(hipMemsetAsync(sync, 0, sync_bytes, s), "srgpt_llm_prefill: re-arming the decode tickets");
     // no embedding row is in place for the new sequences (-1 matches no token id)
     SRGPT_HIP_TRY(hipMemsetAsync(l.tok_emb, 0xFF, (size_t)B * sizeof(int64_t), s), "srgpt_llm_prefill: resetting the embedded-token record");
-    SRGPT_HIP_TRY(hipMemsetAsync(l.chain_bar, 0, (size_t)srgpt_gemv_chain_bar_words() * 4, s), "srgpt_llm_prefill: re-arming the chain barrier");
+    SRGPT_HIP_TRY(hipMemsetAsync(l.err, 0, sizeof(int), s), "srgpt_llm_prefill: clearing the decode error word");
   }
   if (hipMemcpyAsync(l.x, inputs_embeds, hid_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
     srgpt_set_error("srgpt_llm_prefill: memcpy failed");
@@ -500,10 +506,12 @@ static int decode_step_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, srg
   const size_t layer_kv = (size_t)B * Hkv * st->max_pos * D * es;
   if (embed_first) {
     SRGPT_TRY(srgpt_embed_rows(w->embed, st->tok, d.xd, B, Hd, dt, stream));
+    hipLaunchKernelGGL(record_embedded_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, st->tok, d.tok_emb, B);
+    SRGPT_LAUNCH_CHECK();
   } else {  // captured step: one tiny launch that copies nothing unless the caller changed st->tok behind the graph's back
     hipLaunchKernelGGL(embed_sync_kernel, dim3(B < 64 ? B : 64), dim3(256), 0, s, st->tok, d.tok_emb,
                        reinterpret_cast<const unsigned char*>(w->embed), reinterpret_cast<unsigned char*>(d.xd), B, (int)((size_t)Hd * es),
-                       (int64_t)w->vocab);
+                       (int64_t)w->vocab, d.err);
     SRGPT_LAUNCH_CHECK();
   }
   // fp8 copies present -> the decode step streams them (W8A16, half the bytes per token)
@@ -517,40 +525,16 @@ static int decode_step_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, srg
     if (w8) return srgpt_gemv_w8(x, W8p, sc, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, stream);
     return srgpt_gemv(x, Wd, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, dt, stream);
   };
-  // batch 1, bf16: the four GEMVs between two attention launches (o_proj, gate/up, down, the next layer's qkv) run as ONE persistent
-  // launch whose loader streams the next phase's weights across every dependency edge (chain.hip); bit-identical to the launches
-  // (experiment, tuning build only -- bit-identical, 3.52 ms per token against 2.96 for the launches: profiles/r03_gemv_chain.txt)
-  const bool chain = SRGPT_KNOB("SRGPT_DECODE_CHAIN", 0) && !w8 && dt == SRGPT_BF16 && B == 1;
-  bool qkv_done = false;
   for (int i = 0; i < w->layers; ++i) {
     char* kc = reinterpret_cast<char*>(st->kcache) + (size_t)i * layer_kv;
     char* vc = reinterpret_cast<char*>(st->vcache) + (size_t)i * layer_kv;
-    if (!qkv_done)
-      SRGPT_TRY(mv(d.xd, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, w->attn_norm[i], nullptr,
-                   d.qkvd, QW, Hd, 0, 0));
-    qkv_done = false;
+    SRGPT_TRY(mv(d.xd, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, w->attn_norm[i], nullptr,
+                 d.qkvd, QW, Hd, 0, 0));
     // the attention launch also pulls o_proj's weights into L2 (HBM is idle while it runs).  Round 3 built the next step -- o_proj
     // itself inside this launch, weights in registers, agent-scope hand-off -- bit-exact and 3 us per layer SLOWER
     // (profiles/r03_fused_attention_oproj.txt)
     SRGPT_TRY(srgpt_decode_attention_pf(d.qkvd, kc, vc, st->pos, w->rope_cos, w->rope_sin, d.attnd, d.dws, B, Hq, Hkv, D,
                                         st->max_pos, dt, w8 ? w->wo8[i] : w->wo[i], Hd, Hq * D, w8 ? 1 : 0, stream));
-#ifdef SRGPT_TUNING_KNOBS
-    if (chain) {
-      const bool next = i + 1 < w->layers;
-      const void* cW[4] = {w->wo[i], w->wgu[i], w->wdown[i], next ? w->wqkv[i + 1] : nullptr};
-      const void* cN[4] = {nullptr, w->mlp_norm[i], nullptr, next ? w->attn_norm[i + 1] : nullptr};
-      const void* cX[4] = {d.attnd, d.xd, d.actd, d.xd};
-      void* cO[4] = {d.xd, d.actd, d.xd, d.qkvd};
-      const void* cR[4] = {d.xd, nullptr, d.xd, nullptr};
-      const int cNn[4] = {Hd, I, Hd, QW}, cK[4] = {Hq * D, Hd, I, Hd}, cS[4] = {0, 1, 0, 0};
-      const int rc = srgpt_gemv_chain(cW, cN, cX, cO, cR, cNn, cK, cS, next ? 4 : 3, w->rms_eps, d.chain_bar, stream);
-      if (rc == SRGPT_OK) {
-        qkv_done = next;
-        continue;
-      }
-      if (rc != SRGPT_ERR_UNSUPPORTED) return rc;
-    }
-#endif
     SRGPT_TRY(mv(d.attnd, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, nullptr, d.xd, d.xd, Hd,
                  Hq * D, 0, 0));
     SRGPT_TRY(mv(d.xd, w->wgu[i], w8 ? w->wgu8[i] : nullptr, w8 ? w->wgu_scale[i] : nullptr, w->mlp_norm[i], nullptr,
@@ -566,27 +550,25 @@ extern "C" int srgpt_llm_decode_step(const srgpt_llm_weights* w, srgpt_llm_state
   return decode_step_impl(w, st, stream, true);
 }
 
-// Health of the in-launch hand-off of the decode step (synchronises `stream`): between steps every arrival ticket of the decode
-// attention (the split that draws the last ticket merges and re-arms it) must be zero again -- a non-zero ticket means a launch
-// was aborted or merged nothing, and every later step would silently use stale attention output.  Cheap: once per generate().
+// Health of the decode steps since the last prefill (synchronises `stream` ONCE: both read-backs are queued, then one wait):
+// (1) between steps every arrival ticket of the decode attention (the split that draws the last ticket merges and re-arms it) must
+// be zero again -- a non-zero ticket means a launch was aborted or merged nothing, and every later step would silently use stale
+// attention output; (2) the sticky error word of the captured step (a caller-written token id outside the embedding table).
 extern "C" int srgpt_llm_decode_sync_state(const srgpt_llm_weights* w, const srgpt_llm_state* st, srgpt_stream_t stream) {
   SRGPT_TRY(check_llm(w, st));
   const LlmWs d = carve_llm(w, st->batch, st->ws_tokens, st->ws);
   size_t bytes = 0;
   void* sync = srgpt_decode_attn_sync_words(d.dws, st->batch, w->heads, w->head_dim, &bytes);
-  std::vector<int> host(bytes / sizeof(int));
+  std::vector<int> host(bytes / sizeof(int) + 1);
   SRGPT_HIP_TRY(hipMemcpyAsync(host.data(), sync, bytes, hipMemcpyDeviceToHost, as_stream(stream)), "srgpt_llm_decode_sync_state: copy");
+  SRGPT_HIP_TRY(hipMemcpyAsync(&host.back(), d.err, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)), "srgpt_llm_decode_sync_state: copy");
   SRGPT_HIP_TRY(hipStreamSynchronize(as_stream(stream)), "srgpt_llm_decode_sync_state: synchronize");
-  const size_t n = host.size();
+  const size_t n = host.size() - 1;
   for (size_t i = 0; i < n; ++i)
     SRGPT_CHECK(host[i] == 0, SRGPT_ERR_STATE, "decode step: arrival ticket %zu of %zu is %d between steps (expected 0)", i, n, host[i]);
-  // the persistent GEMV chain's grid-barrier words: re-armed by the last block of every launch; word 273 = a bounded spin expired
-  std::vector<unsigned int> bw((size_t)srgpt_gemv_chain_bar_words());
-  SRGPT_HIP_TRY(hipMemcpyAsync(bw.data(), d.chain_bar, bw.size() * 4, hipMemcpyDeviceToHost, as_stream(stream)), "srgpt_llm_decode_sync_state: copy");
-  SRGPT_HIP_TRY(hipStreamSynchronize(as_stream(stream)), "srgpt_llm_decode_sync_state: synchronize");
-  SRGPT_CHECK(bw[273] == 0, SRGPT_ERR_STATE, "decode step: a bounded wait of the persistent GEMV chain expired");
-  for (size_t i = 0; i < bw.size(); ++i)
-    SRGPT_CHECK(bw[i] == 0, SRGPT_ERR_STATE, "decode step: chain barrier word %zu is %u between steps (expected 0)", i, bw[i]);
+  SRGPT_CHECK((host.back() & 1) == 0, SRGPT_ERR_STATE,
+              "decode step: a token id written into st->tok lies outside the embedding table [0, %d); the step ran on a stale row",
+              w->vocab);
   return SRGPT_OK;
 }
 

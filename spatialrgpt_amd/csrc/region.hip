@@ -99,6 +99,10 @@ __global__ __launch_bounds__(256, MM <= 8 ? 3 : 2) void region_pool_kernel(const
   // one LDS array, two lives: the slab's weights [MM][RP_ROWS] during the FMAs, then the reduce staging [16][MM * VEC][RP_CL]
   constexpr int LDS_BIG = (MM * RP_ROWS > 16 * MM * VEC * RP_CL) ? MM * RP_ROWS : 16 * MM * VEC * RP_CL;
   __shared__ float lds_big[LDS_BIG];
+  // gfx950 only (the library's one target, Makefile ARCH): the 16-mask instance declares ~72 KB of static LDS, which fits the 160 KB of
+  // a CDNA4 CU and no 64 KB-LDS part; say so at compile time instead of failing inside the assembler of another ARCH
+  static_assert(sizeof(float) * (LDS_BIG + MM + MM * 32 + MM * CW) + sizeof(int) <= 160 * 1024,
+                "region_pool_kernel: static LDS exceeds the 160 KB of a gfx950 CU");
   float (*wsm)[RP_ROWS] = reinterpret_cast<float (*)[RP_ROWS]>(lds_big);
   float* rstage = lds_big;
   __shared__ float den[MM];

@@ -331,14 +331,18 @@ class LlavaLlamaModel:
             order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)
             valid = (torch.arange(T, device=keep.device)[None, :] < lens[:, None])
             packed = torch.gather(inputs_embeds, 1, order[:, :, None].expand(-1, -1, inputs_embeds.shape[2]))
-            packed = torch.where(valid[:, :, None], packed, torch.zeros_like(packed))
+            packed.masked_fill_(~valid[:, :, None], 0)
             st, plog, hs = self.engine.prefill(packed, max_new=reserve, all_logits=True,
                                                hidden_states=bool(output_hidden_states), lens=lens, fresh_state=bool(use_cache))
-            plog = torch.where(valid[:, :, None], plog, torch.zeros_like(plog))
-            logits = torch.zeros_like(plog).scatter_(1, order[:, :, None].expand(-1, -1, plog.shape[2]), plog)
+            # one logits-sized result, nothing else of that size (~1 GB per row at T = 2048, V = 128k -- the where /
+            # zeros_like / scatter form held three): padded positions are zeroed in place, then every packed row is scattered to
+            # its padded position -- `order` is a permutation of the T positions, so the scatter fills the whole output
+            plog.masked_fill_(~valid[:, :, None], 0)
+            logits = torch.empty_like(plog).scatter_(1, order[:, :, None].expand(-1, -1, plog.shape[2]), plog)
+            del plog
             if hs is not None:
-                hs = torch.where(valid[None, :, :, None], hs, torch.zeros_like(hs))
-                hs = torch.zeros_like(hs).scatter_(2, order[None, :, :, None].expand(hs.shape[0], -1, -1, hs.shape[3]), hs)
+                hs.masked_fill_(~valid[None, :, :, None], 0)
+                hs = torch.empty_like(hs).scatter_(2, order[None, :, :, None].expand(hs.shape[0], -1, -1, hs.shape[3]), hs)
         else:
             st, logits, hs = self.engine.prefill(inputs_embeds, max_new=reserve, all_logits=True,
                                                  hidden_states=bool(output_hidden_states), fresh_state=bool(use_cache))
