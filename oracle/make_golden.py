@@ -450,6 +450,127 @@ def mint_checkpoint():
     print("  wrote ckpt_tiny/ and ckpt_tiny_kat.npz; reference ids:", gen.tolist())
 
 
+def mint_vendored_llama_kat():
+    """The reference's VENDORED Llama file (llava/train/transformers_replace/models/llama/modeling_llama.py: the decoder the
+    reference actually runs -- LlamaFlashAttention2 hard-wired at :611-619, LlamaLinearScalingRotaryEmbedding :133-140) executed
+    on CPU with oracle/flash_attn_cpu.py standing in for the flash-attn CUDA extension, under `rope_scaling = {linear, 3.0}` as
+    context_length_extension writes it (language_model/builder.py:31-38; 3.0 is not a power of two, so "divide the positions" and
+    "divide inv_freq" round differently and the fixture tells them apart).  Cases:
+      single : one 40-token prompt, fp32 -- all-position logits, then 10 greedy steps over the returned cache (positions 40..49
+               of a model whose max_position_embeddings is 32: beyond the original context, the reason the scaling exists)
+      ragged : a right-padded batch (lengths 40 / 23) with the attention mask, position ids and seqlens_in_batch the LLaVA wrapper
+               passes (llava_llama.py:150-176) -- the varlen / unpad branch of _flash_attention_forward
+      bf16   : the single case in bfloat16
+    Asserts that oracle.llama_forward reproduces all of them (fp32: 2e-6 of the logit range, ids equal; bf16: 3e-2) and writes
+    tests/golden/vendored_llama_kat.npz."""
+    m = rh.install_vendored_llama()
+    from transformers import LlamaConfig
+
+    geo = dict(hidden_size=64, intermediate_size=160, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+               vocab_size=128, max_position_embeddings=32, rms_norm_eps=1e-5)
+    factor, theta = 3.0, 10000.0
+    lc = LlamaConfig(**geo)
+    for k, v in dict(rope_theta=theta, rope_scaling={"type": "linear", "factor": factor}, attention_bias=False,
+                     attention_dropout=0.0, pretraining_tp=1, use_cache=True, output_attentions=False,
+                     output_hidden_states=False).items():
+        setattr(lc, k, v)  # transformers 5 moved / dropped these LlamaConfig fields; the vendored file reads the 4.37.2 names
+    torch.manual_seed(11)
+    lm = m.LlamaForCausalLM(lc).eval()
+    assert type(lm.model.layers[0].self_attn).__name__ == "LlamaFlashAttention2"
+    assert type(lm.model.layers[0].self_attn.rotary_emb).__name__ == "LlamaLinearScalingRotaryEmbedding"
+    with torch.no_grad():  # spread the logits (default init gives a near-flat distribution: argmax would sit on rounding noise)
+        lm.lm_head.weight.mul_(8.0)
+        lm.model.embed_tokens.weight.mul_(20.0)
+    sd = {"llm." + k: v.detach().clone() for k, v in lm.state_dict().items() if "rotary_emb" not in k}
+    cfg = so.SrgptConfig(hidden=64, inter=160, layers=2, heads=4, kv_heads=2, vocab=128, rms_eps=1e-5, rope_theta=theta,
+                         rope_factor=factor, mask_token_id=126, depth_token_id=127)
+    g = torch.Generator().manual_seed(5)
+    T, G = 40, 10
+    ids = torch.randint(3, 120, (1, T), generator=g)
+    out = {"geo_json": np.frombuffer(json.dumps(dict(geo, rope_theta=theta, rope_factor=factor)).encode(), dtype=np.uint8)}
+    for k, v in sd.items():
+        out["w." + k] = v.numpy()
+
+    def run_single(model, dtype):
+        with torch.no_grad():
+            o = model(input_ids=ids, use_cache=True)
+            logits, past = o.logits, o.past_key_values
+            new, steps = [], []
+            nxt = logits[:, -1].argmax(-1)
+            for t in range(G):
+                new.append(nxt)
+                o = model(input_ids=nxt[:, None], past_key_values=past, use_cache=True,
+                          position_ids=torch.tensor([[T + t]]))
+                past = o.past_key_values
+                steps.append(o.logits[:, -1])
+                nxt = o.logits[:, -1].argmax(-1)
+        return logits, torch.stack(new, 1), torch.stack(steps, 1)
+
+    def oracle_single(w, dtype):
+        kv = so.KVCache(cfg.layers)
+        emb = torch.nn.functional.embedding(ids, w["llm.model.embed_tokens.weight"])
+        logits = so.llama_forward(w, cfg, emb, torch.arange(T)[None], kv)
+        new, steps = [], []
+        nxt = logits[:, -1].argmax(-1)
+        for t in range(G):
+            new.append(nxt)
+            e = torch.nn.functional.embedding(nxt[:, None], w["llm.model.embed_tokens.weight"])
+            lg = so.llama_forward(w, cfg, e, torch.tensor([[T + t]]), kv, last_only=True)[:, -1]
+            steps.append(lg)
+            nxt = lg.argmax(-1)
+        return logits, torch.stack(new, 1), torch.stack(steps, 1)
+
+    ref_l, ref_ids, ref_s = run_single(lm, torch.float32)
+    got_l, got_ids, got_s = oracle_single(sd, torch.float32)
+    rng = float(ref_l.abs().max())
+    top2 = ref_s.topk(2, -1).values
+    print(f"  vendored llama fp32: logit range {rng:.2f}, min top-1/top-2 margin over the {G} steps {float((top2[..., 0] - top2[..., 1]).min()):.3f}")
+    check("vendored.single.prefill_logits", got_l, ref_l, 2e-6 * rng)
+    check("vendored.single.step_logits", got_s, ref_s, 2e-6 * rng)
+    assert torch.equal(got_ids, ref_ids), (got_ids, ref_ids)
+    out.update({"single.ids": ids.numpy(), "single.prefill_logits": ref_l.numpy(), "single.new_ids": ref_ids.numpy(),
+                "single.step_logits": ref_s.numpy()})
+
+    # the rotary tables of the vendored class itself (fp32 and bf16), positions 0 .. 63: pins weights.rope_tables bit for bit
+    rot = lm.model.layers[0].self_attn.rotary_emb
+    pp = torch.arange(64)[None]
+    c32, s32 = rot(torch.zeros(1, dtype=torch.float32), pp)
+    c16, s16 = rot(torch.zeros(1, dtype=torch.bfloat16), pp)
+    oc, osn = so.rope_cos_sin(cfg, pp, torch.float32)
+    assert torch.equal(oc, c32) and torch.equal(osn, s32)
+    half = cfg.head_dim // 2
+    out.update({"rope.cos_f32": c32[0, :, :half].numpy(), "rope.sin_f32": s32[0, :, :half].numpy(),
+                "rope.cos_bf16": c16[0, :, :half].float().numpy(), "rope.sin_bf16": s16[0, :, :half].float().numpy()})
+
+    # ragged right-padded batch through the unpad / varlen branch, called the way LlavaLlamaModel.forward calls the LLM
+    lens = [40, 23]
+    ids2 = torch.randint(3, 120, (2, T), generator=g)
+    am = torch.zeros((2, T), dtype=torch.long)
+    pos2 = torch.zeros((2, T), dtype=torch.long)
+    for b, n in enumerate(lens):
+        am[b, :n] = 1
+        pos2[b, :n] = torch.arange(n)
+    with torch.no_grad():
+        o2 = lm(input_ids=ids2, attention_mask=am, position_ids=pos2, seqlens_in_batch=am.sum(-1).int(), use_cache=False)
+    emb2 = torch.nn.functional.embedding(ids2, sd["llm.model.embed_tokens.weight"])
+    got2 = so.llama_forward(sd, cfg, emb2, pos2, so.KVCache(cfg.layers), key_padding_mask=am.bool())
+    for b, n in enumerate(lens):
+        check(f"vendored.ragged.row{b}", got2[b, :n], o2.logits[b, :n], 2e-6 * rng)
+    out.update({"ragged.ids": ids2.numpy(), "ragged.lens": np.array(lens), "ragged.logits": o2.logits.numpy()})
+
+    lm16 = m.LlamaForCausalLM(lc).eval()
+    lm16.load_state_dict(lm.state_dict())
+    lm16 = lm16.to(torch.bfloat16)
+    sd16 = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+    b_l, b_ids, b_s = run_single(lm16, torch.bfloat16)
+    o_l, o_ids, o_s = oracle_single(sd16, torch.bfloat16)
+    check("vendored.bf16.prefill_logits", o_l, b_l, 3e-2 * rng)
+    check("vendored.bf16.step_logits", o_s, b_s, 3e-2 * rng)
+    out.update({"bf16.prefill_logits": b_l.float().numpy(), "bf16.new_ids": b_ids.numpy(), "bf16.step_logits": b_s.float().numpy()})
+    np.savez_compressed(os.path.join(GOLD, "vendored_llama_kat.npz"), **out)
+    print("  wrote vendored_llama_kat.npz; vendored greedy ids:", ref_ids.tolist(), " bf16:", b_ids.tolist())
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -458,6 +579,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt":  # only the reference-written checkpoint directory
         mint_checkpoint()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "vendored":  # only the vendored-Llama fixture (rope scaling, flash-attn call sites)
+        mint_vendored_llama_kat()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "labels":  # only the labels / loss fixture (reuses tiny_fp32.npz's weights)
         mint_labels_kat()
@@ -470,4 +594,5 @@ if __name__ == "__main__":
     mint_labels_kat()
     mint_posembed_kat()
     mint_checkpoint()
+    mint_vendored_llama_kat()
     print("golden vectors written to", GOLD)

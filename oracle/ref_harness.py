@@ -116,6 +116,47 @@ def install_shims() -> None:
     _installed = True
 
 
+_vendored = None
+
+
+def install_vendored_llama():
+    """Load the reference's VENDORED Llama (llava/train/transformers_replace/models/llama/modeling_llama.py -- the file the
+    reference copies over transformers' own, environment_setup.sh:33-35) from where it lies, as a module inside the installed
+    `transformers.models.llama` package so that its relative imports resolve.  Its decoder layer hard-wires
+    `LlamaFlashAttention2` (:611-619) and the file imports `flash_attn` at module level: `oracle/flash_attn_cpu.py` (a plain-torch
+    restatement of flash-attn's published semantics) stands in for that CUDA extension.  Returns the module."""
+    global _vendored
+    if _vendored is not None:
+        return _vendored
+    install_shims()
+    import importlib.util
+
+    import transformers.models.llama  # noqa: F401
+
+    from oracle import flash_attn_cpu
+
+    fa = types.ModuleType("flash_attn")
+    fa.flash_attn_func = flash_attn_cpu.flash_attn_func
+    fa.flash_attn_varlen_func = flash_attn_cpu.flash_attn_varlen_func
+    fa.__spec__ = importlib.machinery.ModuleSpec("flash_attn", None)
+    fa.__path__ = []
+    bp = types.ModuleType("flash_attn.bert_padding")
+    bp.index_first_axis = flash_attn_cpu.index_first_axis
+    bp.pad_input = flash_attn_cpu.pad_input
+    bp.unpad_input = flash_attn_cpu.unpad_input
+    bp.__spec__ = importlib.machinery.ModuleSpec("flash_attn.bert_padding", None)
+    fa.bert_padding = bp
+    sys.modules["flash_attn"] = fa
+    sys.modules["flash_attn.bert_padding"] = bp
+    path = os.path.join(REFERENCE_ROOT, "llava/train/transformers_replace/models/llama/modeling_llama.py")
+    spec = importlib.util.spec_from_file_location("transformers.models.llama._srgpt_vendored_modeling_llama", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    _vendored = mod
+    return mod
+
+
 # ------------------------------------------------------------------------------------------------
 # tiny on-disk sub-models so that the reference's own builders (from_pretrained based) can run
 # ------------------------------------------------------------------------------------------------

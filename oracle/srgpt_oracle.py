@@ -381,10 +381,14 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor: 
 def rope_cos_sin(cfg: SrgptConfig, position_ids: torch.Tensor, dtype):  # modeling_llama.py:81-140
     d = cfg.head_dim
     inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
+    pos = position_ids.float()
     if cfg.rope_factor != 1.0:
-        inv_freq = inv_freq / cfg.rope_factor  # linear scaling == dividing positions
+        # LlamaLinearScalingRotaryEmbedding.forward (modeling_llama.py:133-140): the POSITIONS are divided, in fp32, before the
+        # product with inv_freq.  (transformers >= 4.45 divides inv_freq instead: the same angles only for power-of-two factors;
+        # context_length_extension, language_model/builder.py:31-38, produces any integer factor.)
+        pos = pos / cfg.rope_factor
     freqs = (inv_freq[None, :, None].float().expand(position_ids.shape[0], -1, 1)
-             @ position_ids[:, None, :].float()).transpose(1, 2)
+             @ pos[:, None, :]).transpose(1, 2)
     emb = torch.cat((freqs, freqs), dim=-1)
     return emb.cos().to(dtype), emb.sin().to(dtype)
 

@@ -35,9 +35,12 @@ def _ptr_array(tensors: List[torch.Tensor]):
 def rope_tables(cfg: SrgptConfig, n_pos: int, dtype, device):
     d = cfg.head_dim
     inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.int64).float() / d))
-    if cfg.rope_factor != 1.0:
-        inv_freq = inv_freq / cfg.rope_factor
     pos = torch.arange(n_pos, dtype=torch.int64).float()
+    if cfg.rope_factor != 1.0:
+        # linear scaling (context_length_extension, language_model/builder.py:31-38): the reference's vendored
+        # LlamaLinearScalingRotaryEmbedding divides the fp32 POSITIONS (modeling_llama.py:133-140); dividing inv_freq instead
+        # rounds differently for factors that are not powers of two (pinned by tests/golden/vendored_llama_kat.npz)
+        pos = pos / cfg.rope_factor
     freqs = pos[:, None] * inv_freq[None, :]  # fp32, as LlamaRotaryEmbedding (autocast disabled)
     return freqs.cos().to(dtype).to(device).contiguous(), freqs.sin().to(dtype).to(device).contiguous()
 

@@ -302,6 +302,9 @@ def _attn_ref(q, k, v, causal, kv_len=None):
     (1, 130, 130, 4, 4, 16, True),     # tiny config
     (2, 65, 200, 4, 2, 64, True),      # Tq != Tk causal offset
     (1, 64, 64, 2, 1, 32, False),
+    (1, 2048, 2048, 8, 2, 128, True),  # long prompts (model_max_length 4096, scripts/srgpt/llama3_8b/3_sft.sh:58): 32 / 64 key tiles per
+    (1, 4096, 4096, 4, 1, 128, True),  # query block, the online rescale runs the whole way
+    (1, 700, 4096, 4, 2, 128, True),   # a late chunk of queries against a long cache (causal offset Tk - Tq = 3396)
 ])
 def test_attention(dtype, B, Tq, Tk, Hq, Hkv, D, causal):
     ops, L = _ops()
@@ -334,7 +337,10 @@ def test_attention_packed_qkv_and_kvlen():
     # beyond 64 x 64 positions where every wave walks more than one key group (online rescale of the running P.V)
     (1, 4, 4, 128, 0, 512), (1, 4, 4, 128, 1, 512), (2, 8, 4, 128, 15, 512), (1, 8, 4, 128, 16, 512), (1, 32, 8, 128, 63, 512),
     (1, 32, 8, 128, 64, 512), (3, 32, 8, 128, 259, 512), (1, 16, 2, 128, 386, 512), (1, 32, 8, 128, 511, 512),
-    (1, 8, 2, 128, 5000, 8192), (2, 4, 4, 128, 8000, 8192)])
+    (1, 8, 2, 128, 5000, 8192), (2, 4, 4, 128, 8000, 8192),
+    # long contexts in a 4096-position cache (64 fixed 64-key splits): 32 and 63 live splits -- the merge walks them in batches of
+    # 16 -- and a short sequence in the same cache (5 live splits, 59 blocks per kv head leave at once)
+    (1, 32, 8, 128, 2047, 4096), (1, 32, 8, 128, 4000, 4096), (2, 32, 8, 128, 300, 4096), (1, 32, 8, 128, 1030, 4096)])
 def test_rope_append_and_decode_attention(dtype, B, Hq, Hkv, D, P, max_pos):
     """prefill RoPE+append of P tokens, then one decode step; both against the oracle's rotary + softmax."""
     from oracle import srgpt_oracle as so

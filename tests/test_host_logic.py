@@ -244,3 +244,27 @@ def test_fp8_quantisation_rules_agree_between_host_and_oracle():
     x3 = xb.view(5, 8, 256)
     assert torch.equal(so.fp8_rowwise_fake_quant(x3).view(40, 256), deq)
     assert inspect.signature(so.llama_forward).parameters["act_quant"].default is None
+
+
+def test_rope_tables_follow_the_vendored_linear_scaling_class_bit_for_bit():
+    """weights.rope_tables (the tables srgpt_rope_kv_append / srgpt_decode_attention index) == cos / sin of the reference's vendored
+    LlamaLinearScalingRotaryEmbedding (modeling_llama.py:133-140) under rope_scaling {linear, 3.0}, fp32 and bf16, positions
+    0 .. 63 of a model with max_position_embeddings 32 (tests/golden/vendored_llama_kat.npz; context_length_extension,
+    language_model/builder.py:31-38)."""
+    import json
+    import os
+
+    import numpy as np
+
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.weights import rope_tables
+    from tests.util import GOLD
+
+    z = np.load(os.path.join(GOLD, "vendored_llama_kat.npz"))
+    geo = json.loads(bytes(z["geo_json"]).decode())
+    cfg = SrgptConfig(hidden=geo["hidden_size"], heads=geo["num_attention_heads"], kv_heads=geo["num_key_value_heads"],
+                      rope_theta=geo["rope_theta"], rope_factor=geo["rope_factor"])
+    c32, s32 = rope_tables(cfg, 64, torch.float32, "cpu")
+    assert torch.equal(c32, torch.from_numpy(z["rope.cos_f32"])) and torch.equal(s32, torch.from_numpy(z["rope.sin_f32"]))
+    c16, s16 = rope_tables(cfg, 64, torch.bfloat16, "cpu")
+    assert torch.equal(c16.float(), torch.from_numpy(z["rope.cos_bf16"])) and torch.equal(s16.float(), torch.from_numpy(z["rope.sin_bf16"]))
