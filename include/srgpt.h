@@ -230,6 +230,30 @@ int srgpt_cross_entropy(const float* logits, const int64_t* labels, float* row_l
                         int64_t ignore_index, srgpt_stream_t stream);
 
 
+/* Sampling parameters of the decode step (ABI 6): a block in DEVICE memory, read by the kernels of every step -- one captured graph
+ * serves every setting; the host rewrites the block between requests (hipMemcpyAsync on the decode stream).  The warper chain is
+ * HF GenerationMixin.sample's, as the reference's interactive callers reach it (demo/gradio_web_server_multi.py:202-213,
+ * llava/eval/model_vqa.py:66-80): scores = logits / temperature -> TopKLogitsWarper (everything below the k-th largest score is
+ * removed, ties at it kept) -> TopPLogitsWarper (ascending cumulative softmax; entries whose cumulative mass is <= 1 - top_p are
+ * removed, never the largest) -> one categorical draw from the softmax of what is left.
+ *   top_k 1 .. 64; top_k = 0: no top-k filter -- then top_p must be >= 1 (pure temperature sampling, drawn by Gumbel-max over the
+ *   whole vocabulary).  Other settings (top_k > 64; top_p < 1 without top_k) are not served on the device.
+ *   Randomness: Philox4x32-10, key = seed, counter = (counter, sequence, ...); every step advances `counter` by one. */
+typedef struct {
+  float temperature;   /* > 0 */
+  int top_k;
+  float top_p;         /* (0, 1]; >= 1 switches the top-p filter off */
+  float top_p_rm;      /* (float)(1.0 - (double)top_p): the removal threshold exactly as HF's comparison sees it */
+  uint64_t seed;
+  uint64_t counter;
+  int* kept_out;       /* parity hook (device, may be NULL): int[batch][257] = the kept-set size, then its token ids best first */
+} srgpt_sampling;
+
+/* Stand-alone draw over fp32 logits [B, V] with the parameter block above (what the decode step runs after its lm_head):
+ * tok_out[b] = the drawn id; advances sp->counter.  ws = srgpt_sample_ws_bytes(B) bytes of scratch.  V <= 262144. */
+int64_t srgpt_sample_ws_bytes(int B);
+int srgpt_sample(const float* logits, srgpt_sampling* sp, int64_t* tok_out, void* ws, int B, int V, srgpt_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Composite: vision tower (VisionTower.forward, multimodal_encoder/vision_encoder.py:115-132 over HF
  * SiglipVisionModel; returns hidden_states[select_layer], i.e. runs `n_layers_run` encoder layers).
@@ -334,6 +358,8 @@ typedef struct {
                    * must be zero before a decode step: every srgpt_llm_prefill* zeroes them (so a hipMalloc'ed, never-zeroed
                    * workspace is fine as long as a prefill precedes the first step, which it must anyway) */
   float* logits;  /* [batch, vocab] fp32 (last position) */
+  srgpt_sampling* sampling; /* ABI 6: DEVICE pointer or NULL.  NULL: greedy (argmax).  Set: srgpt_llm_sample_first / srgpt_llm_decode_step
+                             * and the graphs captured from this state DRAW the next token (see srgpt_sampling) */
 } srgpt_llm_state;
 
 int64_t srgpt_llm_ws_bytes(const srgpt_llm_weights* w, int batch, int max_tokens);

@@ -53,10 +53,21 @@ class LlmState(C.Structure):
     _fields_ = [
         ("batch", i32), ("max_pos", i32), ("kcache", vp), ("vcache", vp), ("pos", vp), ("tok", vp),
         ("out_ids", vp), ("step", vp), ("max_new", i32), ("ws_tokens", i32), ("ws", vp), ("logits", vp),
+        ("sampling", vp),  # ABI 6: device pointer to a Sampling block, or NULL = greedy
     ]
 
 
-ABI_VERSION = 5  # include/srgpt.h; bumped with every export / layout change
+class Sampling(C.Structure):
+    """srgpt_sampling (include/srgpt.h): the parameter block of the device-side draw; lives in DEVICE memory (40 bytes)."""
+    _fields_ = [("temperature", f32), ("top_k", i32), ("top_p", f32), ("top_p_rm", f32), ("seed", C.c_uint64),
+                ("counter", C.c_uint64), ("kept_out", vp)]
+
+
+SAMPLING_TOP_K_MAX = 64        # sample.hip SMP_K
+SAMPLING_KEPT_MAX = 256        # sample.hip SMP_LIST
+SAMPLING_VOCAB_MAX = 128 * 2048
+
+ABI_VERSION = 6  # include/srgpt.h; bumped with every export / layout change
 
 _SIGNATURES = {
     "srgpt_last_error": (C.c_char_p, []),
@@ -89,6 +100,8 @@ _SIGNATURES = {
     "srgpt_silu_mul": (i32, [vp, vp, i32, i32, i32, vp]),
     "srgpt_argmax": (i32, [vp, vp, i32, i32, vp]),
     "srgpt_cross_entropy": (i32, [vp, vp, vp, vp, i32, i32, i64, vp]),
+    "srgpt_sample_ws_bytes": (i64, [i32]),
+    "srgpt_sample": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "srgpt_image_resize_normalize": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp]),
     "srgpt_mask_resize_nearest": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp]),
     "srgpt_vit_assemble_cls": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

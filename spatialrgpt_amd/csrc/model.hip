@@ -9,6 +9,9 @@ int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const
                               const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D, int max_pos, int dtype,
                               const void* next_w, int next_n, int next_k, int next_fp8, srgpt_stream_t stream);  // attn.hip
 void* srgpt_decode_attn_sync_words(float* ws, int B, int Hq, int D, size_t* bytes);  // attn.hip
+int srgpt_sample_launch(const float* logits, const srgpt_sampling* sp, int64_t* tok, void* ws, float* pv, int* pi, int* err, int B, int V,
+                        hipStream_t s);  // sample.hip
+extern "C" int srgpt_sample_slices(void);
 namespace {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -55,6 +58,7 @@ struct LlmWs {
   float* amax_v;  // [batch, ARGMAX_BLOCKS] partial maxima
   int* amax_i;    // [batch, ARGMAX_BLOCKS] their indices
   int64_t* tok_emb;  // [batch] the token whose embedding row currently sits in xd (-1: none)
+  void* smp;         // sampling: the slices' top-k candidates (srgpt_sample_ws_bytes)
   int* err;          // sticky error word of the decode step (bit 0: a caller-written st->tok outside the table), read by srgpt_llm_decode_sync_state
   void* a8;       // fp8_act: the e4m3 bytes of the current GEMM input [rows, max K]
   float* a8s;     // fp8_act: their per-row scales [rows]
@@ -85,6 +89,7 @@ LlmWs carve_llm(const srgpt_llm_weights* w, int batch, int max_tokens, void* ws)
   l.amax_i = reinterpret_cast<int*>(c.take((size_t)batch * ARGMAX_BLOCKS * 4));
   l.tok_emb = reinterpret_cast<int64_t*>(c.take((size_t)batch * 8));
   l.err = reinterpret_cast<int*>(c.take(sizeof(int)));
+  l.smp = c.take((size_t)srgpt_sample_ws_bytes(batch));
   l.a8 = nullptr;
   l.a8s = nullptr;
   if (w->fp8_act) {
@@ -152,14 +157,17 @@ constexpr int ADVANCE_MAXB = 256;
 __global__ __launch_bounds__(1024) void advance_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int nb, int64_t* tok,
                                int64_t* out_ids, int* pos, int* step, int B, int max_new, int bump_pos,
                                const unsigned char* __restrict__ embed, unsigned char* __restrict__ xd, int row_bytes,
-                               int64_t* __restrict__ tok_emb) {
+                               int64_t* __restrict__ tok_emb, srgpt_sampling* __restrict__ sp) {
   __shared__ int picked[ADVANCE_MAXB];
   const int s = *step;
   const int lane = threadIdx.x & 63;
+  // sampling with a top-k filter: sample_select_kernel already drew tok[b]; greedy and Gumbel-max sampling (top_k = 0): the slices'
+  // maxima are merged here
+  const bool drawn = sp != nullptr && sp->top_k > 0;
   for (int b = threadIdx.x >> 6; b < B; b += blockDim.x >> 6) {
     float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = lane; i < nb; i += 64) {
+    int bi = drawn ? (int)tok[b] : 0x7fffffff;
+    for (int i = lane; i < (drawn ? 0 : nb); i += 64) {
       const float v = pv[(size_t)b * nb + i];
       const int ix = pi[(size_t)b * nb + i];
       if (v > best || (v == best && ix < bi)) {
@@ -188,7 +196,10 @@ __global__ __launch_bounds__(1024) void advance_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) *step = s + 1;
+  if (threadIdx.x == 0) {
+    *step = s + 1;
+    if (sp) sp->counter += 1;  // the next step draws from a fresh Philox counter
+  }
   if (embed) {
     // the rows of the picked tokens, four independent 16-byte loads in flight per thread (one at a time, a dependent load -> store
     // chain per chunk, this copy was 8 of the kernel's 13 us at 8 sequences)
@@ -250,13 +261,19 @@ static inline bool advance_embeds(const srgpt_llm_weights* w, const srgpt_llm_st
   return st->batch <= ADVANCE_MAXB && ((size_t)w->hidden * dtype_size(w->dtype)) % 16 == 0;
 }
 
+// the next token of every sequence from st->logits: argmax (st->sampling == NULL) or a draw (sample.hip), then the bookkeeping
 static int greedy_pick(const srgpt_llm_weights* w, srgpt_llm_state* st, const LlmWs& d, int bump_pos, hipStream_t s) {
   const int B = st->batch;
   const bool emb = advance_embeds(w, st);
-  hipLaunchKernelGGL(argmax_partial_kernel, dim3(ARGMAX_BLOCKS, B), dim3(256), 0, s, st->logits, d.amax_v, d.amax_i, w->vocab);
+  if (st->sampling) {
+    SRGPT_CHECK(srgpt_sample_slices() == ARGMAX_BLOCKS, SRGPT_ERR_STATE, "sampling: slice count differs from the argmax merge's");
+    SRGPT_TRY(srgpt_sample_launch(st->logits, st->sampling, st->tok, d.smp, d.amax_v, d.amax_i, d.err, B, w->vocab, s));
+  } else {
+    hipLaunchKernelGGL(argmax_partial_kernel, dim3(ARGMAX_BLOCKS, B), dim3(256), 0, s, st->logits, d.amax_v, d.amax_i, w->vocab);
+  }
   hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(B > 4 ? 1024 : 256), 0, s, d.amax_v, d.amax_i, ARGMAX_BLOCKS, st->tok, st->out_ids,
                      st->pos, st->step, B, st->max_new, bump_pos, emb ? reinterpret_cast<const unsigned char*>(w->embed) : nullptr,
-                     reinterpret_cast<unsigned char*>(d.xd), (int)((size_t)w->hidden * dtype_size(w->dtype)), d.tok_emb);
+                     reinterpret_cast<unsigned char*>(d.xd), (int)((size_t)w->hidden * dtype_size(w->dtype)), d.tok_emb, st->sampling);
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }
@@ -566,6 +583,8 @@ extern "C" int srgpt_llm_decode_sync_state(const srgpt_llm_weights* w, const srg
   const size_t n = host.size() - 1;
   for (size_t i = 0; i < n; ++i)
     SRGPT_CHECK(host[i] == 0, SRGPT_ERR_STATE, "decode step: arrival ticket %zu of %zu is %d between steps (expected 0)", i, n, host[i]);
+  SRGPT_CHECK((host.back() & 2) == 0, SRGPT_ERR_STATE,
+              "decode step: more than 256 vocabulary entries tie at the top-k threshold of a sampling step (kept set truncated)");
   SRGPT_CHECK((host.back() & 1) == 0, SRGPT_ERR_STATE,
               "decode step: a token id written into st->tok lies outside the embedding table [0, %d); the step ran on a stale row",
               w->vocab);

@@ -48,26 +48,40 @@ class DecodeState:
         st.kcache, st.vcache = self.kcache.data_ptr(), self.vcache.data_ptr()
         st.pos, st.tok, st.out_ids, st.step = self.pos.data_ptr(), self.tok.data_ptr(), self.out_ids.data_ptr(), self.step.data_ptr()
         st.ws, st.logits = self.ws.data_ptr(), self.logits.data_ptr()
+        st.sampling = None
         self.c = st
         self.host_len = [0] * batch  # cached positions per row as known on the host (prefill lengths + steps taken)
-        self.graph = None
+        self.graphs = {}             # "greedy" / "sample" -> captured decode step (the pick kernels differ)
+        self.sampling: Optional[ops.SamplingParams] = None  # device parameter block of the draw; ONE address for the state's lifetime
         self._eng = eng
 
     def seq_len(self) -> int:
         """cached positions (longest row) -- what `past_key_values[-1][-1].shape[-2]` is for the reference (llava_arch.py:364)."""
         return max(self.host_len)
 
+    def set_sampling(self, sampling: Optional[dict]):
+        """None: the step picks argmax.  dict(temperature, top_k, top_p, seed): the step DRAWS (sample.hip); the parameters go to
+        the state's device block (one small H2D copy), so the graph captured for sampling serves every setting."""
+        if sampling is None:
+            self.c.sampling = None
+            return
+        if self.sampling is None:
+            self.sampling = ops.SamplingParams(self._eng.device, self.batch)
+        self.sampling.set(sampling["temperature"], sampling.get("top_k"), sampling.get("top_p"), sampling.get("seed", 0))
+        self.c.sampling = self.sampling.ptr()
+
     def ensure_graph(self):
-        if self.graph is None:
+        key = "greedy" if not self.c.sampling else "sample"
+        if key not in self.graphs:
             g = L.vp()
             L.check(L.load().srgpt_llm_decode_graph_create(C.byref(self._eng.w.llm), C.byref(self.c), ops._stream(), C.byref(g)))
-            self.graph = g
-        return self.graph
+            self.graphs[key] = g
+        return self.graphs[key]
 
     def __del__(self):
         try:
-            if self.graph is not None:
-                L.load().srgpt_graph_destroy(self.graph)
+            for g in self.graphs.values():
+                L.load().srgpt_graph_destroy(g)
         except Exception:
             pass
 
@@ -438,12 +452,18 @@ class SrgptEngine:
         return st.logits.clone()
 
     def greedy_decode(self, st: DecodeState, max_new_tokens: int, eos_token_id=None, pad_token_id=None,
-                      stopping_criteria=None, check_every: int = 8) -> torch.Tensor:
-        """HF greedy loop semantics (new ids only, finished rows padded), device-side steps via hipGraph."""
+                      stopping_criteria=None, check_every: int = 8, sampling: Optional[dict] = None) -> torch.Tensor:
+        """HF generation-loop semantics (new ids only, finished rows padded), device-side steps via hipGraph.
+        sampling = None: greedy.  sampling = dict(temperature, top_k, top_p, seed): every step DRAWS its token on the device
+        (temperature -> top-k -> top-p -> categorical, sample.hip) -- same loop, same graph mechanism, no per-token host work."""
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            n_keep, eos = self._decode_loop(st, max_new_tokens, eos_token_id, stopping_criteria, check_every)
+            st.set_sampling(sampling)
+            try:
+                n_keep, eos = self._decode_loop(st, max_new_tokens, eos_token_id, stopping_criteria, check_every)
+            finally:
+                st.c.sampling = None
         cur.wait_stream(self.stream)
         # the decode attention hands partials between workgroups inside a launch (arrival tickets): a ticket left non-zero means a
         # launch merged nothing and later steps used stale attention output -- fail loudly, never return such ids
@@ -466,16 +486,19 @@ class SrgptEngine:
             eos = [int(e) for e in eos_token_id] if isinstance(eos_token_id, (list, tuple, set)) else [int(eos_token_id)]
             eos = eos or None
         interactive = stopping_criteria is not None and len(stopping_criteria) > 0
-        chunk = 1 if interactive else (check_every if eos else max_new_tokens)
-        done_step = 1
         graph = st.ensure_graph() if self.use_graph and max_new_tokens > 1 else None
         B = st.batch
         finished = [False] * B
-        n_keep = max_new_tokens
 
-        def scan(lo, hi):
-            """host-side EOS / stopping-criteria scan of steps [lo, hi); returns stop step or None."""
-            ids = st.out_ids[:, :hi].to("cpu")
+        def launch(n):
+            if graph is not None:
+                L.check(lib.srgpt_graph_launch(graph, n, stream))
+            else:
+                for _ in range(n):
+                    L.check(lib.srgpt_llm_decode_step(C.byref(self.w.llm), C.byref(st.c), stream))
+
+        def judge(ids, lo, hi):
+            """host-side EOS / stopping-criteria scan of steps [lo, hi) of `ids` (CPU int64 [B, >= hi]); -> stop step or None."""
             for s_ in range(lo, hi):
                 for b in range(B):
                     if eos and not finished[b] and int(ids[b, s_]) in eos:
@@ -491,17 +514,60 @@ class SrgptEngine:
                             return s_ + 1
             return None
 
-        stop = scan(0, 1) if (eos or interactive) else None
+        if interactive:
+            return self._decode_loop_run_ahead(st, max_new_tokens, launch, judge), eos
+
+        chunk = check_every if eos else max_new_tokens
+        done_step = 1
+        n_keep = max_new_tokens
+        stop = judge(st.out_ids[:, :1].to("cpu"), 0, 1) if eos else None
         while stop is None and done_step < max_new_tokens:
             n = min(chunk, max_new_tokens - done_step)
-            if graph is not None:
-                L.check(lib.srgpt_graph_launch(graph, n, stream))
-            else:
-                for _ in range(n):
-                    L.check(lib.srgpt_llm_decode_step(C.byref(self.w.llm), C.byref(st.c), stream))
-            if eos or interactive:
-                stop = scan(done_step, done_step + n)
+            launch(n)
+            if eos:
+                stop = judge(st.out_ids[:, :done_step + n].to("cpu"), done_step, done_step + n)
             done_step += n
         if stop is not None:
             n_keep = stop
         return n_keep, eos
+
+    def _decode_loop_run_ahead(self, st: DecodeState, max_new_tokens: int, launch, judge) -> int:
+        """A stopping criterion (the demo's KeywordsStoppingCriteria, gradio_web_server_multi.py:195-197; model_vqa.py's conv stop
+        strings) is host Python over the ids so far: HF evaluates it after every token.  Round 3 did launch -> D2H -> Python ->
+        launch, serialising the device behind the host every token.  Here step t + 1 is launched BEFORE step t is judged: the
+        ids of step t travel on a side stream behind an event recorded after step t (so the copy does not wait for step t + 1),
+        the criteria run while step t + 1 computes, and a stop discards the one step that ran ahead (it only wrote cache rows
+        and ids beyond the kept prefix).  Same ids, same stop step as the serial loop."""
+        B = st.batch
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        host = torch.empty((B, max_new_tokens), dtype=torch.int64).pin_memory()
+        dec = torch.cuda.current_stream(self.device)
+
+        def mark():
+            ev = torch.cuda.Event()
+            ev.record(dec)
+            return ev
+
+        def fetch(col, ev):
+            with torch.cuda.stream(self._copy_stream):
+                self._copy_stream.wait_event(ev)
+                host[:, col:col + 1].copy_(st.out_ids[:, col:col + 1], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self._copy_stream)
+            return done
+
+        ev = mark()            # step 0 (srgpt_llm_sample_first) is on the stream
+        produced = 1
+        for t in range(max_new_tokens):
+            ready = fetch(t, ev)
+            if produced < max_new_tokens:  # run ahead: step t + 1 goes out before step t is judged
+                launch(1)
+                produced += 1
+                ev = mark()
+            ready.synchronize()
+            if judge(host, t, t + 1) is not None:
+                dec.wait_stream(self._copy_stream)
+                return t + 1
+        dec.wait_stream(self._copy_stream)
+        return max_new_tokens

@@ -420,6 +420,17 @@ class LlavaLlamaModel:
                 lens = None
         st, _, _ = self.engine.prefill(inputs_embeds, max_new=max_new_tokens, lens=lens)
         if g.do_sample and g.temperature is not None and g.temperature > 0:
+            from . import ops
+
+            if ops.SamplingParams.supported(g.temperature, g.top_k, g.top_p, self.engine.w.vocab):
+                # the draw runs INSIDE the captured decode step (csrc/sample.hip): temperature -> top-k -> top-p -> categorical on a
+                # Philox stream seeded from torch's default CPU generator -- torch.manual_seed / transformers.set_seed make a
+                # request reproducible, as with HF's torch.multinomial (whose stream itself cannot be matched)
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                return self.engine.greedy_decode(st, max_new_tokens, eos_token_id=eos_ids, pad_token_id=g.pad_token_id,
+                                                 stopping_criteria=stopping_criteria,
+                                                 sampling=dict(temperature=g.temperature, top_k=g.top_k, top_p=g.top_p, seed=seed))
+            # settings the device sampler does not serve (top_k > 64; top-p without top-k): warpers + draw as torch ops per token
             return self._sample_loop(st, max_new_tokens, g.temperature, g.top_p, g.top_k, eos_ids, g.pad_token_id,
                                      stopping_criteria)
         return self.engine.greedy_decode(st, max_new_tokens, eos_token_id=eos_ids, pad_token_id=g.pad_token_id,
@@ -427,9 +438,10 @@ class LlavaLlamaModel:
 
     def _sample_loop(self, st, max_new_tokens, temperature, top_p, top_k, eos_token_id, pad_token_id, stopping_criteria,
                      check_every: int = 8):
-        """temperature / top-k / top-p sampling (demo path, gradio_web_server_multi.py:202-213).  Outside the timed greedy
-        path: the transformer steps are the HIP decode step; the warpers (generation.warp_logits, pinned to HF's) and the
-        categorical draw over the final logits use torch.  Host round trips: none per step unless a stopping criterion is given
+        """temperature / top-k / top-p sampling for the settings the device sampler (csrc/sample.hip) does not serve -- top_k > 64, or
+        a top-p filter without top-k; every setting of the reference's callers (demo: temperature 0.2, top_k 50; model_vqa.py) runs on
+        the device instead.  The transformer steps are the HIP decode step; the warpers (generation.warp_logits, pinned to HF's) and
+        the categorical draw over the final logits use torch.  Host round trips: none per step unless a stopping criterion is given
         (HF semantics need the ids on the host then); the all-rows-finished test is read back every `check_every` steps."""
         import ctypes as C
 

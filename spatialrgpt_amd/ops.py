@@ -3,6 +3,7 @@ streams: every arithmetic op below is a HIP kernel from libsrgpt_hip.so, launche
 current torch stream.  Inputs must be CUDA(HIP) tensors; there is no CPU path."""
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import Optional
 
@@ -392,3 +393,56 @@ def cross_entropy(shift_logits: torch.Tensor, shift_labels: torch.Tensor, ignore
     L.check(L.load().srgpt_cross_entropy(_p(_c(shift_logits)), _p(_c(shift_labels)), _p(row_loss), _p(out), rows, V,
                                          int(ignore_index), _stream()))
     return out[0], out[1]
+
+
+class SamplingParams:
+    """The device-resident parameter block of the device-side draw (srgpt_sampling, include/srgpt.h): temperature -> top-k ->
+    top-p -> categorical, HF GenerationMixin.sample's warper chain.  `supported()` says whether a setting is served on the device
+    (top_k 1..64 with any top_p; or no top-k and no top-p: pure temperature sampling by Gumbel-max)."""
+
+    def __init__(self, device, batch: int, keep_kept_sets: bool = False):
+        self.device = torch.device(device)
+        self.buf = torch.zeros((C.sizeof(L.Sampling),), dtype=torch.uint8, device=self.device)
+        self.kept = torch.zeros((batch, L.SAMPLING_KEPT_MAX + 1), dtype=torch.int32, device=self.device) if keep_kept_sets else None
+        self.host = L.Sampling()
+
+    @staticmethod
+    def supported(temperature, top_k, top_p, vocab: int) -> bool:
+        if temperature is None or not temperature > 0 or vocab > L.SAMPLING_VOCAB_MAX:
+            return False
+        k = 0 if top_k is None else int(top_k)
+        p_on = top_p is not None and top_p < 1.0
+        if k == 0:
+            return not p_on
+        return 1 <= k <= L.SAMPLING_TOP_K_MAX
+
+    def set(self, temperature: float, top_k, top_p, seed: int, counter: int = 0):
+        """one small H2D copy on the current stream"""
+        h = self.host
+        h.temperature = float(temperature)
+        h.top_k = 0 if top_k is None else int(top_k)
+        tp = 1.0 if top_p is None else float(top_p)
+        h.top_p = tp
+        h.top_p_rm = float(torch.tensor(1.0 - tp, dtype=torch.float64).to(torch.float32))  # HF compares against (1 - top_p) in fp32
+        h.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        h.counter = int(counter)
+        h.kept_out = None if self.kept is None else self.kept.data_ptr()
+        src = torch.frombuffer(bytearray(bytes(h)), dtype=torch.uint8)
+        self.buf.copy_(src, non_blocking=False)
+        return self
+
+    def ptr(self):
+        return self.buf.data_ptr()
+
+
+def sample(logits: torch.Tensor, params: SamplingParams) -> torch.Tensor:
+    """one draw per row of fp32 logits [B, V] with the device-side sampler; advances params' counter.  -> int64 [B]"""
+    _dev(logits)
+    if logits.dtype != torch.float32 or logits.ndim != 2:
+        raise ValueError("sample: logits must be fp32 [B, V]")
+    B, V = logits.shape
+    lib = L.load()
+    ws = torch.empty((lib.srgpt_sample_ws_bytes(B),), dtype=torch.uint8, device=logits.device)
+    out = torch.empty((B,), dtype=torch.int64, device=logits.device)
+    L.check(lib.srgpt_sample(_p(_c(logits)), params.ptr(), _p(out), _p(ws), B, V, _stream()))
+    return out

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/srgpt.h but not exported"
     assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.srgpt_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.srgpt_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_struct_layouts_match_header():
@@ -48,6 +48,8 @@ def test_struct_layouts_match_header():
     assert fields("srgpt_vit_weights") == [f[0] for f in _lib.VitWeights._fields_]
     assert fields("srgpt_llm_weights") == [f[0] for f in _lib.LlmWeights._fields_]
     assert fields("srgpt_llm_state") == [f[0] for f in _lib.LlmState._fields_]
+    assert fields("srgpt_sampling") == [f[0] for f in _lib.Sampling._fields_]
+    assert ctypes.sizeof(_lib.Sampling) == 40  # the device block the host copies as raw bytes
 
 
 def test_error_code_mapping():
@@ -82,3 +84,7 @@ def test_argument_validation_without_gpu():
     # v [M, L] + psum [M, ceil(L / 1024)] + partials [ceil(L / 300) row slabs, M, C] + one ticket per channel slab (fp32 worst case)
     assert lib.srgpt_region_pool_ws_floats(8, 108, 1152) == 8 * 11664 + 8 * 12 + 39 * 8 * 1152 + 36
     assert lib.srgpt_gemm_ws_bytes(259, 4096) == 8 * 259 * 4096 * 4
+    # sampling: 128 slices x 64 candidates x (key + index) per sequence, the Gumbel-mode slice maxima, one error word
+    assert lib.srgpt_sample_ws_bytes(2) == 2 * 128 * 64 * 8 + 2 * 128 * 8 + 256
+    rc = lib.srgpt_sample(16, 16, 16, 16, 1, 128 * 2048 + 1, None)  # vocabulary beyond 128 slices x 2048 entries
+    assert rc == _lib.ERR_UNSUPPORTED and b"vocabulary" in lib.srgpt_last_error()

@@ -140,7 +140,7 @@ def _teacher_forced_case(tag, T_target, rope_factor, mpe, G=64):
     t0 = time.perf_counter()
     w32 = {k: v.float() for k, v in w_cpu.items()}
     del w_cpu
-    _, _, steps32, _ = oracle_pass(w32, torch.float32, teacher=ref_ids, steps=FLOOR_STEPS)
+    _, hid32, steps32, _ = oracle_pass(w32, torch.float32, teacher=ref_ids, steps=FLOOR_STEPS)
     del w32
     t_oracle32 = time.perf_counter() - t0
 
@@ -160,9 +160,20 @@ def _teacher_forced_case(tag, T_target, rope_factor, mpe, G=64):
     chk(emb, emb_ref, "inputs_embeds")
     st, _, hs = eng.prefill(emb, max_new=G + 1, hidden_states=True)
     assert st.max_pos >= T + G
+    # hidden states, all T positions x 4096 channels (8 - 16 M elements per layer): a fixed max-abs bound over that many bf16
+    # values sits on the tail of the rounding noise (the first GPU run: 3 of 8.4 M elements of layer 3 at 2.8e-2 of the max), so
+    # the bound is calibrated like the logits -- floor = oracle_bf16 - oracle_fp32 of the same layer: max <= 2 x floor max (never
+    # tighter than 2.5e-2 of the tensor's max), rms <= 2 x floor rms
     for i in range(cfg.layers + 1):
-        chk(hs[i], hid_ref[i], f"hidden state after layer {i} (all {T} positions)")
-    del hs
+        ref16, ref32, gotl = hid_ref[i].float(), hid32[i].float(), hs[i].float().cpu()
+        scale = float(ref16.abs().max()) + 1e-6
+        fl_max, fl_rms = float((ref16 - ref32).abs().max()), float((ref16 - ref32).pow(2).mean().sqrt())
+        e_max, e_rms = float((gotl - ref16).abs().max()), float((gotl - ref16).pow(2).mean().sqrt())
+        rep["stages"][f"hidden state after layer {i}"] = {"max_abs_over_max": e_max / scale, "rms_over_max": e_rms / scale,
+                                                          "floor_max_over_max": fl_max / scale, "floor_rms_over_max": fl_rms / scale}
+        assert e_max <= max(2.5e-2 * scale, 2 * fl_max), (i, rep["stages"])
+        assert e_rms <= 2 * fl_rms + 1e-6 * scale, (i, rep["stages"])
+    del hs, hid32
     dec = teacher_forced_decode_logits(eng, st, ref_ids)
     floor = logit_parity_report(steps_ref[:, :FLOOR_STEPS], steps32, 1.0, "NOISE FLOOR oracle_bf16 vs oracle_fp32")
     tol_max = min(LOGIT_MAX_CAP, 2 * floor["max_abs_over_range"])

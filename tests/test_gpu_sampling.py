@@ -1,0 +1,203 @@
+"""GPU: the device-side sampler (csrc/sample.hip) -- the demo's decoding mode (demo/gradio_web_server_multi.py:202-213: do_sample,
+temperature 0.2, top_k = the transformers==4.37.2 default 50, a KeywordsStoppingCriteria) inside the captured decode step.
+
+torch's random stream cannot be matched (HF's own draws differ between CPU and GPU), so parity is stated as
+  * the KEPT SET of every row == the set HF's warper chain keeps on the same logits (`generation.warp_logits`, which
+    tests/test_host_generation.py pins bit-for-bit to TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper), including
+    planted ties at the top-k threshold and top-p cuts;
+  * the DRAWN DISTRIBUTION == softmax of the kept scores: chi-square tests at the 0.1 % level over tens of thousands of draws, for the
+    top-k path (inverse CDF) and for the top_k = 0 path (Gumbel-max over the whole vocabulary);
+  * determinism: the same (seed, counter) draws the same ids, every step advances the counter;
+and end to end through `model.generate`: at temperature 0.2 on peaked-margin weights the draws equal the greedy ids (the margin
+makes any other token's probability ~e^-40), the stopping-criteria loop (one step run ahead of the host check) returns exactly the
+serial loop's prefix, and `torch.manual_seed` makes a request reproducible."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from spatialrgpt_amd import ops
+
+    return ops
+
+
+def _logits(B, V, seed, scale=3.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn((B, V), generator=g) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("temperature,top_k,top_p", [(0.2, 50, None), (0.7, 50, 0.9), (1.0, 5, 0.5), (0.2, 1, None), (1.3, 64, 0.95),
+                                                     (1.0, 50, 0.05), (0.5, 17, 1.0)])
+@pytest.mark.parametrize("V", [128258, 32002, 1000, 70])
+def test_kept_set_equals_hf_warpers(temperature, top_k, top_p, V):
+    from spatialrgpt_amd.generation import warp_logits
+    ops = _ops()
+    B = 3
+    lg = _logits(B, V, seed=V + top_k)
+    # planted ties: the value at the top-k boundary is copied onto two other entries of row 1 (TopKLogitsWarper keeps every entry
+    # >= the k-th largest score), and a run of equal maxima in row 2
+    kth = lg[1].topk(min(top_k, V)).values[-1]
+    lg[1, 7] = kth
+    lg[1, V - 3] = kth
+    lg[2, 11] = lg[2, 13] = lg[2].max()
+    sp = ops.SamplingParams(DEV, B, keep_kept_sets=True).set(temperature, top_k, top_p, seed=1)
+    tok = ops.sample(lg, sp)
+    kept = sp.kept.cpu()
+    ref = warp_logits(lg.cpu(), temperature, top_k, top_p)
+    for b in range(B):
+        want = set(torch.nonzero(ref[b] > float("-inf")).flatten().tolist())
+        n = int(kept[b, 0])
+        got = kept[b, 1:1 + n].tolist()
+        assert len(set(got)) == n and set(got) == want, (b, n, len(want), sorted(set(got) ^ want)[:10])
+        # best first: scores non-increasing, ties by index
+        sc = (lg[b].cpu() / temperature)[got]
+        assert bool((sc[:-1] >= sc[1:]).all())
+        assert int(tok[b]) in want
+
+
+def _chi2_crit(df):
+    """0.1 % upper quantile of chi-square(df), Wilson-Hilferty"""
+    z = 3.0902
+    return df * (1 - 2 / (9 * df) + z * math.sqrt(2 / (9 * df))) ** 3
+
+
+@pytest.mark.parametrize("temperature,top_k,top_p", [(1.0, 8, None), (0.6, 20, 0.8), (2.0, 64, None)])
+def test_top_k_draws_follow_the_kept_softmax(temperature, top_k, top_p):
+    from spatialrgpt_amd.generation import warp_logits
+    ops = _ops()
+    V, B, CALLS = 5000, 512, 64
+    row = _logits(1, V, seed=3, scale=1.5)
+    lg = row.expand(B, V).contiguous()
+    sp = ops.SamplingParams(DEV, B).set(temperature, top_k, top_p, seed=1234)
+    draws = torch.stack([ops.sample(lg, sp) for _ in range(CALLS)]).flatten().cpu()
+    probs = warp_logits(row.cpu(), temperature, top_k, top_p).softmax(-1)[0]
+    keep = torch.nonzero(probs > 0).flatten()
+    N = draws.numel()
+    counts = torch.bincount(draws, minlength=V).double()
+    assert float(counts[probs == 0].sum()) == 0, "a filtered token was drawn"
+    exp = probs[keep].double() * N
+    big = exp >= 5  # pool the tail cells
+    obs = torch.cat([counts[keep][big], counts[keep][~big].sum()[None]])
+    ex = torch.cat([exp[big], exp[~big].sum()[None]])
+    if float(ex[-1]) == 0:
+        obs, ex = obs[:-1], ex[:-1]
+    chi2 = float(((obs - ex) ** 2 / ex).sum())
+    assert chi2 < _chi2_crit(len(ex) - 1), (chi2, len(ex) - 1, _chi2_crit(len(ex) - 1))
+
+
+def test_gumbel_max_draws_follow_the_full_softmax():
+    ops = _ops()
+    V, B, CALLS, T = 3000, 512, 96, 0.8
+    row = _logits(1, V, seed=5, scale=1.2)
+    lg = row.expand(B, V).contiguous()
+    sp = ops.SamplingParams(DEV, B).set(T, 0, None, seed=99)
+    draws = torch.stack([ops.sample(lg, sp) for _ in range(CALLS)]).flatten().cpu()
+    probs = (row.cpu()[0] / T).softmax(-1).double()
+    N = draws.numel()
+    counts = torch.bincount(draws, minlength=V).double()
+    order = probs.argsort(descending=True)
+    head = order[:40]
+    obs = torch.cat([counts[head], (N - counts[head].sum())[None]])
+    ex = torch.cat([probs[head] * N, (N - (probs[head] * N).sum())[None]])
+    chi2 = float(((obs - ex) ** 2 / ex).sum())
+    assert chi2 < _chi2_crit(len(ex) - 1), (chi2, _chi2_crit(len(ex) - 1))
+
+
+def test_draws_are_a_function_of_seed_and_counter():
+    ops = _ops()
+    lg = _logits(4, 128258, seed=8, scale=1.0)
+    for k in (50, 0):
+        a = ops.SamplingParams(DEV, 4).set(1.0, k, None, seed=7)
+        b = ops.SamplingParams(DEV, 4).set(1.0, k, None, seed=7)
+        c = ops.SamplingParams(DEV, 4).set(1.0, k, None, seed=8)
+        s1 = [ops.sample(lg, a) for _ in range(6)]
+        s2 = [ops.sample(lg, b) for _ in range(6)]
+        s3 = [ops.sample(lg, c) for _ in range(6)]
+        assert all(torch.equal(x, y) for x, y in zip(s1, s2))          # same seed, same counters
+        assert not all(torch.equal(x, y) for x, y in zip(s1, s3))      # another seed
+        assert not all(torch.equal(s1[0], x) for x in s1[1:])          # the counter advances
+        b.set(1.0, k, None, seed=7, counter=3)
+        assert torch.equal(ops.sample(lg, b), s1[3])                   # a draw is addressed by (seed, counter)
+
+
+# ------------------------------------------------------------------------------------------------ through model.generate
+def _peaked_model(layers=2):
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.model import LlavaLlamaModel
+    from spatialrgpt_amd.weights import synth_state_dict
+    from tests.util import make_peaked
+
+    cfg = SrgptConfig(vit_hidden=64, vit_inter=176, vit_layers=3, vit_heads=4, image_size=378, patch_size=14, hidden=1024, inter=2816,
+                      layers=layers, heads=8, kv_heads=2, vocab=32002, mask_token_id=32000, depth_token_id=32001,
+                      max_position_embeddings=1024)
+    sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device=DEV)
+    make_peaked(sd, cfg)
+    return cfg, LlavaLlamaModel(cfg, sd, device=DEV, dtype=torch.bfloat16, consume_state_dict=True)
+
+
+def _request(cfg, batch=1):
+    from oracle import srgpt_oracle as so
+
+    ocfg = so.SrgptConfig(**{k: v for k, v in cfg.to_dict().items() if k in so.SrgptConfig.__dataclass_fields__})
+    ids, images, depths, masks = so.synth_inputs(ocfg, batch=batch, regions=4, prompt_len=40, seed=2, dtype=torch.bfloat16)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    return dict(input_ids=d(ids), images=d(images), depths=d(depths), masks=[d(m) for m in masks])
+
+
+def test_generate_with_the_demo_settings_runs_the_device_sampler_and_follows_the_margin():
+    cfg, model = _peaked_model()
+    req = _request(cfg, batch=2)
+    G = 48
+    greedy = model.generate(**req, do_sample=False, max_new_tokens=G, eos_token_id=None)
+    torch.manual_seed(0)
+    drawn = model.generate(**req, do_sample=True, temperature=0.2, max_new_tokens=G, eos_token_id=None)  # top_k = 50 (4.37.2 default)
+    assert torch.equal(drawn, greedy)  # margin ~10 at T = 0.2: every other token has probability ~e^-50
+    st = model.engine._state
+    assert "sample" in st.graphs and "greedy" in st.graphs and st.c.sampling is None
+    # a hot temperature does leave the greedy path, reproducibly for a seed
+    torch.manual_seed(1)
+    hot1 = model.generate(**req, do_sample=True, temperature=30.0, top_k=64, max_new_tokens=G, eos_token_id=None)
+    torch.manual_seed(1)
+    hot2 = model.generate(**req, do_sample=True, temperature=30.0, top_k=64, max_new_tokens=G, eos_token_id=None)
+    torch.manual_seed(2)
+    hot3 = model.generate(**req, do_sample=True, temperature=30.0, top_k=64, max_new_tokens=G, eos_token_id=None)
+    assert torch.equal(hot1, hot2) and not torch.equal(hot1, greedy) and not torch.equal(hot1, hot3)
+    # settings outside the device sampler still work (torch path): top-p without top-k
+    torch.manual_seed(3)
+    alt = model.generate(**req, do_sample=True, temperature=0.2, top_k=0, top_p=0.9, max_new_tokens=8, eos_token_id=None)
+    assert torch.equal(alt, greedy[:, :8])
+
+
+@pytest.mark.parametrize("do_sample", [False, True])
+def test_stopping_criteria_run_ahead_returns_the_serial_loops_prefix(do_sample):
+    """a criterion that fires when a given id shows up: the loop must stop exactly there (HF evaluates the criteria after every
+    token), although step t + 1 is already in flight when step t is judged"""
+    cfg, model = _peaked_model()
+    req = _request(cfg)
+    G = 40
+    kw = dict(do_sample=True, temperature=0.2) if do_sample else dict(do_sample=False)
+    torch.manual_seed(0)
+    full = model.generate(**req, **kw, max_new_tokens=G, eos_token_id=None)
+    calls = []
+    for stop_at in (0, 1, 7, G - 1):
+        target = int(full[0, stop_at])
+
+        def crit(ids, scores, target=target):
+            calls.append(ids.shape[1])
+            return bool((ids[0] == target).any())
+
+        torch.manual_seed(0)
+        out = model.generate(**req, **kw, max_new_tokens=G, eos_token_id=None, stopping_criteria=[crit])
+        assert torch.equal(out, full[:, :stop_at + 1]), (stop_at, out.shape)
+    # never firing: the whole budget, and the criteria saw every prefix length once per request
+    calls.clear()
+    out = model.generate(**req, **kw, max_new_tokens=G, eos_token_id=None, stopping_criteria=[lambda ids, s: (calls.append(ids.shape[1]), False)[1]])
+    assert torch.equal(out, full) and calls == list(range(1, G + 1))
+    # the next request on the pooled state is unaffected by the step that ran ahead
+    again = model.generate(**req, do_sample=False, max_new_tokens=G, eos_token_id=None)
+    assert torch.equal(again, model.generate(**req, do_sample=False, max_new_tokens=G, eos_token_id=None))
