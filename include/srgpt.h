@@ -297,7 +297,8 @@ int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images, void* out,
  *   *coef [out][k]) -> value * rescale -> (v - mean[c]) / std[c] if do_normalize -> out [C, Hout, Wout] in dtype.
  *   tmp_u8 = H * Wout * C bytes of scratch.  A dimension that is not resized gets the identity table (1 tap, 1<<22).
  * srgpt_mask_resize_nearest: uint8 masks [K, H, W] -> out [K, Hout, Wout] in dtype, out[m,y,x] = src[m, ys[y], xs[x]]
- *   (cv2.INTER_NEAREST index tables from the host).
+ *   (cv2.INTER_NEAREST index tables from the host: OpenCV resizeNN's published arithmetic, min(floor(dst * (1 / (out / in))), in - 1)
+ *   in double -- pinned by tests/golden/cv2_nearest_kat.json; cv2 itself is not installed in the build image).
  * --------------------------------------------------------------------------------------------- */
 int srgpt_image_resize_normalize(const void* src_u8, int H, int W, int C, const int* hbounds, const int* hcoef, int hk,
                                  const int* vbounds, const int* vcoef, int vk, int Hout, int Wout, void* tmp_u8,
@@ -305,6 +306,14 @@ int srgpt_image_resize_normalize(const void* src_u8, int H, int W, int C, const 
                                  int dtype, srgpt_stream_t stream);
 int srgpt_mask_resize_nearest(const void* src_u8, int K, int H, int W, const int* ys, const int* xs, int Hout, int Wout,
                               void* out, int dtype, srgpt_stream_t stream);
+/* ABI 6: process_regions with image_aspect_ratio == "pad" (mm_utils.py:505-531): each uint8 mask [H, W] is centred on a zero square
+ * of side max(H, W) (pad_to_square: offsets (side - H) / 2, (side - W) / 2) and the HF processor resizes that one-channel square
+ * to Hout x Wout with Pillow's bicubic filter, rescale_factor 1.0, no normalisation.  masks [K, H, W] -> out [K, Hout, Wout] in
+ * dtype (values 0 .. 255 as the uint8 result holds them); *bounds / *coef are Pillow's tables for side -> Wout (h) and side -> Hout
+ * (v) as for srgpt_image_resize_normalize; tmp_u8 = K * side * Wout bytes.  The padded square is never materialised. */
+int srgpt_mask_pad_resize(const void* src_u8, int K, int H, int W, const int* hbounds, const int* hcoef, int hk,
+                          const int* vbounds, const int* vcoef, int vk, int Hout, int Wout, void* tmp_u8, void* out,
+                          int dtype, srgpt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Composite: Llama decoder (LlamaForCausalLM.forward, modeling_llama.py:972-1110 inference branch,

@@ -104,6 +104,7 @@ _SIGNATURES = {
     "srgpt_sample": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "srgpt_image_resize_normalize": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp]),
     "srgpt_mask_resize_nearest": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp]),
+    "srgpt_mask_pad_resize": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32, vp]),
     "srgpt_vit_assemble_cls": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "srgpt_vit_ws_bytes": (i64, [C.POINTER(VitWeights), i32]),
     "srgpt_vit_forward": (i32, [C.POINTER(VitWeights), vp, vp, vp, i32, vp]),

@@ -64,6 +64,51 @@ __global__ void nearest_u8_kernel(const unsigned char* __restrict__ src, T* __re
   }
 }
 
+// pad-mode masks (process_regions with image_aspect_ratio == "pad", mm_utils.py:505-531): the mask is centred on a zero square of
+// side max(H, W) and the HF processor then resizes that square with Pillow's bicubic filter (uint8, one channel).  The square is
+// never materialised: the horizontal pass reads through the padding offsets (outside the mask = 0).
+// src [K, H, W] -> tmp [K, side, Wout]
+__global__ void mask_pad_resize_h_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                         const int* __restrict__ bounds, const int* __restrict__ coef, int ksize, int K, int H, int W,
+                                         int side, int pad_top, int pad_left, int Wout) {
+  const int64_t total = (int64_t)K * side * Wout;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % Wout);
+    const int y = (int)((i / Wout) % side);
+    const int m = (int)(i / ((int64_t)Wout * side));
+    const int py = y - pad_top;
+    int ss = 1 << 21;
+    if (py >= 0 && py < H) {
+      const int x0 = bounds[2 * xx], n = bounds[2 * xx + 1];
+      const unsigned char* row = src + ((int64_t)m * H + py) * W;
+      const int* k = coef + (int64_t)xx * ksize;
+      for (int x = 0; x < n; ++x) {
+        const int px = x0 + x - pad_left;
+        if (px >= 0 && px < W) ss += (int)row[px] * k[x];
+      }
+    }
+    dst[i] = (unsigned char)clip8(ss >> 22);
+  }
+}
+
+// tmp [K, side, Wout] -> out [K, Hout, Wout] (dtype T): the vertical pass; rescale_factor 1.0, no normalisation (process_regions)
+template <typename T>
+__global__ void mask_resize_v_kernel(const unsigned char* __restrict__ src, T* __restrict__ out, const int* __restrict__ bounds,
+                                     const int* __restrict__ coef, int ksize, int K, int side, int Hout, int Wout) {
+  const int64_t total = (int64_t)K * Hout * Wout;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % Wout);
+    const int yy = (int)((i / Wout) % Hout);
+    const int m = (int)(i / ((int64_t)Wout * Hout));
+    const int y0 = bounds[2 * yy], n = bounds[2 * yy + 1];
+    const unsigned char* p = src + ((int64_t)m * side + y0) * Wout + xx;
+    const int* k = coef + (int64_t)yy * ksize;
+    int ss = 1 << 21;
+    for (int y = 0; y < n; ++y) ss += (int)p[(int64_t)y * Wout] * k[y];
+    out[i] = from_f<T>((float)clip8(ss >> 22));
+  }
+}
+
 inline int grid_for(int64_t total) {
   int64_t g = (total + 255) / 256;
   const int64_t cap = (int64_t)srgpt_device_cus() * 16;
@@ -110,6 +155,28 @@ extern "C" int srgpt_mask_resize_nearest(const void* src_u8, int K, int H, int W
   else
     hipLaunchKernelGGL(nearest_u8_kernel<float>, dim3(grid_for(t)), dim3(256), 0, s, (const unsigned char*)src_u8, (float*)out, ys, xs,
                        K, H, W, Hout, Wout);
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
+
+extern "C" int srgpt_mask_pad_resize(const void* src_u8, int K, int H, int W, const int* hbounds, const int* hcoef, int hk,
+                                     const int* vbounds, const int* vcoef, int vk, int Hout, int Wout, void* tmp_u8, void* out,
+                                     int dtype, srgpt_stream_t stream) {
+  SRGPT_CHECK(src_u8 && hbounds && hcoef && vbounds && vcoef && tmp_u8 && out, SRGPT_ERR_ARG, "srgpt_mask_pad_resize: null pointer");
+  SRGPT_CHECK(K > 0 && H > 0 && W > 0 && Hout > 0 && Wout > 0 && hk > 0 && vk > 0, SRGPT_ERR_ARG, "srgpt_mask_pad_resize: bad shape");
+  SRGPT_CHECK(dtype == SRGPT_F32 || dtype == SRGPT_BF16, SRGPT_ERR_ARG, "srgpt_mask_pad_resize: bad dtype %d", dtype);
+  hipStream_t s = as_stream(stream);
+  const int side = H > W ? H : W, pad_top = (side - H) / 2, pad_left = (side - W) / 2;  // pad_to_square, mm_utils.py:505-514
+  const int64_t t1 = (int64_t)K * side * Wout, t2 = (int64_t)K * Hout * Wout;
+  hipLaunchKernelGGL(mask_pad_resize_h_kernel, dim3(grid_for(t1)), dim3(256), 0, s, (const unsigned char*)src_u8, (unsigned char*)tmp_u8,
+                     hbounds, hcoef, hk, K, H, W, side, pad_top, pad_left, Wout);
+  SRGPT_LAUNCH_CHECK();
+  if (dtype == SRGPT_BF16)
+    hipLaunchKernelGGL(mask_resize_v_kernel<bf16_t>, dim3(grid_for(t2)), dim3(256), 0, s, (const unsigned char*)tmp_u8, (bf16_t*)out,
+                       vbounds, vcoef, vk, K, side, Hout, Wout);
+  else
+    hipLaunchKernelGGL(mask_resize_v_kernel<float>, dim3(grid_for(t2)), dim3(256), 0, s, (const unsigned char*)tmp_u8, (float*)out,
+                       vbounds, vcoef, vk, K, side, Hout, Wout);
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }

@@ -10,7 +10,8 @@
 //             score + Gumbel noise IS a draw from softmax(score) -- as per-slice maxima for the greedy merge kernel.
 //   launch 2  sample_select_kernel    one block per sequence: the 128 x 64 candidates in LDS, the global k-th largest score by the
 //             same radix select, kept = every candidate >= it (ties kept, like TopKLogitsWarper's `scores < kth` mask), rank-sorted
-//             by (score desc, index asc) -- deterministic whatever order the LDS atomics appended them in; then, on one thread over
+//             by (score desc, index desc: torch.sort's order among ties, reversed) -- deterministic whatever order the LDS atomics
+//             appended them in; then, on one thread over
 //             <= 256 entries: top-p exactly as TopPLogitsWarper (ascending cumulative softmax, remove <= 1 - top_p, never the
 //             largest), and the draw by inverse CDF on one Philox4x32-10 uniform.
 //   launch 3  advance_kernel (model.hip) books the token like the greedy path and advances the Philox counter.
@@ -239,11 +240,14 @@ __global__ __launch_bounds__(1024) void sample_select_kernel(const srgpt_samplin
   __syncthreads();
   if (n_list > (unsigned)SMP_LIST && tid == 0) atomicOr(err, 2);  // > 256 - k entries tie at the k-th score: reported, not silent
   const int nk = min((int)n_list, SMP_LIST);
-  for (int e = tid; e < nk; e += nt) {  // rank by (score desc, index asc)
+  // rank by (score desc, index DESC): TopPLogitsWarper sorts ascending -- torch.sort leaves equal scores in index order -- and
+  // cuts from the small end, never the last entry: among equal scores the HIGHEST index survives longest (three equal maxima
+  // under a tight top-p keep the one with the largest id).  A total order: the list does not depend on the append order above.
+  for (int e = tid; e < nk; e += nt) {
     const unsigned ke = lkey[e];
     const int ie = lidx[e];
     int r = 0;
-    for (int j = 0; j < nk; ++j) r += (lkey[j] > ke) || (lkey[j] == ke && lidx[j] < ie);
+    for (int j = 0; j < nk; ++j) r += (lkey[j] > ke) || (lkey[j] == ke && lidx[j] > ie);
     ss[r] = score_of(ke);
     sidx[r] = ie;
   }

@@ -154,9 +154,19 @@ class SrgptEngine:
             if m is None:
                 out.append(None)
             elif m.dtype == torch.uint8:
-                # raw uint8 masks [K, H, W]: nearest resize to the processor size + float + resample in the kernel
+                # raw uint8 masks [K, H, W]
+                if self.cfg.image_aspect_ratio == "pad":
+                    # process_regions' pad mode (mm_utils.py:505-531): zero square + the processor's bicubic resize on the device,
+                    # then the pooling of float masks (soft edges: the nearest-tap fusion below does not apply)
+                    from .mm_utils import masks_pad_resize_device
+
+                    S = self.cfg.image_size
+                    out.append(ops.region_pool(feats[i].to(self.dtype), masks_pad_resize_device(m.to(self.device), S, S, self.dtype)))
+                    continue
                 if self.cfg.image_aspect_ratio != "resize":
-                    raise NotImplementedError("raw uint8 masks need image_aspect_ratio == 'resize' (process_regions otherwise)")
+                    raise NotImplementedError(f"raw uint8 masks: image_aspect_ratio {self.cfg.image_aspect_ratio!r} "
+                                              "(process_regions handles 'resize' and 'pad')")
+                # "resize": nearest resize to the processor size + float + resample fused into the pooling kernel
                 out.append(ops.region_pool_u8(feats[i].to(self.dtype), m.to(self.device), self.cfg.image_size))
             else:
                 out.append(ops.region_pool(feats[i].to(self.dtype), m.to(self.device)))

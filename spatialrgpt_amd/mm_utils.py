@@ -109,13 +109,18 @@ class SrgptImageProcessor:
         from PIL import Image
 
         if isinstance(image, np.ndarray):
-            arr = image.astype(np.float32)
-            if arr.ndim == 2:
-                arr = arr[None]
-            (rh, rw), crop = self._target(arr.shape[-2], arr.shape[-1])
-            if arr.shape[-2:] != (rh, rw):
-                chans = [np.asarray(Image.fromarray(c, mode="F").resize((rw, rh), self.resample)) for c in arr]
-                arr = np.stack(chans, 0)
+            src = image[None] if image.ndim == 2 else image
+            (rh, rw), crop = self._target(src.shape[-2], src.shape[-1])
+            if src.shape[-2:] != (rh, rw):
+                if src.dtype == np.uint8:
+                    # HF converts a uint8 array to a PIL image and resizes THERE: 8 bits per channel, rounded and clipped after
+                    # each pass (process_regions' pad mode feeds [1, side, side] uint8 masks, mm_utils.py:505-531) -- pinned to
+                    # transformers' own SiglipImageProcessor by tests/test_host_logic.py
+                    chans = [np.asarray(Image.fromarray(np.ascontiguousarray(c), mode="L").resize((rw, rh), self.resample)) for c in src]
+                else:
+                    chans = [np.asarray(Image.fromarray(c.astype(np.float32), mode="F").resize((rw, rh), self.resample)) for c in src]
+                src = np.stack(chans, 0)
+            arr = src.astype(np.float32)
         else:
             if self.do_convert_rgb:
                 image = image.convert("RGB")
@@ -173,11 +178,11 @@ def process_images(images, image_processor, model_cfg):
 
 
 def _nearest_resize(m: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
-    """cv2.resize(..., interpolation=cv2.INTER_NEAREST): src = min(floor(dst * in/out), in - 1)."""
+    """cv2.resize(m, (out_w, out_h), interpolation=cv2.INTER_NEAREST) (mm_utils.py:520): OpenCV's resizeNN gathers
+    src[min(floor(dst * (1 / (out / in))), in - 1)] -- the RECIPROCAL of the rounded scale, not in / out: the two differ at exact
+    multiples for many sizes (72 -> 224, 76 -> 336, ...; tests/golden/cv2_nearest_kat.json).  Same tables as the device path."""
     h, w = m.shape
-    ys = np.minimum((np.arange(out_h) * (h / out_h)).astype(np.int64), h - 1)
-    xs = np.minimum((np.arange(out_w) * (w / out_w)).astype(np.int64), w - 1)
-    return m[ys][:, xs]
+    return m[cv2_nearest_index(h, out_h)][:, cv2_nearest_index(w, out_w)]
 
 
 def process_regions(masks: Sequence[np.ndarray], image_processor, data_args):
@@ -307,21 +312,49 @@ def process_images_device(images, image_processor, model_cfg, device="cuda", dty
 
 
 def process_regions_device(masks: Sequence[np.ndarray], image_processor, data_args, device="cuda", dtype=torch.bfloat16):
-    """Device counterpart of process_regions (mm_utils.py:477-532) for image_aspect_ratio == "resize" (the SpatialRGPT
-    configuration): uint8 [H, W] masks -> [M, S, S] on the GPU in `dtype` (values are the mask's own 0/1 or 0/255)."""
+    """Device counterpart of process_regions (mm_utils.py:477-532): uint8 [H, W] masks -> [M, S, S] on the GPU in `dtype`,
+    bit-identical to the host path followed by `.to(dtype)`.
+      image_aspect_ratio == "resize" (the SpatialRGPT configuration): cv2.INTER_NEAREST gather to the processor size (values are
+        the mask's own 0/1 or 0/255);
+      image_aspect_ratio == "pad": pad_to_square (zeros, centred) + the processor's Pillow-bicubic resize of the one-channel
+        square, fused (the square is never materialised)."""
     from . import _lib as L, ops
 
-    if getattr(data_args, "image_aspect_ratio", None) != "resize":
-        raise NotImplementedError("process_regions_device handles image_aspect_ratio == 'resize'; use process_regions otherwise")
+    mode = getattr(data_args, "image_aspect_ratio", None)
+    if mode not in ("resize", "pad"):
+        raise NotImplementedError(f"process_regions_device: image_aspect_ratio {mode!r} (the reference handles 'resize' and 'pad')")
     cs = _crop_size(data_args.image_processor if hasattr(data_args, "image_processor") else image_processor)
     S_h, S_w = cs["height"], cs["width"]
     ms = [np.asarray(m) for m in masks]
     if not ms or any(m.ndim != 2 or m.dtype != np.uint8 or m.shape != ms[0].shape for m in ms):
         raise ValueError("process_regions_device: expected equally sized uint8 [H, W] masks")
-    H, W = ms[0].shape
     src = torch.from_numpy(np.ascontiguousarray(np.stack(ms, 0))).to(device)
-    ys, xs = _dev_tables((cv2_nearest_index(H, S_h), cv2_nearest_index(W, S_w)), device)
-    out = torch.empty((len(ms), S_h, S_w), dtype=dtype, device=device)
-    L.check(L.load().srgpt_mask_resize_nearest(src.data_ptr(), len(ms), H, W, ys.data_ptr(), xs.data_ptr(), S_h, S_w, out.data_ptr(),
+    return (masks_pad_resize_device if mode == "pad" else masks_nearest_device)(src, S_h, S_w, dtype)
+
+
+def masks_nearest_device(src: torch.Tensor, S_h: int, S_w: int, dtype) -> torch.Tensor:
+    """uint8 [K, H, W] on the GPU -> [K, S_h, S_w]: the cv2.INTER_NEAREST step of process_regions ("resize" mode)."""
+    from . import _lib as L, ops
+
+    K, H, W = src.shape
+    ys, xs = _dev_tables((cv2_nearest_index(H, S_h), cv2_nearest_index(W, S_w)), src.device)
+    out = torch.empty((K, S_h, S_w), dtype=dtype, device=src.device)
+    L.check(L.load().srgpt_mask_resize_nearest(src.data_ptr(), K, H, W, ys.data_ptr(), xs.data_ptr(), S_h, S_w, out.data_ptr(),
                                                ops.dt_code(out), ops._stream()))
+    return out
+
+
+def masks_pad_resize_device(src: torch.Tensor, S_h: int, S_w: int, dtype) -> torch.Tensor:
+    """uint8 [K, H, W] on the GPU -> [K, S_h, S_w]: pad_to_square + the processor's bicubic resize ("pad" mode, mm_utils.py:505-531)."""
+    from . import _lib as L, ops
+
+    K, H, W = src.shape
+    side = max(H, W)
+    hb, hc = _dev_tables(pil_bicubic_tables(side, S_w), src.device)
+    vb, vc = _dev_tables(pil_bicubic_tables(side, S_h), src.device)
+    tmp = torch.empty((K, side, S_w), dtype=torch.uint8, device=src.device)
+    out = torch.empty((K, S_h, S_w), dtype=dtype, device=src.device)
+    L.check(L.load().srgpt_mask_pad_resize(src.contiguous().data_ptr(), K, H, W, hb.data_ptr(), hc.data_ptr(), hc.shape[1], vb.data_ptr(),
+                                           vc.data_ptr(), vc.shape[1], S_h, S_w, tmp.data_ptr(), out.data_ptr(), ops.dt_code(out),
+                                           ops._stream()))
     return out

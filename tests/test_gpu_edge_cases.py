@@ -215,8 +215,25 @@ def test_device_preprocessing_equals_host_path():
     refm = process_regions(masks, proc, cfg)
     gotm = process_regions_device(masks, proc, cfg, device=DEV, dtype=torch.float32)
     assert gotm.shape == (5, 384, 384) and torch.equal(gotm.cpu(), refm)
+    # sizes at which floor(dst * in / out) and OpenCV's floor(dst * (1 / (out / in))) pick different source pixels
+    # (tests/golden/cv2_nearest_kat.json): host and device follow the published resizeNN arithmetic
+    for h, w in [(72, 76), (333, 500), (1080, 1920)]:
+        mk = [(rng.random((h, w)) > 0.5).astype(np.uint8) * 255 for _ in range(2)]
+        assert torch.equal(process_regions_device(mk, proc, cfg, device=DEV, dtype=torch.float32).cpu(), process_regions(mk, proc, cfg))
+    # pad mode (mm_utils.py:505-531): zero square + the processor's bicubic resize of the one-channel square -- soft edges; the
+    # device path never materialises the square.  Landscape, portrait, square, 0/1 and 0/255 masks, fp32 and bf16.
+    cfgp = SimpleNamespace(image_aspect_ratio="pad", image_processor=proc)
+    for (h, w), hi in [((480, 640), 1), ((640, 480), 255), ((333, 500), 255), ((384, 384), 1), ((200, 731), 255), ((97, 97), 255)]:
+        mk = [(rng.random((h, w)) > 0.6).astype(np.uint8) * hi for _ in range(3)]
+        mk[1][h // 4:h // 2, w // 4:w // 2] = hi  # a solid box: interior stays `hi`, the rim goes soft
+        refp = process_regions(mk, proc, cfgp)
+        gotp = process_regions_device(mk, proc, cfgp, device=DEV, dtype=torch.float32)
+        assert gotp.shape == (3, 384, 384) and torch.equal(gotp.cpu(), refp), ((h, w), float((gotp.cpu() - refp).abs().max()))
+        assert torch.equal(process_regions_device(mk, proc, cfgp, device=DEV, dtype=torch.bfloat16).cpu(), refp.to(torch.bfloat16))
+        if hi == 255 and h != w:
+            assert 0 < float(((refp > 0) & (refp < 255)).float().mean()), "pad mode should produce soft (bicubic) mask edges"
     with pytest.raises(NotImplementedError):
-        process_regions_device(masks, proc, SimpleNamespace(image_aspect_ratio="pad", image_processor=proc), device=DEV)
+        process_regions_device(masks, proc, SimpleNamespace(image_aspect_ratio="crop", image_processor=proc), device=DEV)
 
 
 def test_raw_uint8_masks_go_straight_into_region_pooling():
@@ -254,3 +271,17 @@ def test_raw_uint8_masks_go_straight_into_region_pooling():
     b = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=[hostm.to(DEV)], do_sample=False,
                        max_new_tokens=5, eos_token_id=None)
     assert torch.equal(a, b)
+    # pad-mode models: raw uint8 masks take the fused pad + bicubic kernel, then the float-mask pooling == host process_regions(pad)
+    model.engine.cfg.image_aspect_ratio = "pad"
+    try:
+        hostp = process_regions(list(rawm), proc2, SimpleNamespace(image_aspect_ratio="pad", image_processor=proc2))
+        a = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=[torch.from_numpy(rawm).to(DEV)],
+                           do_sample=False, max_new_tokens=5, eos_token_id=None)
+        b = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=[hostp.to(DEV)], do_sample=False,
+                           max_new_tokens=5, eos_token_id=None)
+        assert torch.equal(a, b)
+        feat = torch.randn((108 * 108, 64), generator=g, device=DEV).to(model.engine.dtype)
+        mp = model.engine.mask_pooling(feat[None], [torch.from_numpy(rawm).to(DEV)])[0]
+        assert torch.equal(mp, ops.region_pool(feat, hostp.to(DEV)))
+    finally:
+        model.engine.cfg.image_aspect_ratio = "resize"

@@ -54,7 +54,7 @@ def test_kept_set_equals_hf_warpers(temperature, top_k, top_p, V):
         n = int(kept[b, 0])
         got = kept[b, 1:1 + n].tolist()
         assert len(set(got)) == n and set(got) == want, (b, n, len(want), sorted(set(got) ^ want)[:10])
-        # best first: scores non-increasing, ties by index
+        # best first: scores non-increasing
         sc = (lg[b].cpu() / temperature)[got]
         assert bool((sc[:-1] >= sc[1:]).all())
         assert int(tok[b]) in want

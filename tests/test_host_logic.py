@@ -268,3 +268,63 @@ def test_rope_tables_follow_the_vendored_linear_scaling_class_bit_for_bit():
     assert torch.equal(c32, torch.from_numpy(z["rope.cos_f32"])) and torch.equal(s32, torch.from_numpy(z["rope.sin_f32"]))
     c16, s16 = rope_tables(cfg, 64, torch.bfloat16, "cpu")
     assert torch.equal(c16.float(), torch.from_numpy(z["rope.cos_bf16"])) and torch.equal(s16.float(), torch.from_numpy(z["rope.sin_bf16"]))
+
+
+def test_cv2_nearest_tables_follow_opencv_resizenn():
+    """`cv2_nearest_index` (the tables of the device mask resize AND of the host process_regions) == OpenCV's published resizeNN
+    arithmetic, min(cvFloor(x * (1. / ((double)out / in))), in - 1), derived with exact rationals by oracle/make_cv2_nearest_kat.py
+    (cv2 is not installed here: stated in INTEGRATION.md).  6 of the 20 size pairs differ from floor(x * in / out) -- the formula
+    round 3 used on the host."""
+    from types import SimpleNamespace
+
+    from spatialrgpt_amd.mm_utils import SrgptImageProcessor, cv2_nearest_index, process_regions
+
+    kat = json.load(open(os.path.join(GOLD, "cv2_nearest_kat.json")))
+    differing = 0
+    for c in kat["cases"]:
+        idx = cv2_nearest_index(c["in"], c["out"])
+        assert idx.tolist() == c["index"], (c["in"], c["out"])
+        differing += bool(c["differs_from_floor_x_in_over_out_at"])
+    assert differing >= 5
+    # the host process_regions gathers through the same tables: a ramp mask reads back the KAT's indices
+    c = next(c for c in kat["cases"] if c["in"] == 72 and c["out"] == 224)
+    proc = SrgptImageProcessor(size=224)
+    ramp = np.tile(np.arange(72, dtype=np.uint8)[None, :], (72, 1))
+    out = process_regions([ramp, ramp.T.copy()], proc, SimpleNamespace(image_aspect_ratio="resize", image_processor=proc))
+    assert out.shape == (2, 224, 224)
+    assert out[0, 0].to(torch.int64).tolist() == c["index"] and out[1, :, 0].to(torch.int64).tolist() == c["index"]
+
+
+def test_pad_mode_masks_follow_pillow_and_the_hf_processor_bit_for_bit():
+    """process_regions with image_aspect_ratio == "pad" (mm_utils.py:505-531): pad_to_square, then the processor's resize of the
+    [1, side, side] uint8 array -- HF resizes it as an 8-bit PIL image (bicubic, rounded and clipped).  The host path == Pillow
+    == transformers' own SiglipImageProcessor on the same array (the device path is pinned to the host path by
+    tests/test_gpu_edge_cases.py)."""
+    import copy
+    from types import SimpleNamespace
+
+    from PIL import Image
+
+    from spatialrgpt_amd.mm_utils import SrgptImageProcessor, process_regions
+
+    rng = np.random.default_rng(0)
+    proc = SrgptImageProcessor(size=384)
+    for (h, w), hi in [((333, 500), 255), ((640, 480), 1), ((97, 97), 255)]:
+        m = (rng.random((h, w)) > 0.6).astype(np.uint8) * hi
+        out = process_regions([m], proc, SimpleNamespace(image_aspect_ratio="pad", image_processor=proc))
+        side = max(h, w)
+        p = np.zeros((side, side), np.uint8)
+        p[(side - h) // 2:(side - h) // 2 + h, (side - w) // 2:(side - w) // 2 + w] = m
+        pil = np.asarray(Image.fromarray(p, "L").resize((384, 384), Image.BICUBIC)).astype(np.float32)
+        assert out.shape == (1, 384, 384) and out.dtype == torch.float32
+        assert torch.equal(out[0], torch.from_numpy(pil))
+        try:
+            from transformers import SiglipImageProcessor
+            hf = SiglipImageProcessor(size={"height": 384, "width": 384}, resample=3, do_rescale=True, rescale_factor=1 / 255,
+                                      do_normalize=True, image_mean=[0.5] * 3, image_std=[0.5] * 3)
+        except Exception:  # pragma: no cover
+            continue
+        mp = copy.deepcopy(hf)  # process_regions' own edits of the processor (mm_utils.py:479-482)
+        mp.do_normalize, mp.do_convert_rgb, mp.rescale_factor = False, False, 1.0
+        ref = mp.preprocess(p[None, ...], return_tensors="pt")["pixel_values"][0]
+        assert torch.equal(out, torch.as_tensor(ref).float())
