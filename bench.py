@@ -47,21 +47,27 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--batch", type=int, default=1, help="equal-length requests per generate() call per GPU")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8_w8a8"],
-                    help="fp8 = BASELINE configs[4]: weight-only OCP e4m3fn for the streamed LLM matrices (W8A16); fp8_w8a8 = the "
-                         "same weights, prefill on the fp8 matrix pipe with per-token e4m3 activations (opt-in); NOT the headline")
-    ap.add_argument("--preset", default=None, choices=["config1", "config2", "config3", "config4"],
+                    help="fp8 = weight-only OCP e4m3fn for the streamed LLM matrices, W8A16 throughout; fp8_w8a8 = BASELINE configs[4] "
+                         "('fp8 weights on CDNA4 fp8 MFMA'): the same weights, prefill on the fp8 matrix pipe with per-token e4m3 "
+                         "activations; neither is the headline (configs[1], bf16)")
+    ap.add_argument("--preset", default=None, choices=["config1", "config2", "config3", "config4", "config4_w8a16"],
                     help="BASELINE.json configs[i] per-GPU shape: config1 = bs 1 (default); config2 = bs 32 over 8 GPUs = 4 requests "
-                         "per GPU; config3 = llama2_7b, 16 regions, 512-id prompt; config4 = fp8 weights, bs 64 over 8 GPUs = 8 per GPU")
+                         "per GPU; config3 = llama2_7b, 16 regions, 512-id prompt; config4 = 'fp8 weights on CDNA4 fp8 MFMA', bs 64 over "
+                         "8 GPUs = 8 per GPU = --weights fp8_w8a8 (the mode README / DESIGN quote for configs[4]); config4_w8a16 = the "
+                         "same shape with W8A16 throughout (--weights fp8)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="no model, no GPU: the N ranks only rendezvous (gloo), exchange fake ids through the same gather and print "
                          "the rank-0 line -- checks the self-launch / rendezvous / gather plumbing on a CPU box")
     ap.add_argument("--cpu-decode-steps", type=int, default=12, help="decode steps the CPU baseline measures (full depth)")
+    ap.add_argument("--no-cpu-fp32", action="store_true", help="skip the float32 leg of the CPU baseline (BASELINE.md asks for fp32 and bf16)")
     a = ap.parse_args()
     if a.preset == "config2":
         a.batch = 4
     elif a.preset == "config3":
         a.model, a.regions, a.prompt_len = "llama2_7b", 16, 512
     elif a.preset == "config4":
+        a.weights, a.batch = "fp8_w8a8", 8
+    elif a.preset == "config4_w8a16":
         a.weights, a.batch = "fp8", 8
     return a
 
@@ -147,7 +153,10 @@ def synth_request(cfg, regions, prompt_len, seed, device, dtype):
     return torch.tensor([seq], device=device), images, depths, masks
 
 
-def cpu_baseline(cfg, sd_cpu, regions, prompt_len, g_cpu):
+CPU_THREADS = 16  # probed on the bench host class (scripts/cpu_probe.py): torch's CPU bf16 GEMMs are fastest at 16 threads
+
+
+def cpu_baseline(cfg, sd_cpu, regions, prompt_len, g_cpu, dtype=torch.bfloat16):
     """The oracle (CPU restatement of the reference's path, oracle/srgpt_oracle.py) on the host cores at FULL depth and true
     widths: both tower passes, refinement / pooling / projector / splice, the T-position prefill with lm_head on every row (as the
     reference computes it) and `g_cpu` greedy decode steps -- every stage of the request is measured, only the decode-step count
@@ -158,8 +167,8 @@ def cpu_baseline(cfg, sd_cpu, regions, prompt_len, g_cpu):
     ocfg = so.SrgptConfig(**{k: v for k, v in cfg.to_dict().items() if k in names})
     # thread count: probed on the 256-core bench host (scripts/cpu_probe.py) -- torch's CPU bf16 path is fastest
     # at 16 threads (22.9 ms / 2-layer decode step) and collapses beyond 64 (5.1 s at 256 threads)
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    ids, images, depths, masks = so.synth_inputs(ocfg, batch=1, regions=regions, prompt_len=prompt_len, seed=1, dtype=torch.bfloat16)
+    torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or 1))
+    ids, images, depths, masks = so.synth_inputs(ocfg, batch=1, regions=regions, prompt_len=prompt_len, seed=1, dtype=dtype)
     t = {}
     with torch.no_grad():
         t0 = time.perf_counter()
@@ -227,17 +236,30 @@ def launcher_selftest(args):
 
     from spatialrgpt_amd.dist import gather_ids, init_distributed
 
+    from spatialrgpt_amd.dist import barrier
+
     rank, world, _ = init_distributed(backend="gloo")
     assert world == args.gpus
     G = args.max_new_tokens
     ids = torch.full((args.batch, G), rank, dtype=torch.int64)
     out = gather_ids(ids)
-    if world > 1:
-        dist.barrier()
+    barrier()
     assert out.shape == (world * args.batch, G) and all(int(out[r * args.batch, 0]) == r for r in range(world))
+    # per-rank figures travel like the real run's (all_gather of one row per rank)
+    mine = torch.tensor([float(rank), float(args.batch * G)], dtype=torch.float64)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allr, mine)
+    else:
+        allr = [mine]
     if rank == 0:
+        cfg = make_cfg(args.model)
         print(json.dumps({"selftest": "launcher", "n_gpus": world, "world_size_seen": world, "gathered_rows": int(out.shape[0]),
-                          "launcher": "self" if os.environ.get("SRGPT_BENCH_SELF_LAUNCHED") else "external"}), flush=True)
+                          "launcher": "self" if os.environ.get("SRGPT_BENCH_SELF_LAUNCHED") else "external",
+                          "preset": args.preset, "llm_weights": args.weights, "requests_per_step_per_gpu": args.batch,
+                          "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                          "workload": workload_name(args, cfg, spliced_len(cfg, args.prompt_len)),
+                          "per_rank_rows": [[int(t[0]), int(t[1])] for t in allr]}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -295,10 +317,11 @@ def main():
     for _ in range(args.warmup):
         out = step()
 
+    from spatialrgpt_amd.dist import barrier as dist_barrier
+
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        dist_barrier(device.index)  # names this rank's device under RCCL (no guessing from the global rank)
         torch.cuda.synchronize()
 
     barrier()
@@ -401,9 +424,25 @@ def main():
     if sd_cpu is not None:
         g_cpu = max(1, args.cpu_decode_steps)
         t = cpu_baseline(cfg, sd_cpu, args.regions, args.prompt_len, g_cpu)
-        del sd_cpu
         total = t["vit_x2"] + t["region_proj_splice"] + t["prefill"] + (G - 1) * t["decode_step"]
+        # fp32 leg (BASELINE.md section 3 asks for fp32 and bf16): the same request on the same (bf16-valued) weights in float32,
+        # bounded harder -- 3 decode steps -- because the conversion alone doubles the host footprint
+        fp32 = None
+        if not args.no_cpu_fp32:
+            sd32 = {k: v.float() for k, v in sd_cpu.items()}
+            del sd_cpu
+            t32 = cpu_baseline(cfg, sd32, args.regions, args.prompt_len, min(3, g_cpu), dtype=torch.float32)
+            del sd32
+            tot32 = t32["vit_x2"] + t32["region_proj_splice"] + t32["prefill"] + (G - 1) * t32["decode_step"]
+            fp32 = {"value": round(G / tot32, 4), "measured_s": {k: round(v, 4) for k, v in t32.items()}}
         cpu = {"value": round(G / total, 4), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+               "dtype": "bf16 (the reference's eval dtype, eval_spatial.py:221-237)",
+               "fp32_value": None if fp32 is None else fp32["value"], "fp32_measured_s": None if fp32 is None else fp32["measured_s"],
+               "threads": torch.get_num_threads(), "host_cores": os.cpu_count(),
+               "threads_probed": "1 .. 256 on this host class (scripts/cpu_probe.py): 16 fastest for torch's CPU bf16 GEMMs, >64 collapses",
+               "port_vs_reference": ("the oracle takes 0.82x (fp32) / 0.98x (bf16) of the REAL reference generate()'s time on the same "
+                                     "weights, inputs and threads, ids identical (scaled-down geometry, build container: "
+                                     "profiles/r02_cpu_reference_vs_oracle.txt) -- /root/reference does not exist on the bench box"),
                "sample": (f"oracle (CPU restatement of the reference path, bf16, same weights) at FULL depth ({cfg.layers} LLM layers, "
                           f"{cfg.vit_layers_run} ViT layers x2 images) on one request: vision {t['vit_x2']:.2f}s + region/projector/splice "
                           f"{t['region_proj_splice']:.2f}s + prefill(T={spliced_len(cfg, args.prompt_len)}, lm_head on all rows) {t['prefill']:.2f}s "
@@ -426,7 +465,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        dist_barrier(device.index)
         dist.destroy_process_group()
 
 

@@ -31,6 +31,18 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     return rank, world, local
 
 
+def barrier(local: Optional[int] = None, group=None) -> None:
+    """dist.barrier that names this rank's device under the RCCL backend: without `device_ids` the nccl backend guesses the device
+    from the global rank (and warns), which is wrong the moment ranks and devices are not numbered alike."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    if dist.get_backend(group) == "nccl":
+        dev = torch.cuda.current_device() if local is None else local
+        dist.barrier(group=group, device_ids=[dev])
+    else:
+        dist.barrier(group=group)
+
+
 def split_list(lst: Sequence, n: int) -> List[Sequence]:
     """eval_spatial.py:72-75: chunks of size ceil(len/n) (the last ranks may get fewer / none)."""
     chunk = math.ceil(len(lst) / n) if len(lst) else 1

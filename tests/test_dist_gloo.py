@@ -89,3 +89,30 @@ def test_bench_self_launch_plumbing():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["world_size_seen"] == 2 and j["gathered_rows"] == 6 and j["launcher"] == "self"
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("preset,batch,weights", [("config2", 4, "bf16"), ("config4", 8, "fp8_w8a8")])
+def test_bench_eight_rank_dry_run_names_the_global_batch(preset, batch, weights):
+    """Nobody can hand this build 8 GPUs (one per lease; SCALE_rNN.json has been a `skipped` record every round), so the 8-rank leg
+    of `bench.py --gpus 8 --preset config2|config4` is exercised with 8 CPU ranks over gloo: self-launch of 8 processes, rendezvous,
+    the id gather over 8 shards, the per-rank rows, and a rank-0 line that names BASELINE configs[2] / configs[4]'s GLOBAL batch
+    (32 / 64) and the mode the preset selects (configs[4] = fp8 weights on the fp8 matrix pipe = fp8_w8a8, VERDICT r3 weak #8)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--preset", preset, "--selftest-launcher",
+                        "--max-new-tokens", "16"], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["world_size_seen"] == 8 and j["parallelism"] == "dp8" and j["launcher"] == "self"
+    assert j["requests_per_step_per_gpu"] == batch and j["global_batch"] == 8 * batch == {"config2": 32, "config4": 64}[preset]
+    assert j["gathered_rows"] == 8 * batch and j["llm_weights"] == weights
+    assert f"configs[{preset[-1]}]" in j["workload"]
+    assert j["per_rank_rows"] == [[r_, batch * 16] for r_ in range(8)]
