@@ -571,6 +571,92 @@ def mint_vendored_llama_kat():
     print("  wrote vendored_llama_kat.npz; vendored greedy ids:", ref_ids.tolist(), " bf16:", b_ids.tolist())
 
 
+def mint_beam_kat():
+    """`generate(num_beams=3)` of the REFERENCE model (tiny fp32, the weights of tiny_fp32.npz) -- the `--num_beams` flag of
+    eval_spatial.py:234 / eval_region_cls.py:321 / model_vqa.py:75 -- for three settings: no EOS (every hypothesis runs to the
+    budget), an EOS id that the search meets (hypotheses of different lengths compete under the length penalty), and a batch of two
+    different prompts.  Asserts that spatialrgpt_amd.generation.beam_search, driven by the oracle's llama_forward, returns the same
+    ids, and writes tests/golden/beam_kat.npz (inputs are tiny_fp32.npz's; only the settings and the reference ids are stored)."""
+    print("== beam_kat.npz")
+    from spatialrgpt_amd.generation import beam_search
+
+    dtype = torch.float32
+    with tempfile.TemporaryDirectory() as td:
+        model, tok = rh.build_tiny_reference_model(td, llm=TINY_LLM, vit=TINY_VIT, dtype="torch.float32", seed=0)
+    g = torch.Generator().manual_seed(123)
+    with torch.no_grad():  # the same post-init edits as mint_model_case / mint_labels_kat: identical weights
+        for n, p in model.named_parameters():
+            if n.endswith("norm.weight") or "layernorm" in n or "layer_norm" in n or n.endswith("module.1.weight") \
+                    or n == "mm_projector.layers.1.weight":
+                if n.endswith("weight"):
+                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif n.endswith(".bias"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    cfg = cfg_from(model, tok)
+    w = canonical_state_dict(model)
+    gold = np.load(os.path.join(GOLD, "tiny_fp32.npz"))
+    for k, v in w.items():
+        assert np.array_equal(gold["w." + k], tensor_np(v)), k
+    ids, images, depths, masks = so.synth_inputs(cfg, batch=1, regions=2, prompt_len=15, seed=1, dtype=dtype)
+    ids2, images2, depths2, masks2 = so.synth_inputs(cfg, batch=2, regions=2, prompt_len=15, seed=5, dtype=dtype)
+    NB, G = 3, 12
+    # a NON-ZERO pad id: the installed transformers pads finished rows with `pad_token_id or eos_token_id[0]`, so pad id 0 is
+    # replaced by the first EOS id there; the reference's pinned 4.37.2 (BeamSearchScorer.finalize) pads with pad_token_id itself,
+    # which is what spatialrgpt_amd.generation.beam_search does -- with a non-zero pad id the two releases agree
+    PAD = 7
+
+    def ref(ids_, im, dp, mk, **kw):
+        with torch.no_grad():
+            return model.generate(input_ids=ids_, images=im, depths=dp, masks=mk, do_sample=False, num_beams=NB, max_new_tokens=G,
+                                  use_cache=True, **kw)
+
+    def mine(ids_, im, dp, mk, eos, pad):
+        emb, am, pid, _ = so.prepare_inputs(w, cfg, ids_, im, dp, mk)
+        B, T, _ = emb.shape
+        emb = emb.repeat_interleave(NB, dim=0)
+        state = {"kv": so.KVCache(cfg.layers), "pos": T}
+        first = so.llama_forward(w, cfg, emb, torch.arange(T)[None].expand(B * NB, -1), state["kv"], last_only=True)[:, -1]
+
+        def step(tokens, beam_idx):
+            kv = state["kv"]
+            kv.k = [k.index_select(0, beam_idx) for k in kv.k]
+            kv.v = [v.index_select(0, beam_idx) for v in kv.v]
+            e = torch.nn.functional.embedding(tokens[:, None], w["llm.model.embed_tokens.weight"])
+            lg = so.llama_forward(w, cfg, e, torch.full((B * NB, 1), state["pos"]), kv, last_only=True)[:, -1]
+            state["pos"] += 1
+            return lg
+
+        return beam_search(first, step, B, NB, G, eos, pad)
+
+    out = {}
+    a = ref(ids, images, depths, masks, eos_token_id=None, pad_token_id=PAD)
+    b = mine(ids, images, depths, masks, None, PAD)
+    assert torch.equal(a, b), (a, b)
+    greedy = gold["ref.new_ids"]
+    print("  no EOS:", a.tolist(), " (greedy:", greedy.tolist(), ")")
+    out["noeos.ids"] = a.numpy()
+    # an EOS id the search meets: a token the no-EOS best hypothesis emits mid-way, plus one it never emits (a LIST, like Llama-3)
+    eos = [int(a[0, 5]), 119]
+    a2 = ref(ids, images, depths, masks, eos_token_id=eos, pad_token_id=PAD)
+    b2 = mine(ids, images, depths, masks, eos, PAD)
+    assert torch.equal(a2, b2), (a2, b2)
+    print("  EOS", eos, ":", a2.tolist())
+    out["eos.ids"], out["eos.eos"] = a2.numpy(), np.array(eos)
+    a3 = ref(ids2, images2, depths2, masks2, eos_token_id=eos, pad_token_id=PAD)
+    b3 = mine(ids2, images2, depths2, masks2, eos, PAD)
+    assert torch.equal(a3, b3), (a3, b3)
+    print("  batch of 2, EOS", eos, ":", a3.tolist())
+    out["batch2.ids"], out["batch2.input_ids"] = a3.numpy(), ids2.numpy()
+    out["batch2.images_q32"] = (images2 * 32).round().to(torch.int8).numpy()
+    out["batch2.depths_q32"] = (depths2[:, :1] * 32).round().to(torch.int8).numpy()
+    out["batch2.masks_u8"] = torch.stack(masks2).to(torch.uint8).numpy()
+    out["num_beams"], out["max_new_tokens"], out["pad_token_id"] = np.int64(NB), np.int64(G), np.int64(PAD)
+    np.savez_compressed(os.path.join(GOLD, "beam_kat.npz"), **out)
+    print("  wrote beam_kat.npz")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -579,6 +665,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt":  # only the reference-written checkpoint directory
         mint_checkpoint()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "beam":  # only the beam-search fixture
+        mint_beam_kat()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "vendored":  # only the vendored-Llama fixture (rope scaling, flash-attn call sites)
         mint_vendored_llama_kat()
@@ -595,4 +684,5 @@ if __name__ == "__main__":
     mint_posembed_kat()
     mint_checkpoint()
     mint_vendored_llama_kat()
+    mint_beam_kat()
     print("golden vectors written to", GOLD)

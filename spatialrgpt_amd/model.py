@@ -392,8 +392,8 @@ class LlavaLlamaModel:
         g = resolve_generation(self.generation_defaults(), do_sample=do_sample, temperature=temperature, top_p=top_p, top_k=top_k,
                                num_beams=num_beams, max_new_tokens=max_new_tokens, max_length=max_length,
                                min_new_tokens=min_new_tokens, pad_token_id=pad_token_id, eos_token_id=eos_token_id)
-        if g.num_beams != 1:
-            raise NotImplementedError("beam search is not implemented (the reference's callers use num_beams=1)")
+        if g.num_beams != 1 and g.do_sample:
+            raise NotImplementedError("beam-sample decoding (num_beams > 1 with do_sample=True) is not implemented")
         max_new_tokens = g.max_new_tokens
         eos_ids = g.eos_token_ids
         if g.min_new_tokens is not None and g.min_new_tokens >= max_new_tokens:
@@ -418,6 +418,8 @@ class LlavaLlamaModel:
             inputs_embeds = packed.contiguous()
             if min(lens_h) == Tmax:
                 lens = None
+        if g.num_beams != 1:
+            return self._beam_search(inputs_embeds, lens, g.num_beams, max_new_tokens, eos_ids, g.pad_token_id, stopping_criteria)
         st, _, _ = self.engine.prefill(inputs_embeds, max_new=max_new_tokens, lens=lens)
         if g.do_sample and g.temperature is not None and g.temperature > 0:
             from . import ops
@@ -435,6 +437,32 @@ class LlavaLlamaModel:
                                      stopping_criteria)
         return self.engine.greedy_decode(st, max_new_tokens, eos_token_id=eos_ids, pad_token_id=g.pad_token_id,
                                          stopping_criteria=stopping_criteria)
+
+    def _beam_search(self, inputs_embeds, lens, num_beams, max_new_tokens, eos_ids, pad_token_id, stopping_criteria):
+        """`generate(num_beams > 1)` -- the `--num_beams` flag of eval_spatial.py:234, eval_region_cls.py:321, model_vqa.py:75 (default
+        1: the benchmarked path is the greedy loop).  HF semantics in spatialrgpt_amd/generation.beam_search (pinned to the
+        reference's own generate(num_beams=3), tests/golden/beam_kat.npz); here only the device side: every batch item's prompt is
+        prefilled once per beam (HF's `_expand_inputs_for_generation`), each step runs the HIP decode step on batch * num_beams
+        rows, and the KV-cache rows are gathered by the beam indices the search picked.  The beam bookkeeping itself (log-softmax,
+        top-k over num_beams * vocab, a handful of [batch, 2 * num_beams] tensors) is torch on the device: a rarely used,
+        latency-tolerant mode -- not part of the measured path."""
+        from .generation import beam_search
+
+        eng = self.engine
+        B = inputs_embeds.shape[0]
+        emb = inputs_embeds.repeat_interleave(num_beams, dim=0)
+        lens_x = None if lens is None else lens.repeat_interleave(num_beams, dim=0)
+        st, _, _ = eng.prefill(emb, max_new=max_new_tokens, lens=lens_x)
+
+        def step(tokens, beam_idx):
+            # rows of the next step continue from the caches of the beams the search kept (all beams of a batch item share their
+            # position, so only K / V rows move)
+            st.kcache.copy_(st.kcache.index_select(1, beam_idx))
+            st.vcache.copy_(st.vcache.index_select(1, beam_idx))
+            return eng.step(st, tokens[:, None])
+
+        return beam_search(st.logits.clone(), step, B, num_beams, max_new_tokens, eos_ids, pad_token_id,
+                           stopping_criteria=stopping_criteria)
 
     def _sample_loop(self, st, max_new_tokens, temperature, top_p, top_k, eos_token_id, pad_token_id, stopping_criteria,
                      check_every: int = 8):

@@ -413,3 +413,35 @@ def test_graph_replay_honours_a_token_written_into_state_between_replays():
     L.check(lib.srgpt_llm_decode_step(C.byref(eng.w.llm), C.byref(st3.c), ops._stream()))
     torch.cuda.synchronize()
     assert not torch.equal(st3.logits, a_logits)
+
+
+def test_beam_search_matches_the_references_generate_num_beams_3():
+    """model.generate(num_beams=3) on the fp32 engine == the ids of the REFERENCE model's generate(num_beams=3)
+    (tests/golden/beam_kat.npz, minted from the reference on the tiny_fp32 weights): no EOS, an EOS list the search meets, and a
+    batch of two prompts (a finished row padded with pad_token_id).  The `--num_beams` flag of eval_spatial.py:234 /
+    eval_region_cls.py:321 / model_vqa.py:75; the KV-cache rows follow the beam permutation every step."""
+    import os
+
+    from tests.util import GOLD
+    model, cfg, dtype, w, inp, ref = _engine("tiny_fp32.npz")
+    d = _to_dev(inp)
+    z = np.load(os.path.join(GOLD, "beam_kat.npz"))
+    NB, G, PAD = int(z["num_beams"]), int(z["max_new_tokens"]), int(z["pad_token_id"])
+    kw = dict(do_sample=False, num_beams=NB, max_new_tokens=G, pad_token_id=PAD)
+    out = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], eos_token_id=None, **kw)
+    assert torch.equal(out.cpu(), torch.from_numpy(z["noeos.ids"]))
+    assert not torch.equal(out.cpu(), ref["new_ids"])  # the beam result is NOT the greedy continuation on this model
+    eos = z["eos.eos"].tolist()
+    out = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], eos_token_id=eos, **kw)
+    assert torch.equal(out.cpu(), torch.from_numpy(z["eos.ids"]))
+    images = (torch.from_numpy(z["batch2.images_q32"].astype(np.float32)) / 32).to(DEV)
+    depths = (torch.from_numpy(z["batch2.depths_q32"].astype(np.float32)) / 32).expand(-1, 3, -1, -1).contiguous().to(DEV)
+    masks = [torch.from_numpy(m.astype(np.float32)).to(DEV) for m in z["batch2.masks_u8"]]
+    out = model.generate(torch.from_numpy(z["batch2.input_ids"]).to(DEV), images=images, depths=depths, masks=masks, eos_token_id=eos, **kw)
+    assert torch.equal(out.cpu(), torch.from_numpy(z["batch2.ids"]))
+    # greedy on the same pooled engine afterwards is untouched by the beam run
+    g = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], do_sample=False, max_new_tokens=12,
+                       eos_token_id=None)
+    assert torch.equal(g.cpu(), ref["new_ids"])
+    with pytest.raises(NotImplementedError):
+        model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], do_sample=True, num_beams=2, max_new_tokens=4)

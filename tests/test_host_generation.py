@@ -95,3 +95,49 @@ def test_generation_config_file_beats_model_config(tmp_path):
     tok2 = load_tokenizer(root, cfg2, sd2, model_max_length=777)
     assert tok2.model_max_length == 777
     assert cfg.eos_token_id == [2, 9]  # the tokenizer's eos id never replaces the generation config's
+
+
+def test_beam_search_reproduces_the_references_generate_num_beams_3():
+    """tests/golden/beam_kat.npz = ids of the REFERENCE model's generate(num_beams=3) (oracle/make_golden.py beam) on the tiny fp32
+    model of tiny_fp32.npz: no EOS, an EOS list the search meets (length-penalised hypotheses of different lengths), a batch of two.
+    `generation.beam_search`, driven by the oracle's llama_forward on the CPU, returns the same ids -- and not the greedy ones."""
+    import os
+
+    import numpy as np
+
+    from oracle import srgpt_oracle as so
+    from spatialrgpt_amd.generation import beam_search
+    from tests.util import GOLD, load_tiny
+
+    cfgd, dtype, w, inp, ref = load_tiny("tiny_fp32.npz")
+    cfg = so.SrgptConfig(**{k: v for k, v in cfgd.items() if k in so.SrgptConfig.__dataclass_fields__})
+    z = np.load(os.path.join(GOLD, "beam_kat.npz"))
+    NB, G, PAD = int(z["num_beams"]), int(z["max_new_tokens"]), int(z["pad_token_id"])
+
+    def run(ids, images, depths, masks, eos):
+        emb, _, _, _ = so.prepare_inputs(w, cfg, ids, images, depths, masks)
+        B, T, _ = emb.shape
+        state = {"kv": so.KVCache(cfg.layers), "pos": T}
+        first = so.llama_forward(w, cfg, emb.repeat_interleave(NB, dim=0), torch.arange(T)[None].expand(B * NB, -1), state["kv"],
+                                 last_only=True)[:, -1]
+
+        def step(tokens, beam_idx):
+            kv = state["kv"]
+            kv.k = [k.index_select(0, beam_idx) for k in kv.k]
+            kv.v = [v.index_select(0, beam_idx) for v in kv.v]
+            e = torch.nn.functional.embedding(tokens[:, None], w["llm.model.embed_tokens.weight"])
+            lg = so.llama_forward(w, cfg, e, torch.full((B * NB, 1), state["pos"]), kv, last_only=True)[:, -1]
+            state["pos"] += 1
+            return lg
+
+        return beam_search(first, step, B, NB, G, eos, PAD)
+
+    one = (inp["input_ids"], inp["images"], inp["depths"], inp["masks"])
+    out = run(*one, None)
+    assert torch.equal(out, torch.from_numpy(z["noeos.ids"])) and not torch.equal(out, ref["new_ids"])
+    eos = z["eos.eos"].tolist()
+    assert torch.equal(run(*one, eos), torch.from_numpy(z["eos.ids"]))
+    images = torch.from_numpy(z["batch2.images_q32"].astype(np.float32)) / 32
+    depths = (torch.from_numpy(z["batch2.depths_q32"].astype(np.float32)) / 32).expand(-1, 3, -1, -1).contiguous()
+    masks = [torch.from_numpy(m.astype(np.float32)) for m in z["batch2.masks_u8"]]
+    assert torch.equal(run(torch.from_numpy(z["batch2.input_ids"]), images, depths, masks, eos), torch.from_numpy(z["batch2.ids"]))
