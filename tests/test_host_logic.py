@@ -202,8 +202,10 @@ def test_bench_presets_map_to_baseline_configs(monkeypatch):
     assert a.batch == 4 and "configs[2]" in name
     a, name = wl(["--preset", "config3"])
     assert a.model == "llama2_7b" and a.regions == 16 and a.prompt_len == 512 and "configs[3]" in name and "T=707" in name
-    a, name = wl(["--preset", "config4"])
-    assert a.weights == "fp8" and a.batch == 8 and "configs[4]" in name
+    a, name = wl(["--preset", "config4"])  # "fp8 weights on CDNA4 fp8 MFMA" = the W8A8-prefill mode README / DESIGN quote
+    assert a.weights == "fp8_w8a8" and a.batch == 8 and "configs[4]" in name and "fp8 matrix pipe" in name
+    a, name = wl(["--preset", "config4_w8a16"])
+    assert a.weights == "fp8" and a.batch == 8 and "configs[4]" in name and "fp8 matrix pipe" not in name
     a, name = wl(["--batch", "3"])
     assert "non-BASELINE" in name
     assert isinstance(bench.make_cfg("vila15_8b_clip336"), SrgptConfig)
