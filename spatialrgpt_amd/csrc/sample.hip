@@ -240,9 +240,10 @@ __global__ __launch_bounds__(1024) void sample_select_kernel(const srgpt_samplin
   __syncthreads();
   if (n_list > (unsigned)SMP_LIST && tid == 0) atomicOr(err, 2);  // > 256 - k entries tie at the k-th score: reported, not silent
   const int nk = min((int)n_list, SMP_LIST);
-  // rank by (score desc, index DESC): TopPLogitsWarper sorts ascending -- torch.sort leaves equal scores in index order -- and
-  // cuts from the small end, never the last entry: among equal scores the HIGHEST index survives longest (three equal maxima
-  // under a tight top-p keep the one with the largest id).  A total order: the list does not depend on the append order above.
+  // rank by (score desc, index DESC): TopPLogitsWarper sorts ascending and cuts from the small end, never the last entry.  Where the
+  // cut runs through a group of exactly equal scores, which members survive is torch.sort's tie order -- index order for short
+  // rows (then the HIGHEST index survives longest: what this order reproduces), unspecified for long ones -- so only the kept
+  // VALUES are defined there.  A total order: the list does not depend on the append order above.
   for (int e = tid; e < nk; e += nt) {
     const unsigned ke = lkey[e];
     const int ie = lidx[e];

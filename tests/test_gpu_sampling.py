@@ -53,7 +53,14 @@ def test_kept_set_equals_hf_warpers(temperature, top_k, top_p, V):
         want = set(torch.nonzero(ref[b] > float("-inf")).flatten().tolist())
         n = int(kept[b, 0])
         got = kept[b, 1:1 + n].tolist()
-        assert len(set(got)) == n and set(got) == want, (b, n, len(want), sorted(set(got) ^ want)[:10])
+        assert len(set(got)) == n == len(want), (b, n, len(want))
+        diff = set(got) ^ want
+        if diff:
+            # a top-p cut THROUGH a group of exactly equal scores: which members survive is torch.sort's tie order (stable for
+            # short rows, not for long ones -- observed: V = 70 keeps the highest index, V = 1000 the middle one), i.e. not defined
+            # by HF either; the kept VALUES must agree, and only members of that one tie group may differ
+            vals = {float(lg[b, i]) for i in diff}
+            assert len(vals) == 1 and b == 2, (b, sorted(diff)[:10], vals)
         # best first: scores non-increasing
         sc = (lg[b].cpu() / temperature)[got]
         assert bool((sc[:-1] >= sc[1:]).all())
