@@ -32,7 +32,7 @@ def run(**kw):
     for _ in range(3):
         torch.cuda.synchronize()
         t = time.perf_counter()
-        out = model.generate(req[0], images=req[1], depths=req[2], masks=req[3], max_new_tokens=G, eos_token_id=None, **kw)
+        out = model.generate(req[0], images=req[1], depths=req[2], masks=req[3], max_new_tokens=G, **{'eos_token_id': None, **kw})
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
         best = dt if best is None else min(best, dt)
@@ -41,6 +41,7 @@ def run(**kw):
 
 
 rows = [("greedy", dict(do_sample=False)),
+        ("greedy, EOS id set (never met: judged every step, one behind)", dict(do_sample=False, eos_token_id=2)),
         ("greedy + stopping criterion (run-ahead)", dict(do_sample=False, stopping_criteria=[never])),
         ("sample T=0.2 top_k=50 (the demo)", dict(do_sample=True, temperature=0.2)),
         ("sample T=0.2 top_k=50 + stopping criterion (the demo)", dict(do_sample=True, temperature=0.2, stopping_criteria=[never])),

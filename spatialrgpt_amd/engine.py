@@ -462,7 +462,7 @@ class SrgptEngine:
         return st.logits.clone()
 
     def greedy_decode(self, st: DecodeState, max_new_tokens: int, eos_token_id=None, pad_token_id=None,
-                      stopping_criteria=None, check_every: int = 8, sampling: Optional[dict] = None) -> torch.Tensor:
+                      stopping_criteria=None, sampling: Optional[dict] = None) -> torch.Tensor:
         """HF generation-loop semantics (new ids only, finished rows padded), device-side steps via hipGraph.
         sampling = None: greedy.  sampling = dict(temperature, top_k, top_p, seed): every step DRAWS its token on the device
         (temperature -> top-k -> top-p -> categorical, sample.hip) -- same loop, same graph mechanism, no per-token host work."""
@@ -471,7 +471,7 @@ class SrgptEngine:
         with torch.cuda.stream(self.stream):
             st.set_sampling(sampling)
             try:
-                n_keep, eos = self._decode_loop(st, max_new_tokens, eos_token_id, stopping_criteria, check_every)
+                n_keep, eos = self._decode_loop(st, max_new_tokens, eos_token_id, stopping_criteria)
             finally:
                 st.c.sampling = None
         cur.wait_stream(self.stream)
@@ -487,7 +487,7 @@ class SrgptEngine:
             out = torch.where(after, torch.full_like(out, pad), out)
         return out
 
-    def _decode_loop(self, st: DecodeState, max_new_tokens: int, eos_token_id, stopping_criteria, check_every: int):
+    def _decode_loop(self, st: DecodeState, max_new_tokens: int, eos_token_id, stopping_criteria):
         lib = L.load()
         stream = ops._stream()
         L.check(lib.srgpt_llm_sample_first(C.byref(self.w.llm), C.byref(st.c), stream))
@@ -524,22 +524,16 @@ class SrgptEngine:
                             return s_ + 1
             return None
 
-        if interactive:
+        if interactive or eos:
+            # anything that can end the request early is judged EVERY step, one step behind the device.  Round 3 scanned for EOS
+            # every `check_every` = 8 steps: a request that ends in EOS -- the reference's real eval mode, eval_spatial.py:221-237,
+            # answers of a few dozen tokens -- ran 3.5 steps (10 ms at 2.9 ms per token) past its end on average; the run-ahead
+            # loop wastes at most ONE step and costs 1.6 % while it runs (profiles/r04_sampling.txt)
             return self._decode_loop_run_ahead(st, max_new_tokens, launch, judge), eos
-
-        chunk = check_every if eos else max_new_tokens
-        done_step = 1
-        n_keep = max_new_tokens
-        stop = judge(st.out_ids[:, :1].to("cpu"), 0, 1) if eos else None
-        while stop is None and done_step < max_new_tokens:
-            n = min(chunk, max_new_tokens - done_step)
-            launch(n)
-            if eos:
-                stop = judge(st.out_ids[:, :done_step + n].to("cpu"), done_step, done_step + n)
-            done_step += n
-        if stop is not None:
-            n_keep = stop
-        return n_keep, eos
+        # nothing can stop the request early (the benchmark: EOS disabled): all steps are queued at once, no host work per token
+        if max_new_tokens > 1:
+            launch(max_new_tokens - 1)
+        return max_new_tokens, eos
 
     def _decode_loop_run_ahead(self, st: DecodeState, max_new_tokens: int, launch, judge) -> int:
         """A stopping criterion (the demo's KeywordsStoppingCriteria, gradio_web_server_multi.py:195-197; model_vqa.py's conv stop
