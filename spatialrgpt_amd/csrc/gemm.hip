@@ -286,118 +286,6 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_bf16_glds(const b
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// "tall" kernel (round 4): prefill GEMMs of 257 .. 383 rows -- the bs = 1 request (T = 259 spliced positions), where a 256-row
-// tile pads to 512 and the 96 x 128 tiles above are bound by the global -> LDS fill path of a CU (a 96 x 128 x 64 step pushes
-// 28 KB through LDS-DMA for 1.6 MFLOP; every N tile re-streams its 96 rows of A through the same path: 1.2 GB per gate/up GEMM).
-// Here a block owns ALL rows and 128 columns:
-//   * the weights (the HBM stream: each W tile is read by exactly one block) go HBM -> LDS by LDS-DMA, double buffered, with
-//     gemm_bf16_glds's source-side XOR swizzle -> conflict-free ds_read_b128 fragments;
-//   * the activations never touch LDS: wave w owns rows 32 w .. 32 w + 31 and loads its MFMA A fragments (8 consecutive k of its
-//     row per lane = the operand shape) straight from L2 into registers, one K tile ahead -- the fill path carries 16 KB per K
-//     tile instead of 53 KB, the L1 / TA path the 9 - 12 KB of A;
-//   * every wave multiplies its 32 rows by the 128 columns: 4 accumulators (32 x 32 each), 16 MFMAs per K tile per wave.
-// Per layer of the 8B geometry the four GEMMs then stream 436 MB of weights once with ~2.4 MB of A per block from L2; grids that do
-// not fill the chip split K (deterministic slabs, the reduce kernel below).  NWM = ceil(M / 32) waves, one block per CU.
-// ------------------------------------------------------------------------------------------------
-template <int NWM>
-__global__ __launch_bounds__(64 * NWM, 1) void gemm_bf16_tall(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, int K,
-                                                              int lda, Epilogue e) {
-  constexpr int BN = 128, TN = BN / 32, NG = BN / 8;  // NG groups of 8 weight rows x 128 B per K tile: one LDS-DMA instruction each
-  constexpr int GPW = (NG + NWM - 1) / NWM;           // groups a wave stages
-  constexpr int TILE = BN * BK;
-  __shared__ __attribute__((aligned(1024))) bf16_t lds[2 * TILE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * BN;
-  const int lr = lane >> 3;
-  const int nk_all = K / BK;  // K % 64 == 0 (launcher)
-  const int kt0 = e.splits > 1 ? (int)blockIdx.z * e.tiles_per_split : 0;
-  const int nk = e.splits > 1 ? min(nk_all, kt0 + e.tiles_per_split) : nk_all;
-
-  const bf16_t* pw[GPW];
-  int gdst[GPW];
-#pragma unroll
-  for (int i = 0; i < GPW; ++i) {
-    const int g = min(wave + NWM * i, NG - 1);
-    const int lc = (lane & 7) ^ (((g & 1) << 2) | (lr >> 1));  // logical chunk = physical slot ^ swz(row), swz(row) = (row >> 1) & 7
-    pw[i] = W + (size_t)min(n0 + g * 8 + lr, e.N - 1) * K + lc * 8;
-    gdst[i] = g * 8 * BK;
-  }
-  auto stage = [&](int kt, int buf) {
-    bf16_t* Ws = lds + buf * TILE;
-#pragma unroll
-    for (int i = 0; i < GPW; ++i)
-      if (wave + NWM * i < NG)  // wave-uniform
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw[i] + (size_t)kt * BK),
-                                         (__attribute__((address_space(3))) void*)(Ws + gdst[i]), 16, 0, 0);
-  };
-  // A fragments of v_mfma_f32_32x32x16_bf16: lane (row = lane & 31, k half = lane >> 5) holds 8 consecutive k of its row
-  const bf16_t* pa = A + (size_t)min(wave * 32 + (lane & 31), e.M - 1) * lda + (lane >> 5) * 8;
-  bf16x8 fa[BK / 16], fn[BK / 16];  // this tile's fragments / the next tile's, requested one tile ahead
-  auto load_a = [&](int kt, bf16x8 (&d)[BK / 16]) {
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) d[ks] = *reinterpret_cast<const bf16x8*>(pa + (size_t)kt * BK + ks * 16);
-  };
-
-  f32x16 acc[TN];
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < TN; ++j) acc[j] = zero16;
-
-  if (kt0 < nk) {
-    stage(kt0, 0);
-    load_a(kt0, fa);
-  }
-  for (int kt = kt0; kt < nk; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    __syncthreads();  // tile kt has landed (the barrier carries the vmcnt(0) of the LDS-DMA); every wave is done with tile kt - 1
-    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-    load_a(min(kt + 1, nk - 1), fn);  // unconditional (the last tile re-reads itself): no branch around loads in the loop
-    const bf16_t* Ws = lds + cur * TILE;
-    // fragment reads one k step ahead of their MFMAs, on two register sets (left alone the compiler reads a pair, waits for it and
-    // multiplies: a full LDS latency per pair of MFMAs)
-    bf16x8 fw[2][TN];
-    auto read_w = [&](int ks, bf16x8 (&d)[TN]) {
-      const int slot = ks * 2 + (lane >> 5);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int r = j * 32 + (lane & 31);
-        d[j] = *reinterpret_cast<const bf16x8*>(Ws + r * BK + ((slot ^ ((r >> 1) & 7)) << 3));
-      }
-    };
-    read_w(0, fw[0]);
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      if (ks + 1 < BK / 16) read_w(ks + 1, fw[(ks + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], fw[ks & 1][j], acc[j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) fa[ks] = fn[ks];
-  }
-
-  // D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const int mb = wave * 32 + 4 * (lane >> 5);
-#pragma clang loop unroll(full)
-  for (int j = 0; j < TN; ++j) {
-    const f32x16 a = acc[j];
-    const int n = n0 + j * 32 + (lane & 31);
-    if (e.splits > 1) {
-      float* slab = e.partial + (size_t)blockIdx.z * e.M * e.N;
-#pragma clang loop unroll(full)
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m < e.M && n < e.N) slab[(size_t)m * e.N + n] = a[r];
-      }
-    } else {
-      epilogue_tile32<bf16_t>(e, mb, n, a);
-    }
-  }
-}
-
 // split-K second pass: fixed-order sum of the fp32 slabs, then the fused epilogue
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(Epilogue e) {
@@ -604,41 +492,6 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
     dim3 grid(cdiv(N, 64), cdiv(M, 64));
     hipLaunchKernelGGL(gemm_f32_simple, grid, dim3(256), 0, s, (const float*)A, (const float*)W, K, lda, e);
     SRGPT_LAUNCH_CHECK();
-    return SRGPT_OK;
-  }
-  // ---- tall kernel: 257 .. 383 rows (the bs = 1 prefill, T = 259) -- all rows x 128 columns per block, weights by LDS-DMA, activations
-  //      straight into the MFMA operand registers.  Split K (floor(CUs / column tiles), >= 8 K tiles each) when the column tiles alone
-  //      leave CUs idle: q/k/v 48 tiles x 5, o_proj / down_proj 32 x 8, gate/up 224 x 1.
-  if (K % 64 == 0 && K >= 512 && M > 256 && M < 384 && SRGPT_KNOB("SRGPT_GEMM_TALL", 1)) {
-    const int cus = srgpt_device_cus();
-    const int tn = cdiv(N, 128), nk = K / 64;
-    int sp = 1;
-    if (ws && tn * 4 < cus * 3) {
-      sp = cus / tn;
-      if (sp > 8) sp = 8;
-      if (sp > nk / 8) sp = nk / 8;
-      while (sp > 1 && (int64_t)sp * M * N * 4 > ws_bytes) --sp;
-      if (sp < 1) sp = 1;
-    }
-    if (sp > 1) {
-      e.partial = reinterpret_cast<float*>(ws);
-      e.tiles_per_split = cdiv(nk, sp);
-      e.splits = cdiv(nk, e.tiles_per_split);
-    }
-    dim3 grid(tn, 1, e.splits);
-#define LT(NW) hipLaunchKernelGGL((gemm_bf16_tall<NW>), grid, dim3(64 * NW), 0, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e)
-    switch (cdiv(M, 32)) {
-      case 9: LT(9); break;
-      case 10: LT(10); break;
-      case 11: LT(11); break;
-      default: LT(12); break;
-    }
-#undef LT
-    SRGPT_LAUNCH_CHECK();
-    if (e.splits > 1) {
-      launch_splitk_reduce<bf16_t>(e, s);
-      SRGPT_LAUNCH_CHECK();
-    }
     return SRGPT_OK;
   }
   // ---- 256 x 256 eight-wave kernel (gemm256.hip); rule calibrated on MI355X measurements (profiles/r02_gemm256_*.txt,

@@ -37,8 +37,7 @@ def _tol(ref, dtype, k=1.0):
                                    # 96-row tiles (1 x 4 waves): single-buffered un-split grid (>= 2 blocks per CU), double-buffered
                                    # split-K, ragged last row tile (259 = 2 x 96 + 67), ragged N, K tail through registers
                                    (259, 28672, 512), (259, 4096, 4096), (1458, 4304, 1152), (97, 130, 200), (288, 640, 64),
-                                   # the tall kernel (round 4: 257 .. 383 rows, all rows x 128 columns per block, A fragments straight
-                                   # from L2): 9 / 10 / 11 / 12 waves, split-K 5 / 8 / none, ragged N, the last wave's rows past M
+                                   # 257 .. 383 rows (prompts a little longer than the benchmark's): split-K 5 / 8 / none, ragged N
                                    (259, 6144, 4096), (300, 1000, 1024), (383, 4096, 512), (257, 128, 2048), (352, 264, 4096),
                                    (320, 4096, 14336)])
 def test_gemm_plain(dtype, M, N, K):
@@ -69,7 +68,7 @@ def test_gemm_strided_a_and_row_modulo_residual(dtype):
     ref = ref.to(dtype).float() + pos.float().repeat(3, 1)
     out = ops.gemm(big.to(DEV)[:, 64:128], w.to(DEV), residual=pos.to(DEV), res_mod=32)
     assert_close(out, ref, _tol(ref, dtype), 0, "strided A + residual row modulo")
-    # the same through the tall kernel (its A fragments are loaded with the caller's row stride)
+    # the same at 300 rows (96-row tiles, split K)
     big = _rand((300, 3 * 1024), dtype, 8)
     w2, pos2 = _rand((200, 1024), dtype, 9, 0.05), _rand((100, 200), dtype, 10)
     ref = (big[:, 1024:2048].float() @ w2.float().T).to(dtype).float() + pos2.float().repeat(3, 1)
