@@ -3,7 +3,7 @@ import json
 import re
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04_final"
 g, p = "gpurun_out/" + tag, "profiles/" + tag
 d = json.loads(open(g + "_bench_default.json").read().strip().splitlines()[-1])
 open(p + "_bench.json", "w").write(json.dumps(d, indent=1) + "\n")
@@ -57,7 +57,7 @@ if gu:
 open(p + "_pmc_fetch.txt", "w").write("\n".join(out) + "\n")
 print("composed", p, "| gate/up trace avg", trace_us, "us | bench", d["value"], "tok/s")
 import os
-for extra in ("_pmc_lds.txt", "_kernel_stats_b4.txt", "_kernel_stats_fp8b8.txt"):
+for extra in ("_pmc_lds.txt", "_kernel_stats_b4.txt", "_kernel_stats_fp8a8b8.txt"):
     if os.path.exists(g + extra):
         hdr2 = {"_pmc_lds.txt": "# rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --max-new-tokens 4 --batch 8 (own pass)\n# conflict share of a kernel = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE\n",
                 "_kernel_stats_b4.txt": "# rocprofv3 --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 4   (BASELINE configs[2] per-GPU shape)\n",

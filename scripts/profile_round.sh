@@ -2,7 +2,7 @@
 # Round profile: kernel trace of the bench command + two separate PMC passes (counters never share a run with trace domains).
 # Usage (on the GPU box, from the repo root): bash scripts/profile_round.sh <tag>   -> gpurun_out/<tag>_*.txt
 set -u
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -28,7 +28,7 @@ rm -rf /tmp/prof_l
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES -d /tmp/prof_l -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --max-new-tokens 4 --batch 8 > /tmp/l.log 2>&1
 python $GRAFT_REPO_ROOT/scripts/pmc_summary.py $(find /tmp/prof_l -name "*.db" | head -1) SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES > $OUT/${TAG}_pmc_lds.txt 2>&1
 # 5. kernel tables of the batched / fp8 configurations (configs[2] and [4] per-GPU shapes)
-for cfgname in "b4:--batch 4" "fp8b8:--weights fp8 --batch 8"; do
+for cfgname in "b4:--preset config2" "fp8a8b8:--preset config4"; do
   nm=${cfgname%%:*}; ar=${cfgname#*:}
   rm -rf /tmp/prof_c
   rocprofv3 --kernel-trace -d /tmp/prof_c -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline $ar > /tmp/c.log 2>&1
