@@ -1,5 +1,7 @@
-"""Soak / race screen: many generate() calls of mixed batch sizes and lengths on one engine; every repeat of a request must
-return bit-identical ids (any race in the graph replay, the DMA-staged GEMM or the wave-private LDS stages shows up here)."""
+"""Soak / race screen: many generate() calls of mixed batch sizes, lengths AND decoding modes on one engine; every repeat of a request
+must return bit-identical ids (any race in the graph replay, the DMA-staged GEMM or the wave-private LDS stages shows up here).
+Round 4: the cases rotate through greedy, device-side sampling (seeded), a stopping criterion (the run-ahead loop discards a step that
+is already in flight) and beam search -- the pooled state switches between its greedy and its sampling graph, beams re-size it."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -32,7 +34,18 @@ n = 0
 order = torch.randint(0, len(cases), (int(sys.argv[2]) if len(sys.argv) > 2 else 60,), generator=g).tolist()
 for k, ci in enumerate(order):
     ids, im, dp, mk, G = cases[ci]
-    out = model.generate(ids, images=im, depths=dp, masks=mk, do_sample=False, max_new_tokens=G, eos_token_id=None).cpu()
+    mode = ["greedy", "sample", "greedy", "criterion", "sample", "greedy", "beam", "greedy"][ci]
+    if mode == "sample":
+        torch.manual_seed(1000 + ci)  # the sampler's Philox seed is drawn from torch's CPU generator
+        kw = dict(do_sample=True, temperature=0.9, top_k=40, top_p=0.95)
+    elif mode == "criterion":
+        kw = dict(do_sample=False, stopping_criteria=[lambda ids_, s_: ids_.shape[1] >= 5])
+    elif mode == "beam":
+        kw = dict(do_sample=False, num_beams=2)
+    else:
+        kw = dict(do_sample=False)
+    out = model.generate(ids, images=im, depths=dp, masks=mk, max_new_tokens=G, eos_token_id=None, **kw).cpu()
+    assert out.shape[1] == (5 if mode == "criterion" else G), (mode, out.shape)
     n += 1
     if ci in ref:
         if not torch.equal(out, ref[ci]):
