@@ -60,6 +60,6 @@ import os
 for extra in ("_pmc_lds.txt", "_kernel_stats_b4.txt", "_kernel_stats_fp8a8b8.txt"):
     if os.path.exists(g + extra):
         hdr2 = {"_pmc_lds.txt": "# rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --max-new-tokens 4 --batch 8 (own pass)\n# conflict share of a kernel = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE\n",
-                "_kernel_stats_b4.txt": "# rocprofv3 --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --batch 4   (BASELINE configs[2] per-GPU shape)\n",
-                "_kernel_stats_fp8b8.txt": "# rocprofv3 --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --weights fp8 --batch 8   (BASELINE configs[4] per-GPU shape)\n"}[extra]
+                "_kernel_stats_b4.txt": "# rocprofv3 --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --preset config2   (BASELINE configs[2] per-GPU shape: 4 requests)\n",
+                "_kernel_stats_fp8a8b8.txt": "# rocprofv3 --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --preset config4   (BASELINE configs[4] per-GPU shape: fp8 weights on the fp8 matrix pipe, 8 requests)\n"}[extra]
         open(p + extra, "w").write(hdr2 + open(g + extra).read())
