@@ -9,9 +9,14 @@ Pinning status: the reference ships no tests or golden vectors (SURVEY.md sectio
 restatement is pinned against *outputs of the reference itself run in the build container*:
 `oracle/make_golden.py` imports the real reference (via `oracle/ref_harness.py`), runs it on seeded
 inputs, asserts this file reproduces every stage, and commits the vectors under tests/golden/.
-The ViT arithmetic and the greedy loop live in third-party `transformers` (pinned ==4.37.2 by the
+The ViT arithmetic and the generation loops live in third-party `transformers` (pinned ==4.37.2 by the
 reference's pyproject.toml:17; 5.15.0 is what is installed here) -- for those two pieces the pin is
 "the reference's call sites executed against the installed transformers".
+Round 4: the LLM (`llama_forward`, `rope_cos_sin`) is additionally pinned against the reference's VENDORED
+llava/train/transformers_replace/models/llama/modeling_llama.py executed on CPU with oracle/flash_attn_cpu.py
+standing in for the flash-attn extension (`make_golden.py vendored` -> tests/golden/vendored_llama_kat.npz:
+max|d| = 0 in fp32 incl. linear RoPE scaling, cache steps beyond max_position_embeddings and the ragged
+varlen branch); what stays restated-from-publication on that side is the flash-attn kernel's arithmetic.
 
 Weight naming = the reference checkpoint layout (llava/model/llava_arch.py:181-250): prefixes
 `llm.` (HF LlamaForCausalLM keys), `vision_tower.vision_tower.vision_model.` (HF SiglipVisionModel
