@@ -193,10 +193,11 @@ def load_tokenizer(model_path: str, cfg: SrgptConfig, sd=None, model_max_length=
     return tokenizer
 
 
-def load_image_processor(model_path: str, cfg: SrgptConfig):
+def load_image_processor(model_path: str, cfg: SrgptConfig, tower_dir: str = None):
     """SiglipImageProcessor for SigLIP towers (siglip_encoder.py:10), CLIPImageProcessor for CLIP towers (clip_encoder.py:11);
-    the built-in processor of the same semantics when transformers cannot build its own (no torchvision in this image)."""
-    vt = os.path.join(model_path, "vision_tower")
+    the built-in processor of the same semantics when transformers cannot build its own (no torchvision in this image).
+    tower_dir: the tower directory itself when it is not `<model_path>/vision_tower` (spatialrgpt_amd/factories.py)."""
+    vt = tower_dir or os.path.join(model_path, "vision_tower")
     pp = os.path.join(vt, "preprocessor_config.json")
     try:
         if cfg.tower == "clip":

@@ -88,7 +88,7 @@ class DecodeState:
 
 class SrgptEngine:
     def __init__(self, cfg: SrgptConfig, state_dict: Dict[str, torch.Tensor], device="cuda", dtype=torch.bfloat16,
-                 rope_positions: int = 0, consume_state_dict: bool = False, llm_weight_format: str = "native"):
+                 rope_positions: int = 0, consume_state_dict: bool = False, llm_weight_format: str = "native", parts=None):
         L.load()  # fail loudly if the HIP extension is missing
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         if self.device.type != "cuda":
@@ -100,7 +100,7 @@ class SrgptEngine:
         if cfg.select_feature not in ("cls_patch", "patch"):
             raise ValueError(f"Unexpected select feature: {cfg.select_feature}")
         self.w = PreparedWeights(cfg, state_dict, self.device, dtype, rope_positions, consume=consume_state_dict,
-                                 llm_weight_format=llm_weight_format)
+                                 llm_weight_format=llm_weight_format, parts=parts)
         self._state: Optional[DecodeState] = None
         self._vit_ws: Optional[torch.Tensor] = None
         self.use_graph = True
@@ -112,6 +112,7 @@ class SrgptEngine:
         """[n,3,S,S] (any float dtype: cast to the engine dtype at the boundary, vision_encoder.py:127) ->
         hidden_states[select_layer] [n, grid^2, C] in the ENGINE dtype; `out_dtype` reproduces the module-level cast back
         to the caller's image dtype (vision_encoder.py:130) for callers that use the tower on its own."""
+        self._need("vit")
         x = images.to(device=self.device, dtype=self.dtype).contiguous()  # vision_encoder.py:127
         n, ch, S, S2 = x.shape
         if ch != 3 or S != self.cfg.image_size or S2 != S:
@@ -127,7 +128,12 @@ class SrgptEngine:
         return out if out_dtype is None or out_dtype == out.dtype else out.to(out_dtype)  # vision_encoder.py:130
 
     # ------------------------------------------------------------------ A2
+    def _need(self, part: str):
+        if part not in self.w.parts:
+            raise RuntimeError(f"this engine was built without its {part!r} component (parts = {self.w.parts})")
+
     def feature_refinement(self, tower: torch.Tensor):
+        self._need("region")
         tower = tower.to(device=self.device, dtype=self.dtype)
         n, HW, Cc = tower.shape
         g = int(HW ** 0.5)
@@ -173,6 +179,7 @@ class SrgptEngine:
         return out
 
     def region_extractor(self, hres, depth_features, masks):
+        self._need("region")
         w = self.w
 
         def connect(pooled, W, b):
@@ -186,6 +193,7 @@ class SrgptEngine:
 
     # ------------------------------------------------------------------ A5
     def mm_projector(self, lres: torch.Tensor) -> torch.Tensor:
+        self._need("projector")
         w = self.w
         lres = lres.to(device=self.device, dtype=self.dtype)
         n = lres.shape[0]
@@ -410,6 +418,7 @@ class SrgptEngine:
         """Cache/workspace for `batch` sequences of T prompt positions + max_new generated ones.  The pooled state serves the
         internal generate() path; `fresh=True` allocates an independent one (a handle returned to the caller as
         `past_key_values` must not be overwritten by the next call -- the reference returns independent caches)."""
+        self._need("llm")
         need_pos = T + max_new
         if need_pos > self.w.rope_len:
             raise ValueError(f"sequence of {need_pos} positions exceeds the RoPE table ({self.w.rope_len})")

@@ -124,7 +124,7 @@ class LlavaLlamaModel:
 
     def __init__(self, config=None, state_dict: Dict[str, torch.Tensor] = None, device="cuda",
                  dtype=torch.bfloat16, tokenizer=None, image_processor=None, rope_positions: int = 0,
-                 consume_state_dict: bool = False, llm_weight_format: str = "native", **hf_kwargs):
+                 consume_state_dict: bool = False, llm_weight_format: str = "native", parts=None, **hf_kwargs):
         self.hf_config = None
         if isinstance(config, LlavaConfig):
             # the reference's construction path: config carries the checkpoint location
@@ -148,7 +148,7 @@ class LlavaLlamaModel:
             raise TypeError("LlavaLlamaModel needs (SrgptConfig, state_dict) or a LlavaLlamaConfig that points at a checkpoint")
         self.config = config
         self.engine = SrgptEngine(config, state_dict, device=device, dtype=dtype, rope_positions=rope_positions,
-                                  consume_state_dict=consume_state_dict, llm_weight_format=llm_weight_format)
+                                  consume_state_dict=consume_state_dict, llm_weight_format=llm_weight_format, parts=parts)
         self.tokenizer = tokenizer
         self.vision_tower = _VisionTower(self.engine, image_processor)
         self.region_extractor = _RegionExtractor(self.engine) if config.enable_region else None

@@ -48,13 +48,25 @@ def rope_tables(cfg: SrgptConfig, n_pos: int, dtype, device):
 class PreparedWeights:
     """Owns the device tensors and the C structs pointing at them."""
 
+    ALL_PARTS = ("vit", "region", "projector", "llm")
+
     def __init__(self, cfg: SrgptConfig, sd: Dict[str, torch.Tensor], device, dtype, rope_positions: int = 0,
-                 consume: bool = False, llm_weight_format: str = "native"):
+                 consume: bool = False, llm_weight_format: str = "native", parts=None):
         """llm_weight_format: "native" (the engine dtype) or "fp8" -- weight-only OCP e4m3fn quantisation of the five
         streamed LLM matrices with one fp32 (power-of-two) scale per output row (BASELINE config 5; bf16 engines only).  The
         fp8 bytes are the ONLY copy of those matrices in HBM: decode streams them (srgpt_gemv_w8), prefill multiplies them
         (srgpt_gemm_w8); `dequantised(name, layer)` rebuilds the bf16 values for checks."""
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        # parts: which components to materialise -- all of them for the model, ONE for the module-level factories
+        # (spatialrgpt_amd/factories.py: the reference's build_vision_tower / build_mm_projector / build_region_extractor /
+        # build_llm_and_tokenizer seams, SURVEY 8b); a missing part's weights are neither read nor required
+        self.parts = tuple(self.ALL_PARTS if parts is None else parts)
+        for p_ in self.parts:
+            if p_ not in self.ALL_PARTS:
+                raise ValueError(f"unknown part {p_!r}")
+        self.vit = self.llm = None
+        self.vocab = 0
+        self.rope_len = 0
         if llm_weight_format not in ("native", "fp8", "fp8_w8a8"):
             raise ValueError(f"unknown llm_weight_format {llm_weight_format!r}")
         # "fp8_w8a8": the same fp8 weights; prefill additionally quantises every GEMM input per token to e4m3 and multiplies on
@@ -74,6 +86,20 @@ class PreparedWeights:
             t = sd.pop(name) if consume else sd[name]
             return t.to(device=self.device, dtype=dtype).contiguous()
 
+        if "vit" in self.parts:
+            self._prepare_vit(cfg, get, code)
+        if "region" in self.parts and cfg.enable_region:
+            self._prepare_region(cfg, get)
+        if "projector" in self.parts:
+            # ---------------- projector (mlp_downsample) ----------------
+            self.mp_ln_w, self.mp_ln_b = get(MP + "1.weight"), get(MP + "1.bias")
+            self.mp_w1, self.mp_b1 = get(MP + "2.weight"), get(MP + "2.bias")
+            self.mp_w2, self.mp_b2 = get(MP + "4.weight"), get(MP + "4.bias")
+        if "llm" in self.parts:
+            self._prepare_llm(cfg, get, code, llm_weight_format, rope_positions)
+
+    def _prepare_vit(self, cfg, get, code):
+        dtype = self.dtype
         # ---------------- vision tower ----------------
         C_, p = cfg.vit_hidden, cfg.patch_size
         kk = 3 * p * p
@@ -129,26 +155,23 @@ class PreparedWeights:
             setattr(vw, k, arr)
         self.vit = vw
 
+    def _prepare_region(self, cfg, get):
         # ---------------- region extractor ----------------
-        if cfg.enable_region:
-            fr = RE + "feature_refinement_module."
+        fr = RE + "feature_refinement_module."
 
-            def deconv_w(name):
-                w = get(name)  # [Cin, Cout, 2, 2]
-                cin, cout = w.shape[0], w.shape[1]
-                return w.permute(2, 3, 1, 0).reshape(4 * cout, cin).contiguous()
+        def deconv_w(name):
+            w = get(name)  # [Cin, Cout, 2, 2]
+            cin, cout = w.shape[0], w.shape[1]
+            return w.permute(2, 3, 1, 0).reshape(4 * cout, cin).contiguous()
 
-            self.dc1_w, self.dc1_b = deconv_w(fr + "0.weight"), get(fr + "0.bias")
-            self.ln2d_w, self.ln2d_b = get(fr + "1.weight"), get(fr + "1.bias")
-            self.dc2_w, self.dc2_b = deconv_w(fr + "3.weight"), get(fr + "3.bias")
-            self.rgb_w, self.rgb_b = get(RE + "rgb_projector.weight"), get(RE + "rgb_projector.bias")
-            self.depth_w, self.depth_b = get(RE + "depth_projector.weight"), get(RE + "depth_projector.bias")
+        self.dc1_w, self.dc1_b = deconv_w(fr + "0.weight"), get(fr + "0.bias")
+        self.ln2d_w, self.ln2d_b = get(fr + "1.weight"), get(fr + "1.bias")
+        self.dc2_w, self.dc2_b = deconv_w(fr + "3.weight"), get(fr + "3.bias")
+        self.rgb_w, self.rgb_b = get(RE + "rgb_projector.weight"), get(RE + "rgb_projector.bias")
+        self.depth_w, self.depth_b = get(RE + "depth_projector.weight"), get(RE + "depth_projector.bias")
 
-        # ---------------- projector (mlp_downsample) ----------------
-        self.mp_ln_w, self.mp_ln_b = get(MP + "1.weight"), get(MP + "1.bias")
-        self.mp_w1, self.mp_b1 = get(MP + "2.weight"), get(MP + "2.bias")
-        self.mp_w2, self.mp_b2 = get(MP + "4.weight"), get(MP + "4.bias")
-
+    def _prepare_llm(self, cfg, get, code, llm_weight_format, rope_positions):
+        dtype = self.dtype
         # ---------------- language model ----------------
         self.embed = get(LM + "model.embed_tokens.weight")
         self.final_norm = get(LM + "model.norm.weight")

@@ -277,3 +277,67 @@ def test_reference_written_checkpoint_reproduces_reference_ids_bit_exactly():
     config.model_dtype = "torch.float32"
     m2 = spatialrgpt_amd.LlavaLlamaModel(config=config, low_cpu_mem_usage=True)
     assert m2.dtype == torch.float32 and torch.equal(m2.generate(ids, **kw).cpu(), want)
+
+
+def test_component_factories_compose_to_the_whole_model_bit_for_bit():
+    """SURVEY 8b "factories": build_vision_tower / build_region_extractor / build_mm_projector / build_llm_and_tokenizer
+    (llava/model/{multimodal_encoder,region_extractor,multimodal_projector,language_model}/builder.py) on the component directories
+    the REFERENCE's save_pretrained wrote (tests/golden/ckpt_tiny/*).  Composed by hand the way llava_arch.py:387-411 composes them,
+    every stage tensor equals the whole model's bit for bit, and the stand-alone LLM's generate(inputs_embeds=...) returns the
+    reference's ids (ckpt_tiny_kat.npz).  Each factory engine holds ONLY its component: the others are refused."""
+    import numpy as np
+
+    from spatialrgpt_amd import load_pretrained_model
+    from spatialrgpt_amd.factories import build_llm_and_tokenizer, build_mm_projector, build_region_extractor, build_vision_tower
+    from tests.util import GOLD
+
+    root = os.path.join(GOLD, "ckpt_tiny")
+    z = np.load(os.path.join(GOLD, "ckpt_tiny_kat.npz"))
+    ids = torch.from_numpy(z["input_ids"]).cuda()
+    images = (torch.from_numpy(z["images_q32"].astype(np.float32)) / 32).cuda()
+    depths = (torch.from_numpy(z["depths_q32"].astype(np.float32)) / 32).expand(-1, 3, -1, -1).contiguous().cuda()
+    masks = [torch.from_numpy(z["masks_u8"][i].astype(np.float32)).cuda() for i in range(z["masks_u8"].shape[0])]
+    want = torch.from_numpy(z["new_ids"])
+    _, whole, _, _ = load_pretrained_model(root, "SpatialRGPT-tiny", dtype=torch.float32)
+    st = {}
+    embeds, _, _ = whole.engine.prepare_inputs(ids, images, depths, masks, None, stages=st)
+
+    cfgns = type("Cfg", (), dict(mm_vision_select_layer=-2, mm_vision_select_feature="cls_patch"))()
+    tower = build_vision_tower(os.path.join(root, "vision_tower"), cfgns, dtype=torch.float32)
+    assert tower.is_loaded and tower.image_processor is not None and cfgns.mm_hidden_size == tower.hidden_size == whole.config.vit_hidden
+    rex = build_region_extractor(os.path.join(root, "region_extractor"), cfgns, dtype=torch.float32)
+    proj = build_mm_projector(os.path.join(root, "mm_projector"), cfgns, dtype=torch.float32)
+    llm, tok = build_llm_and_tokenizer(os.path.join(root, "llm"), cfgns, attn_implementation="flash_attention_2", dtype=torch.float32)
+    assert cfgns.hidden_size == whole.config.hidden and tok is not None
+
+    # llava_arch.py:387-411
+    tower_features = tower(images)
+    depth_features = tower(depths)
+    hres, lres = rex.feature_refinement(tower_features)
+    mask_embeds, depth_embeds = rex(hres, depth_features, masks)
+    image_features = proj(lres)
+    assert torch.equal(tower_features, st["tower_features"]) and torch.equal(depth_features, st["depth_features"])
+    assert torch.equal(hres, st["hres"]) and torch.equal(lres, st["lres"])
+    assert all(torch.equal(a, b) for a, b in zip(mask_embeds, st["mask_embeds"]))
+    assert all(torch.equal(a, b) for a, b in zip(depth_embeds, st["depth_embeds"]))
+    assert torch.equal(image_features, st["image_features"])
+    # the stand-alone LLM on the whole model's spliced embeddings: the reference's ids
+    got = llm.generate(inputs_embeds=embeds, attention_mask=None, do_sample=False, max_new_tokens=want.shape[1], use_cache=True,
+                       eos_token_id=None, pad_token_id=0, min_new_tokens=want.shape[1]).cpu()
+    assert torch.equal(got, want)
+    assert torch.equal(llm.get_input_embeddings()(ids.clamp_min(0)), whole.get_input_embeddings()(ids.clamp_min(0)))
+    # a component engine refuses what it does not hold
+    with pytest.raises(RuntimeError):
+        rex._eng.mm_projector(lres)
+    with pytest.raises(RuntimeError):
+        proj._eng.vit(images)
+    # a live module's state dict instead of a directory (how ONE component of a running reference model is replaced)
+    from safetensors.torch import load_file
+
+    sd = load_file(os.path.join(root, "region_extractor", "model.safetensors"))
+    rex2 = build_region_extractor("regiongpt", cfgns, state_dict=sd, dtype=torch.float32)
+    assert all(torch.equal(a, b) for a, b in zip(rex2(hres, depth_features, masks)[0], mask_embeds))
+    with pytest.raises(ValueError):
+        build_region_extractor("regiongpt", cfgns)  # a fresh random component is the training path
+    with pytest.raises(ValueError):
+        build_mm_projector("linear", cfgns, state_dict=sd)
