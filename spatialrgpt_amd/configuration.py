@@ -56,6 +56,47 @@ class LlavaLlamaConfig(LlavaConfig):
     model_type = "llava_llama"
 
 
+class MultimodalProjectorConfig(PretrainedConfig):
+    """multimodal_projector/base_projector.py:56-62 (`<ckpt>/mm_projector/config.json`)"""
+    model_type = "v2l_projector"
+    mm_projector_type: Optional[str] = None
+
+
+class RegionExtractorConfig(PretrainedConfig):
+    """region_extractor/base_extractor.py:104-110 (`<ckpt>/region_extractor/config.json`)"""
+    model_type = "region_extractor"
+    region_extractor_type: Optional[str] = None
+
+
+class MultimodalProjector:
+    """`AutoModel.from_pretrained(<ckpt>/mm_projector)` / `MultimodalProjector.from_pretrained(path, config)` (what the reference's
+    build_mm_projector calls, multimodal_projector/builder.py:17-21) -> the HIP-backed projector of spatialrgpt_amd.factories."""
+    config_class = MultimodalProjectorConfig
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *args, config=None, torch_dtype=None, **kwargs):
+        import torch
+
+        from .factories import build_mm_projector
+
+        dt = torch_dtype if torch_dtype in (torch.bfloat16, torch.float32) else torch.bfloat16
+        return build_mm_projector(str(pretrained_model_name_or_path), config, dtype=dt)
+
+
+class RegionExtractor:
+    """the same for `<ckpt>/region_extractor` (region_extractor/builder.py:18-22)"""
+    config_class = RegionExtractorConfig
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *args, config=None, torch_dtype=None, **kwargs):
+        import torch
+
+        from .factories import build_region_extractor
+
+        dt = torch_dtype if torch_dtype in (torch.bfloat16, torch.float32) else torch.bfloat16
+        return build_region_extractor(str(pretrained_model_name_or_path), config, dtype=dt)
+
+
 def register_auto_classes(model_cls) -> None:
     """AutoConfig.register("llava_llama", LlavaLlamaConfig); AutoModel.register(LlavaLlamaConfig, LlavaLlamaModel)
     (llava_llama.py:216-217).  If another package in the process (e.g. the reference itself) already owns the
@@ -70,3 +111,11 @@ def register_auto_classes(model_cls) -> None:
         AutoModel.register(LlavaLlamaConfig, model_cls)
     except ValueError:
         pass
+    # base_projector.py:97-98, base_extractor.py:176-177: the component directories load through the Auto classes too
+    for name, cfg_cls, mod_cls in (("v2l_projector", MultimodalProjectorConfig, MultimodalProjector),
+                                   ("region_extractor", RegionExtractorConfig, RegionExtractor)):
+        try:
+            AutoConfig.register(name, cfg_cls)
+            AutoModel.register(cfg_cls, mod_cls)
+        except ValueError:
+            pass

@@ -341,3 +341,10 @@ def test_component_factories_compose_to_the_whole_model_bit_for_bit():
         build_region_extractor("regiongpt", cfgns)  # a fresh random component is the training path
     with pytest.raises(ValueError):
         build_mm_projector("linear", cfgns, state_dict=sd)
+    # the Auto-class route of the component directories (base_projector.py:97-98, base_extractor.py:176-177)
+    from transformers import AutoModel
+
+    proj2 = AutoModel.from_pretrained(os.path.join(root, "mm_projector"), torch_dtype=torch.float32)
+    assert torch.equal(proj2(lres), image_features)
+    rex3 = AutoModel.from_pretrained(os.path.join(root, "region_extractor"), torch_dtype=torch.float32)
+    assert torch.equal(rex3.feature_refinement(tower_features)[0], hres)

@@ -227,3 +227,21 @@ def test_loader_reads_the_checkpoint_the_reference_writer_wrote():
     assert _rope({"rope_theta": 10000.0, "rope_scaling": {"type": "linear", "factor": 4.0}}) == (10000.0, 4.0)
     assert _rope({"rope_parameters": {"rope_theta": 500000.0, "rope_type": "default"}}) == (500000.0, 1.0)
     assert _rope({}) == (10000.0, 1.0)
+
+
+def test_component_configs_load_through_the_auto_classes():
+    """base_projector.py:97-98 / base_extractor.py:176-177: `AutoConfig.register("v2l_projector", ...)`,
+    `AutoConfig.register("region_extractor", ...)` -- the component directories the reference's save_pretrained wrote resolve to this
+    package's config classes (their AutoModel entries build the HIP-backed components: tests/test_gpu_loader.py)."""
+    import os
+
+    from transformers import AutoConfig
+
+    import spatialrgpt_amd.model  # noqa: F401  (registration happens at import, like the reference)
+    from spatialrgpt_amd.configuration import MultimodalProjectorConfig, RegionExtractorConfig
+    from tests.util import GOLD
+
+    pc = AutoConfig.from_pretrained(os.path.join(GOLD, "ckpt_tiny", "mm_projector"))
+    rc = AutoConfig.from_pretrained(os.path.join(GOLD, "ckpt_tiny", "region_extractor"))
+    assert isinstance(pc, MultimodalProjectorConfig) and pc.mm_projector_type == "mlp_downsample"
+    assert isinstance(rc, RegionExtractorConfig) and rc.region_extractor_type == "regiongpt"
