@@ -9,7 +9,7 @@ from spatialrgpt_amd import ops
 lib = C.CDLL(_lib.LIB_PATH)
 names = ["entry", "first rows requested", "denominators", "weights in LDS", "rows consumed (FMA)", "in-block reduce", "partials issued",
          "stores drained + barrier", "ticket drawn"]
-for fw in (108, 27):
+for fw in (108, 54, 27):
     feat = torch.randn((fw * fw, 1152), device="cuda").to(torch.bfloat16)
     masks = (torch.rand((8, 384, 384), device="cuda") > 0.5).to(torch.bfloat16)
     for _ in range(5):

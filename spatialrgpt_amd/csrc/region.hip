@@ -275,6 +275,170 @@ __global__ __launch_bounds__(256, MM <= 8 ? 3 : 2) void region_pool_kernel(const
   if (tid == 0) __hip_atomic_store(tickets + cslab, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: the pooling launch on the matrix pipe (bf16 features).  out[16 masks][C] = Wn[16][L] . F[L][C] is a skinny GEMM whose
+// contraction runs over POSITIONS -- the strided axis of the channels-last map -- so the B operand of v_mfma_f32_16x16x32_bf16 (lane
+// (channel, k group) holds 8 consecutive positions of ONE channel) needs a transpose.  A wave streams 32 positions x 64 channels
+// per chunk (4 KB, four coalesced 8 x 128-byte loads), parks the chunk row-major in a PRIVATE 4.5-KB LDS region (row stride 144 B)
+// and reads its fragments back with the transposing LDS read (ds_read_b64_tr_b16: a 16-lane group addresses a [4 positions] x
+// [16 channels] block, 8 bytes per lane, and every lane receives one channel's 4 positions -- two reads per fragment).  The A
+// operand -- the slab's normalised weights rnd(v / denorm), exact in bf16 -- comes from the block's weight array (row stride
+// ROWS + 16 elements: conflict-free ds_read_b128).  Four accumulators (16 masks x 16 channels each) per wave, no cross-lane
+// reduction, 16 masks for the price of 8.
+// Requests go out in the order their consumers run (mask sums, the slab's resampled values, then ALL feature rows of the wave):
+// loads return in order, so the prologue waits for the two small sets only while the features stream in behind them.  Denominators
+// are summed per thread (16 threads per mask, every one of them the same slab order: no exchange, no barrier).
+// Partial publication, arrival ticket and the slab-order final sum are the VALU kernel's; the VALU kernel stays for fp32 features
+// (the 2e-6 KATs).  108 x 108 x 1152, 8 / 16 masks: 18.6 / 31.9 us -> 11.2 / 11.3 us (profiles/r04_region_pooling.txt, which also
+// holds the ablations: without the ticket + last-arriver tail 7.8 us, without the feature loads 11.3 us -- the three dependent
+// memory round trips of the deterministic cross-block sum, not the 26.9-MB stream, are what is left).
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int CH>  // 32-position chunks per wave: a block owns 4 * CH * 32 positions x 64 channels
+__global__ __launch_bounds__(256, 2) void region_pool_mfma_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ v,
+                                                                  const float* __restrict__ psum, int n_psum,
+                                                                  float* __restrict__ partial, int* __restrict__ tickets,
+                                                                  bf16_t* __restrict__ out, int M, int L, int C) {
+  constexpr int ROWS = 4 * CH * 32;
+  constexpr int WLD = ROWS + 16;  // weight row stride (elements): = 16 mod 32 -> the 16-lane groups of ds_read_b128 cover all banks
+  constexpr int TLD = 72;         // transposed-staging row stride (elements) = 144 bytes
+  constexpr int CW = 64;
+  constexpr int FB = 24;  // partials the last arriver keeps in flight: the 23 row slabs of 108 x 108 at CH = 4 in one round trip
+  __shared__ __attribute__((aligned(16))) bf16_t wlds[16 * WLD];
+  __shared__ __attribute__((aligned(16))) bf16_t tlds[4][32 * TLD];
+  __shared__ __attribute__((aligned(16))) float red[4][16][CW];
+  __shared__ int last;
+  const int slab = blockIdx.y, l0 = slab * ROWS, nslab = gridDim.y, cslab = blockIdx.x, c0 = cslab * CW;
+  const int nrows = min(ROWS, L - l0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SRGPT_TUNING_KNOBS
+  int stamp_base = (blockIdx.x == 0 && blockIdx.y == 0) ? 0 : -1;
+#endif
+  RP_STAMP(0);
+  // ---- requests in the order their consumers run: mask sums, the slab's resampled values, then every feature row of the wave.
+  // Loads return in order, so the prologue waits only for the two small sets while the features stream in behind them.
+  const int wm = tid >> 4, wr = tid & 15, wmc = min(wm, M - 1);  // weights: 16 threads per mask, positions wr + 16 j
+  float ps[16], vv[8 * CH];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) ps[q] = psum[(size_t)wmc * n_psum + min(q, n_psum - 1)];
+#pragma unroll
+  for (int j = 0; j < 8 * CH; ++j) vv[j] = v[(size_t)wmc * L + min(l0 + wr + 16 * j, L - 1)];
+  const int lrow = lane >> 3, cch = min(c0 + (lane & 7) * 8, C - 8);
+  u32x4 f[CH][4];
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = min(l0 + (wave * CH + ch) * 32 + 8 * i + lrow, L - 1);
+      f[ch][i] = *reinterpret_cast<const u32x4*>(feat + (size_t)r * C + cch);
+    }
+  RP_STAMP(1);
+  // ---- mask.sum() + 1e-8 in the feature dtype: the psum slabs in slab order (every thread of the mask's group, no exchange) ----
+  float sden = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+    if (q < n_psum) sden += ps[q];
+  for (int i0 = 16; i0 < n_psum; i0 += 16) {  // maps beyond 128 x 128
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ps[q] = psum[(size_t)wmc * n_psum + min(i0 + q, n_psum - 1)];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (i0 + q < n_psum) sden += ps[q];
+  }
+  const float den = rnd<bf16_t>(rnd<bf16_t>(sden) + 1e-8f);
+  RP_STAMP(2);
+  // ---- the slab's normalised weights rnd(v / denorm), bf16-exact; masks past M and rows past the slab weigh 0 ----
+#pragma unroll
+  for (int j = 0; j < 8 * CH; ++j) {
+    const int r = wr + 16 * j;
+    wlds[wm * WLD + r] = (bf16_t)((wm < M && r < nrows) ? rnd<bf16_t>(vv[j] / den) : 0.f);
+  }
+  __syncthreads();
+  RP_STAMP(3);
+  // ---- main: per chunk, park row-major, transpose-read the B fragments (ds_read_b64_tr_b16: a 16-lane group reads a
+  // [4 positions][16 channels] block and every lane receives one channel's 4 positions), four MFMAs ----
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16_t* tl = tlds[wave];
+  const int n16 = lane & 15, g4 = lane >> 4;
+  const bf16_t* trp = tl + (8 * g4 + (n16 >> 2)) * TLD + 4 * (n16 & 3);
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(tl + (8 * i + lrow) * TLD + (lane & 7) * 8) = f[ch][i];
+    __builtin_amdgcn_wave_barrier();
+    const bf16x8 af = *reinterpret_cast<const bf16x8*>(wlds + n16 * WLD + (wave * CH + ch) * 32 + g4 * 8);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(trp + 16 * t));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(trp + 16 * t + 4 * TLD));
+      const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, both), acc[t], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  RP_STAMP(4);
+  // ---- the four waves' partial sums, fixed wave order ----
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[wave][4 * g4 + q][16 * t + n16] = acc[t][q];
+  __syncthreads();
+  RP_STAMP(5);
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(partial, 0, (int)((size_t)nslab * M * C * sizeof(float)), 0x00020000);
+  {
+    const int m = tid >> 4, c = 4 * (tid & 15);
+    if (m < M && c0 + c < C) {  // C % 8 == 0: a group of 4 channels is entirely in or out
+      u32x4 t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[q] = __float_as_uint(((red[0][m][c + q] + red[1][m][c + q]) + red[2][m][c + q]) + red[3][m][c + q]);
+      __builtin_amdgcn_raw_buffer_store_b128(t, prs, (int)((((size_t)slab * M + m) * C + c0 + c) * sizeof(float)), 0, 16);
+    }
+  }
+  RP_STAMP(6);
+  // ---- arrival ticket of the channel slab; the last arriver sums the row slabs in slab order and stores ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  RP_STAMP(7);
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(tickets + cslab, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (t == nslab - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  RP_STAMP(8);
+  if (!last) return;
+#ifdef SRGPT_TUNING_KNOBS
+  if (cslab == 0) stamp_base = 16;
+#endif
+  RP_STAMP(0);
+  {
+    const int m = tid >> 4, c = 4 * (tid & 15);
+    if (m < M && c0 + c < C) {
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < nslab; s0 += FB) {
+        u32x4 pv[FB];
+#pragma unroll
+        for (int q = 0; q < FB; ++q)
+          pv[q] = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)((((size_t)min(s0 + q, nslab - 1) * M + m) * C + c0 + c) * sizeof(float)),
+                                                        0, 16);
+#pragma unroll
+        for (int q = 0; q < FB; ++q)
+          if (s0 + q < nslab) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] += __uint_as_float(pv[q][e]);
+          }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[(size_t)m * C + c0 + c + e] = (bf16_t)t[e];
+    }
+  }
+  RP_STAMP(1);
+  if (tid == 0) __hip_atomic_store(tickets + cslab, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // AdaptiveAvgPool2d(out_w) on a channels-last [n, in_w, in_w, C] map -> [n, out_w*out_w, C]
 template <typename T>
 __global__ void avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int in_w, int out_w, int C) {
@@ -374,7 +538,8 @@ static RegionWs region_ws(int M, int fw, int C) {
   r.v = 0;
   r.psum = r.v + (size_t)M * L;
   r.partial = (r.psum + (size_t)M * r.n_psum + 3) & ~(size_t)3;  // 16-byte pieces
-  r.tickets = r.partial + (size_t)r.nslab * M * C;
+  const size_t nslab_mfma = (L + 127) / 128;  // the MFMA pooling kernel's smallest row slab (one 32-position chunk per wave)
+  r.tickets = r.partial + (nslab_mfma > (size_t)r.nslab ? nslab_mfma : (size_t)r.nslab) * M * C;
   r.total = r.tickets + (size_t)r.ncslab_max;
   return r;
 }
@@ -420,7 +585,20 @@ static int region_pool_impl(const void* feat, const void* masks, void* out, floa
     if (raw) RW(bf16_t, unsigned char, true);
     else if (mask_dtype == SRGPT_BF16) RW(bf16_t, bf16_t, false);
     else RW(bf16_t, float, false);
-    if (M <= 8) RP(bf16_t, 8); else RP(bf16_t, 16);
+    const int mode = SRGPT_KNOB("SRGPT_REGION_MFMA", 3);  // tuning build: 0 = the VALU kernel, 1 / 2 / 4 = that many chunks per wave
+    if (mode == 0) {
+      if (M <= 8) RP(bf16_t, 8); else RP(bf16_t, 16);
+    } else {
+      // chunks per wave by map size: 4 (512 positions per block: 23 row slabs x 18 channel slabs at 108^2 x 1152) / 2 / 1 --
+      // measured per size in profiles/r04_region_pooling.txt (108^2: 26.3 / 15.2 / 11.2 us at 1 / 2 / 4; 27^2: 5.2 / 6.0 / 7.5)
+      const int ch = (mode == 1 || mode == 2 || mode == 4) ? mode : (L >= 8192 ? 4 : (L >= 2048 ? 2 : 1));
+      const dim3 mgrid(ncslab, cdiv(L, 4 * ch * 32));
+#define RPM(CHV)                                                                                                              \
+  hipLaunchKernelGGL((region_pool_mfma_kernel<CHV>), mgrid, dim3(256), 0, s, (const bf16_t*)feat, v, psum, lay.n_psum, partial, \
+                     tickets, (bf16_t*)out, M, L, C)
+      if (ch == 4) RPM(4); else if (ch == 2) RPM(2); else RPM(1);
+#undef RPM
+    }
   } else {
     if (raw) RW(float, unsigned char, true);
     else if (mask_dtype == SRGPT_BF16) RW(float, bf16_t, false);

@@ -408,7 +408,8 @@ def test_region_pool_golden_kats():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("M,S,fw,C", [(8, 384, 108, 1152), (16, 336, 108, 256), (3, 384, 27, 1152), (17, 96, 24, 64)])
+@pytest.mark.parametrize("M,S,fw,C", [(8, 384, 108, 1152), (16, 336, 108, 256), (3, 384, 27, 1152), (17, 96, 24, 64),
+                                      (1, 96, 27, 72), (5, 256, 64, 200), (2, 192, 48, 1096)])  # channel counts off the 64-wide slab, one mask
 def test_region_pool_true_shape_vs_oracle(dtype, M, S, fw, C):
     from oracle import srgpt_oracle as so
     ops, L = _ops()
