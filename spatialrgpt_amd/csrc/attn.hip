@@ -1,9 +1,6 @@
 // Attention kernels.
-//  1. flash_bf16_kernel  -- prefill / ViT: MFMA (v_mfma_f32_16x16x32_bf16) flash attention, online fp32
-//     softmax.  Both products are issued "swapped" (S^T = K Q^T, O^T = V^T P^T) so the softmax row of a
-//     query lives in ONE lane column (col = lane & 15): row max/sum need two cross-lane steps, the
-//     rescale factor is lane-local, and P never leaves registers -- the PV contraction simply runs
-//     over the keys in the order the QK^T accumulator already holds them.
+//  1. flash_bf16_kernel  -- prefill / ViT: MFMA flash attention, in flash.hip (its own translation unit: it is compiled with
+//     MFMA accumulators in arch VGPRs, this file is not); launched from srgpt_attention below.
 //  2. simple_attn_kernel -- one wave per (query, head); any dtype / head_dim; fp32 parity path.
 //  3. decode_split/combine -- single new token against the static KV cache, flash-decoding split over
 //     keys, fused RoPE of the new q/k and cache append.  HBM/latency bound.
@@ -12,191 +9,9 @@
 #include <type_traits>
 
 #include "common.h"
+#include "flash.h"
 
 namespace {
-
-// ================================================================================================
-// 1. MFMA flash attention (bf16)
-// ================================================================================================
-constexpr int QBLK = 64, KVBLK = 64, VT_LD = 68;  // VT_LD: padded key stride of the transposed V tile
-
-struct AttnArgs {
-  const bf16_t *q, *k, *v;
-  bf16_t* o;
-  int Tq, Tk, Hq, Hkv, D;
-  int64_t q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs;
-  float scale;
-  const int* kv_len;
-};
-
-template <int HDP, bool CAUSAL>
-__global__ __launch_bounds__(256) void flash_bf16_kernel(AttnArgs a) {
-  constexpr int NS = HDP / 8;                 // 16-byte slots per K row
-  constexpr int SWM = (NS % 8 == 0) ? 7 : 3;  // swizzle mask (keeps a slot inside its aligned group)
-  constexpr int NKS = HDP / 32;               // k-steps of QK^T
-  constexpr int ND = HDP / 16;                // 16-wide d sub-tiles of the output
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[KVBLK * HDP];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[HDP * VT_LD];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QBLK;
-  const int hk = h / (a.Hq / a.Hkv);
-  const int klen = a.kv_len ? min(a.kv_len[b], a.Tk) : a.Tk;
-  const int qrow = q0 + wave * 16 + lq;  // query row owned by this lane column
-  const int coff = a.Tk - a.Tq;          // causal offset: key s visible iff s <= t + coff
-
-  // Q fragments (B operand of S^T = K Q^T): lane (n = q, kgroup g) holds Q[q][ks*32 + 8g .. +8]
-  bf16x8 qf[NKS];
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    const int d = ks * 32 + g * 8;
-    if (qrow < a.Tq && d < a.D)
-      qf[ks] = *reinterpret_cast<const bf16x8*>(a.q + b * a.q_bs + (int64_t)qrow * a.q_ts + h * a.q_hs + d);
-    else
-#pragma unroll
-      for (int i = 0; i < 8; ++i) qf[ks][i] = (bf16_t)0.f;
-  }
-
-  f32x4 o[ND];
-#pragma unroll
-  for (int i = 0; i < ND; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, l = 0.f;
-
-  int kend = klen;
-  if (CAUSAL) kend = min(kend, q0 + QBLK + coff);  // keys beyond the last query of the block are masked
-  const bf16_t* kb = a.k + b * a.k_bs + hk * a.k_hs;
-  const bf16_t* vb = a.v + b * a.v_bs + hk * a.v_hs;
-
-  // The K / V rows of tile t + 1 are requested (into registers) before tile t is multiplied: without that every tile paid a
-  // full memory latency between two barriers (12 tiles per ViT head: more than half of the kernel).  The loads are
-  // unconditional with clamped addresses -- rows / columns outside the problem are zeroed when the registers go to LDS -- so the
-  // compiler can count them instead of draining the queue.
-  constexpr int NLD = NS / 4;  // 16-byte loads per thread and operand for one tile
-  u32x4 kreg[NLD], vreg[NLD];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int idx = tid + 256 * i;
-      const int key = idx / NS, c = idx - key * NS;
-      kreg[i] = *reinterpret_cast<const u32x4*>(kb + (int64_t)min(k0 + key, klen - 1) * a.k_ts + (c * 8 < a.D ? c * 8 : 0));
-      const int vkey = (idx & 15) | (((idx >> 6) & 3) << 4);
-      const int vc = ((idx >> 4) & 3) | ((idx >> 8) << 2);
-      vreg[i] = *reinterpret_cast<const u32x4*>(vb + (int64_t)min(k0 + vkey, klen - 1) * a.v_ts + (vc * 8 < a.D ? vc * 8 : 0));
-    }
-  };
-  if (kend > 0) fetch(0);
-
-  for (int k0 = 0; k0 < kend; k0 += KVBLK) {
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage K (row-major, swizzled slots) ----
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int idx = tid + 256 * i;
-      const int key = idx / NS, c = idx - key * NS;
-      u32x4 val = kreg[i];
-      if (!(k0 + key < klen && c * 8 < a.D)) val = u32x4{0, 0, 0, 0};
-      *reinterpret_cast<u32x4*>(Ks + key * HDP + ((c ^ (key & SWM)) << 3)) = val;
-    }
-    // ---- stage V transposed: Vt[d][key] ----
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int idx = tid + 256 * i;
-      const int key = (idx & 15) | (((idx >> 6) & 3) << 4);
-      const int c = ((idx >> 4) & 3) | ((idx >> 8) << 2);
-      u32x4 raw = vreg[i];
-      if (!(k0 + key < klen && c * 8 < a.D)) raw = u32x4{0, 0, 0, 0};
-      const bf16x8 val = __builtin_bit_cast(bf16x8, raw);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VT_LD + key] = val[j];
-    }
-    __syncthreads();
-    fetch(k0 + KVBLK);  // next tile (the one past the last re-reads valid rows and is never used)
-
-    // ---- S^T = K Q^T : acc[s][r] = score(key = k0 + 16 s + 4 g + r, query = qrow) ----
-    float p[4][4];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const int key = 16 * s + lq;  // A-operand row of this lane
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + key * HDP + (((ks * 4 + g) ^ (key & SWM)) << 3));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kidx = k0 + 16 * s + 4 * g + r;
-        bool ok = kidx < klen;
-        if (CAUSAL) ok = ok && (kidx <= qrow + coff);
-        const float sv = ok ? acc[r] * a.scale : -INFINITY;
-        p[s][r] = sv;
-        mx = fmaxf(mx, sv);
-      }
-    }
-    // over the four 16-lane rows (the 4 g groups of a query column): v_permlane16/32_swap, not ds_bpermute (common.h)
-    mx = rows_pair(mx, [](float a, float b) { return fmaxf(a, b); });
-    mx = halves_pair(mx, [](float a, float b) { return fmaxf(a, b); });
-    const float m_new = fmaxf(m, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __expf(m - m_use);  // m = -inf -> 0
-    float rs = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        p[s][r] = __expf(p[s][r] - m_use);
-        rs += p[s][r];
-      }
-    rs = rows_pair(rs, [](float a, float b) { return a + b; });
-    rs = halves_pair(rs, [](float a, float b) { return a + b; });
-    l = l * alpha + rs;
-    m = m_new;
-#pragma unroll
-    for (int i = 0; i < ND; ++i) o[i] *= alpha;
-
-    // ---- O^T += V^T P^T ; contraction index 8g+i <-> key 32j + 4g + i (i<4), 32j + 16 + 4g + (i-4) ----
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bf16x8 pf;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pf[r] = (bf16_t)p[2 * j][r];
-        pf[4 + r] = (bf16_t)p[2 * j + 1][r];
-      }
-#pragma unroll
-      for (int ds = 0; ds < ND; ++ds) {
-        const bf16_t* vrow = Vt + (ds * 16 + lq) * VT_LD + 32 * j + 4 * g;
-        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
-        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 16);
-        bf16x8 vf;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          vf[r] = lo[r];
-          vf[4 + r] = hi[r];
-        }
-        o[ds] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[ds], 0, 0, 0);
-      }
-    }
-  }
-
-  // ---- epilogue: O[b, q, h, d], d = 16 ds + 4 g + r ----
-  if (qrow < a.Tq) {
-    const float inv = l > 0.f ? 1.f / l : 0.f;
-    bf16_t* orow = a.o + (((int64_t)b * a.Tq + qrow) * a.Hq + h) * a.D;
-#pragma unroll
-    for (int ds = 0; ds < ND; ++ds) {
-      const int d = ds * 16 + 4 * g;
-      if (d < a.D) {  // D % 8 == 0 -> a group of 4 is entirely in or out
-        bf16x4 w;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = (bf16_t)(o[ds][r] * inv);
-        *reinterpret_cast<bf16x4*>(orow + d) = w;
-      }
-    }
-  }
-}
 
 // ================================================================================================
 // 2. simple attention: one wave per (query row, head)
@@ -1006,23 +821,13 @@ extern "C" int srgpt_attention(const void* q, const void* k, const void* v, void
                       k_hs % 8 == 0 && k_bs % 8 == 0 && v_ts % 8 == 0 && v_hs % 8 == 0 && v_bs % 8 == 0 &&
                       ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
                       ((uintptr_t)o % 8 == 0);
-  if (dtype == SRGPT_BF16 && vec_ok) {
+  // the MFMA kernel takes the row maximum before scaling (scale > 0) and addresses a (batch, head) slice with 32-bit byte offsets;
+  // anything else goes to the one-wave-per-row kernel
+  const int64_t span = ((int64_t)Tk + 4 * 64) * (k_ts > v_ts ? k_ts : v_ts) * 2;
+  if (dtype == SRGPT_BF16 && vec_ok && scale > 0.f && span < srgpt_flash_slice_span_limit()) {
     AttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, Tq, Tk, Hq, Hkv, D,
                q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, scale, kv_len};
-    dim3 grid(cdiv(Tq, QBLK), Hq, B);
-    const int hdp = (D + 31) / 32 * 32;
-#define LF(H)                                                                                  \
-  if (causal)                                                                                  \
-    hipLaunchKernelGGL((flash_bf16_kernel<H, true>), grid, dim3(256), 0, s, a);                \
-  else                                                                                         \
-    hipLaunchKernelGGL((flash_bf16_kernel<H, false>), grid, dim3(256), 0, s, a)
-    switch (hdp) {
-      case 32: LF(32); break;
-      case 64: LF(64); break;
-      case 96: LF(96); break;
-      default: LF(128); break;
-    }
-#undef LF
+    srgpt_flash_bf16_launch(a, B, causal != 0, s);
   } else if (dtype == SRGPT_BF16) {
     hipLaunchKernelGGL(simple_attn_kernel<bf16_t>, dim3(Tq, Hq, B), dim3(64), 0, s, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, (bf16_t*)o, Tq, Tk, Hq, Hkv, D, q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts,
