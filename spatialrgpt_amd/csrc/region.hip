@@ -527,8 +527,12 @@ __global__ void vit_assemble_cls_kernel(const T* __restrict__ patches, const T* 
 // workspace layout (floats): v [M, L] | psum [M, ceil(L / 1024)] | partial [row slabs, M, C] | tickets (ints) [channel slabs]
 struct RegionWs {
   size_t v, psum, partial, tickets, total;
-  int n_psum, nslab, ncslab_max;
+  int n_psum, nslab, nslab_cap, ncslab_max;
 };
+// 32-position chunks per wave of region_pool_mfma_kernel by map size: 4 (512 positions per block: 23 row slabs x 18 channel slabs at
+// 108^2 x 1152) / 2 / 1 -- measured per size in profiles/r04_region_pooling.txt (108^2: 26.3 / 15.2 / 11.2 us at 1 / 2 / 4;
+// 27^2: 5.2 / 6.0 / 7.5)
+static inline int region_mfma_chunks(size_t L) { return L >= 8192 ? 4 : (L >= 2048 ? 2 : 1); }
 static RegionWs region_ws(int M, int fw, int C) {
   RegionWs r;
   const size_t L = (size_t)fw * fw;
@@ -538,8 +542,9 @@ static RegionWs region_ws(int M, int fw, int C) {
   r.v = 0;
   r.psum = r.v + (size_t)M * L;
   r.partial = (r.psum + (size_t)M * r.n_psum + 3) & ~(size_t)3;  // 16-byte pieces
-  const size_t nslab_mfma = (L + 127) / 128;  // the MFMA pooling kernel's smallest row slab (one 32-position chunk per wave)
-  r.tickets = r.partial + (nslab_mfma > (size_t)r.nslab ? nslab_mfma : (size_t)r.nslab) * M * C;
+  const size_t nslab_mfma = (L + 128 * region_mfma_chunks(L) - 1) / (128 * region_mfma_chunks(L));  // row slabs of the MFMA pooling kernel
+  r.nslab_cap = (int)(nslab_mfma > (size_t)r.nslab ? nslab_mfma : (size_t)r.nslab);
+  r.tickets = r.partial + (size_t)r.nslab_cap * M * C;
   r.total = r.tickets + (size_t)r.ncslab_max;
   return r;
 }
@@ -589,9 +594,8 @@ static int region_pool_impl(const void* feat, const void* masks, void* out, floa
     if (mode == 0) {
       if (M <= 8) RP(bf16_t, 8); else RP(bf16_t, 16);
     } else {
-      // chunks per wave by map size: 4 (512 positions per block: 23 row slabs x 18 channel slabs at 108^2 x 1152) / 2 / 1 --
-      // measured per size in profiles/r04_region_pooling.txt (108^2: 26.3 / 15.2 / 11.2 us at 1 / 2 / 4; 27^2: 5.2 / 6.0 / 7.5)
-      const int ch = (mode == 1 || mode == 2 || mode == 4) ? mode : (L >= 8192 ? 4 : (L >= 2048 ? 2 : 1));
+      int ch = region_mfma_chunks((size_t)L);
+      if ((mode == 1 || mode == 2 || mode == 4) && cdiv(L, 128 * mode) <= lay.nslab_cap) ch = mode;  // forced (tuning build), if the partials fit
       const dim3 mgrid(ncslab, cdiv(L, 4 * ch * 32));
 #define RPM(CHV)                                                                                                              \
   hipLaunchKernelGGL((region_pool_mfma_kernel<CHV>), mgrid, dim3(256), 0, s, (const bf16_t*)feat, v, psum, lay.n_psum, partial, \
