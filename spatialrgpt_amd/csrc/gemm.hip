@@ -13,6 +13,7 @@
 #include "gemm_epilogue.h"
 
 int srgpt_gemm256_launch(const void* A, const void* W, int K, int lda, const Epilogue& e, hipStream_t s);  // gemm256.hip
+int srgpt_gemm288_launch(const void* A, const void* W, int K, int lda, const Epilogue& e, hipStream_t s);  // gemm288.hip
 
 namespace {
 
@@ -493,6 +494,47 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
     hipLaunchKernelGGL(gemm_f32_simple, grid, dim3(256), 0, s, (const float*)A, (const float*)W, K, lda, e);
     SRGPT_LAUNCH_CHECK();
     return SRGPT_OK;
+  }
+  // ---- 288 x 128 whole-M kernel (gemm288.hip) for the bs = 1 prefill products (224 < M <= 272): W crosses the global -> LDS path
+  //      once, requests three K tiles deep.  Column tiles x K splits should come to about one block per CU.
+  {
+    const int cus = srgpt_device_cus();
+    const int nk = K / 64;
+    const int gx = cdiv(N, 128);
+    const int mode = SRGPT_KNOB("SRGPT_GEMM_288", 1);  // tuning build: 0 = never, 2 = for any M <= 272, > 2 = forced split count
+    // measured at M = 259 (profiles/r04_gemm288.txt): gate/up 106.5 -> 96.5 us, down 64.8 -> 53.8; q/k/v 33.8 vs 33.6 and o 27.5 vs
+    // 29.2 stay on the small tiles (too few K tiles per block once K is split for 256 CUs: three of them are pipeline fill)
+    bool use288 = mode != 0 && K % 64 == 0 && nk >= 4 &&
+                  ((M > 224 && M <= 272 && (int64_t)N * K >= (int64_t)40 << 20) || (mode >= 2 && M <= 272));
+    int sp = 1;
+    if (use288) {
+      if (gx < cus * 3 / 4 && ws) {
+        sp = (cus + gx / 2) / gx;
+        if (sp > nk / 8) sp = nk / 8;  // keep >= 8 K tiles per split: three of them are pipeline fill
+        if (sp > 8) sp = 8;
+        while (sp > 1 && (int64_t)sp * M * N * 4 > ws_bytes) --sp;
+        if (sp < 1) sp = 1;
+      }
+      if (mode > 2 && ws) {
+        sp = mode - 2;
+        if (sp > nk) sp = nk;
+        while (sp > 1 && (int64_t)sp * M * N * 4 > ws_bytes) --sp;
+      }
+      if ((long)gx * sp < cus / 2) use288 = mode >= 2;  // too few blocks to fill the chip: the small tiles overlap better
+    }
+    if (use288) {
+      if (sp > 1) {
+        e.partial = reinterpret_cast<float*>(ws);
+        e.tiles_per_split = cdiv(nk, sp);
+        e.splits = cdiv(nk, e.tiles_per_split);
+      }
+      SRGPT_TRY(srgpt_gemm288_launch(A, W, K, lda, e, s));
+      if (e.splits > 1) {
+        launch_splitk_reduce<bf16_t>(e, s);
+        SRGPT_LAUNCH_CHECK();
+      }
+      return SRGPT_OK;
+    }
   }
   // ---- 256 x 256 eight-wave kernel (gemm256.hip); rule calibrated on MI355X measurements (profiles/r02_gemm256_*.txt,
   //      profiles/r02_gemm_final.txt: one block per CU, ~15 us of launch + prologue + epilogue per round of tiles) ----

@@ -1,0 +1,229 @@
+// bf16 MFMA GEMM for the bs = 1 prefill products: ALL rows of a 257..288-row activation (T = 259 at BASELINE configs[1]) in one
+// block.  C[M,N] = epilogue(A[M,K] @ W[N,K]^T), both operands K-contiguous, 288 x 128 x 64 block tile, 9 waves.
+//
+// Why a kernel of its own: at M = 259 the product sits on the ridge (259 flop per weight byte against ~312 for the chip), so it
+// has to stream W at HBM rate AND keep the matrix pipe fed.  The 96 x 128 tiles of gemm.hip read every W tile three times (once
+// per row tile; L2 absorbs most of it) and move 17.8 B through the global -> LDS path per kFLOP; here W crosses that path once
+// (11 B / kFLOP) and a block's HBM requests are three K tiles deep:
+//   * waves: 9 x (32 rows x 128 columns) = 4 accumulators of v_mfma_f32_32x32x16_bf16 each (64 VGPRs); a SIMD holds 2 - 3 waves
+//   * LDS: THREE stages x (A 288 x 64 + W 128 x 64) bf16 = 156 KiB (+ 2 KiB scratch), rows of 128 B in 16-byte slots,
+//     slot ^ ((row >> 1) & 7) (gemm256's conflict-free ds_read_b128 layout), filled by LDS-DMA (global_load_lds_dwordx4: one
+//     wave-instruction = 8 rows x 128 B).  Per K tile a wave issues 4 A groups + 2 W groups (wave 8, which has no W group left
+//     of the 16, aims its two at the scratch area so that every wave's counted wait is the same immediate)
+//   * one barrier per K tile: top of tile t = [vmcnt(6): my groups of tile t landed, tile t + 1's may fly] -> barrier -> request
+//     tile t + 2 into the stage tile t - 1 just left -> 4 k-steps of (fragment reads one step ahead, 4 MFMAs).  A request is two
+//     whole K tiles old when it is waited for.  (The round-4 probe of this shape -- profiles/r04_tall_gemm_probe.txt -- kept A out
+//     of LDS and W one tile deep: A fragments from L2 bound it, and one tile of prefetch per CU cannot cover HBM latency.)
+//   * split-K over blockIdx.y for the narrow products (deterministic fp32 slabs, reduced by splitk_reduce_kernel of gemm.hip)
+// Requirements (checked by the launcher): K % 64 == 0.  Selected by srgpt_gemm for 224 < M <= 288 when the grid fills the chip.
+#include <type_traits>
+
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int T_BM = 272, T_BN = 128, T_BK = 64, T_NS = 3;
+constexpr int T_MAIN = 256;                  // rows of the eight 32-row wave tiles; rows 256 .. 271 are the 16-row tail
+constexpr int T_A = T_BM * T_BK * 2;         // 34 KiB
+constexpr int T_W = T_BN * T_BK * 2;         // 16 KiB
+constexpr int T_STAGE = T_A + T_W;           // 50 KiB
+constexpr int T_LDS = T_NS * T_STAGE;        // 150 KiB
+
+#define T_BARRIER()                       \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+#define T_VMCNT(N)                                            \
+  do {                                                        \
+    __builtin_amdgcn_sched_barrier(0);                        \
+    asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                        \
+  } while (0)
+
+template <int ablate>  // 0 = the kernel; tuning build only (wrong results): 1 no DMA in the loop, 4 no MFMA, 5 no barrier, 6 no DMA wait
+__global__ __launch_bounds__(512, 1) void gemm_bf16_288_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, int K,
+                                                               int lda, Epilogue e) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.x * T_BN, m0 = blockIdx.z * T_BM;
+
+  const int nk_all = K / T_BK;
+  const int kt0 = e.splits > 1 ? (int)blockIdx.y * e.tiles_per_split : 0;
+  const int nk = e.splits > 1 ? min(nk_all, kt0 + e.tiles_per_split) : nk_all;
+
+  // ---- requests: lane -> row lane >> 3 of an 8-row group, physical slot lane & 7 = logical chunk ^ ((row >> 1) & 7); every group
+  //      of a wave has g & 1 == wave & 1, so the chunk a lane fetches is the same for all of them.  Per K tile a wave requests A
+  //      groups wave + 8 i (i < 4) and W groups wave + 8 i (i < 2); the 16-row tail (rows 256 .. 271; 3 of them exist at T = 259)
+  //      is two more A groups on waves 0 and 1: those two have 7 requests per tile in flight, the others 6 -- a wave-uniform
+  //      branch picks the wait immediate ----
+  const int lr = lane >> 3, lc = (lane & 7) ^ (((wave & 1) << 2) | (lr >> 1));
+  const bool has_tail = m0 + T_MAIN < e.M;  // uniform
+  const bool tail_wave = has_tail && wave < 2;
+  const bf16_t* pa[4];
+  const bf16_t* pw[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pa[i] = A + (size_t)min(m0 + (wave + 8 * i) * 8 + lr, e.M - 1) * lda + lc * 8;  // A groups 0 .. 31
+#pragma unroll
+  for (int i = 0; i < 2; ++i) pw[i] = W + (size_t)min(n0 + (wave + 8 * i) * 8 + lr, e.N - 1) * K + lc * 8;    // W groups 0 .. 15
+  const bf16_t* ptl = A + (size_t)min(m0 + T_MAIN + wave * 8 + lr, e.M - 1) * lda + lc * 8;                    // A group 32 + wave
+  auto dma = [&](const void* s_, int lds_off) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,
+                                     (__attribute__((address_space(3))) void*)(lds + lds_off), 16, 0, 0);
+  };
+  auto request = [&](int kt) {  // the wave's groups of K tile kt into stage kt % 3
+    const int k0 = kt * T_BK;
+    const int soff = (kt % T_NS) * T_STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma(pw[i] + k0, soff + T_A + (wave + 8 * i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma(pa[i] + k0, soff + (wave + 8 * i) * 1024);
+    if (tail_wave) dma(ptl + k0, soff + (32 + wave) * 1024);
+  };
+  // tail fragments for v_mfma_f32_16x16x32_bf16: lane (row lane & 15, k group lane >> 4), 16 bytes: chunk 4 s + (lane >> 4);
+  // wave w multiplies the 16 tail rows with W rows 16 w .. 16 w + 15 of the block's column tile
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int trow = wave * 16 + l15;
+  int toff[2], taoff[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    toff[s2] = T_A + trow * 128 + (((4 * s2 + g4) ^ ((trow >> 1) & 7)) << 4);
+    taoff[s2] = (T_MAIN + l15) * 128 + (((4 * s2 + g4) ^ ((l15 >> 1) & 7)) << 4);
+  }
+
+  // ---- fragment addresses (gemm256): row = tile row + (lane & 31), slot = (2 ks + (lane >> 5)) ^ ((row >> 1) & 7) ----
+  const int l31 = lane & 31, hi = lane >> 5, sw = (l31 >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + ((hi ^ (sw & 1)) << 4) + ((ks ^ (sw >> 1)) << 5);
+  const int wm = wave >> 1, wn = wave & 1;  // waves 4 (M) x 2 (N): 64 x 64 of C each = 2 x 2 MFMA tiles (8 A + 8 W fragment reads per K tile)
+  const int a_base = wm * 64 * 128, w_base = T_A + wn * 64 * 128;
+
+  f32x16 acc[4];
+  {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = z;
+  }
+  f32x4 acct = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: K tiles kt0 and kt0 + 1 requested ----
+  request(kt0);
+  if (kt0 + 1 < nk) request(kt0 + 1);
+
+  for (int kt = kt0; kt < nk; ++kt) {
+    // my groups of tile kt have landed (those of tile kt + 1 may fly)
+    if (ablate != 6 && ablate != 1) {
+      if (kt + 1 >= nk) T_VMCNT(0);
+      else if (tail_wave) T_VMCNT(7);
+      else T_VMCNT(6);
+    }
+    if (ablate != 5) T_BARRIER();  // everyone's have; everyone is done reading tile kt - 1
+    if (ablate != 1 && kt + 2 < nk) request(kt + 2);  // into the stage tile kt - 1 occupied
+    const char* buf = lds + (kt % T_NS) * T_STAGE;
+    const char* bufw = buf + T_A;
+    // fragments one k-step ahead of their products, in program order the compiler may not change (sched_barrier): left alone it
+    // read each fragment right before its MFMA (lgkmcnt(0) in front of every product)
+    bf16x8 fa[2][2], fw[2][2], fta[2], ftw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[0][i] = *reinterpret_cast<const bf16x8*>(buf + a_base + i * 32 * 128 + koff[0]);
+      fw[0][i] = *reinterpret_cast<const bf16x8*>(buf + w_base + i * 32 * 128 + koff[0]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks & 1, nx = c ^ 1;
+      if (ks < 3) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[nx][i] = *reinterpret_cast<const bf16x8*>(buf + a_base + i * 32 * 128 + koff[ks + 1]);
+          fw[nx][i] = *reinterpret_cast<const bf16x8*>(buf + w_base + i * 32 * 128 + koff[ks + 1]);
+        }
+      } else if (has_tail) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          fta[s2] = *reinterpret_cast<const bf16x8*>(buf + taoff[s2]);
+          ftw[s2] = *reinterpret_cast<const bf16x8*>(buf + toff[s2]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+          if (ablate != 4) acc[2 * mi + jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][mi], fw[c][jn], acc[2 * mi + jn], 0, 0, 0);
+          else asm volatile("" ::"v"(fa[c][mi]), "v"(fw[c][jn]));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (has_tail) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (ablate != 4) acct = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fta[s2], ftw[s2], acct, 0, 0, 0);
+        else asm volatile("" ::"v"(fta[s2]), "v"(ftw[s2]));
+      }
+    }
+  }
+
+  // ---- epilogue.  32x32 D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
+  float* slab = e.splits > 1 ? e.partial + (size_t)blockIdx.y * e.M * e.N : nullptr;
+#pragma clang loop unroll(full)
+  for (int t = 0; t < 4; ++t) {
+    const f32x16 a = acc[t];
+    const int n = n0 + wn * 64 + (t & 1) * 32 + l31;
+    const int mb = m0 + wm * 64 + (t >> 1) * 32 + 4 * hi;
+    if (slab) {
+#pragma clang loop unroll(full)
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m < e.M && n < e.N) slab[(size_t)m * e.N + n] = a[r];
+      }
+    } else {
+      epilogue_tile32<bf16_t>(e, mb, n, a);
+    }
+  }
+  // tail: 16x16 D layout: row = 4 * (lane >> 4) + reg, col = lane & 15
+  if (has_tail) {
+    const int n = n0 + wave * 16 + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + T_MAIN + 4 * g4 + r;
+      if (slab) {
+        if (m < e.M && n < e.N) slab[(size_t)m * e.N + n] = acct[r];
+      } else {
+        epilogue_store<bf16_t>(e, m, n, acct[r]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// e.splits / e.tiles_per_split / e.partial are set by the caller (srgpt_gemm) when it wants split-K; the deterministic slab
+// reduction (splitk_reduce_kernel in gemm.hip) follows there.
+int srgpt_gemm288_launch(const void* A, const void* W, int K, int lda, const Epilogue& e, hipStream_t s) {
+#define T_LAUNCH(AB)                                                                                                            \
+  do {                                                                                                                          \
+    static std::atomic<uint64_t> attr_done{0};                                                                                  \
+    SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)gemm_bf16_288_kernel<AB>, T_LDS));                                   \
+    hipLaunchKernelGGL(gemm_bf16_288_kernel<AB>, dim3(cdiv(e.N, T_BN), e.splits > 1 ? e.splits : 1, cdiv(e.M, T_BM)), dim3(512), \
+                       T_LDS, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);                                                \
+  } while (0)
+#ifdef SRGPT_TUNING_KNOBS
+  switch (SRGPT_KNOB("SRGPT_GEMM288_ABLATE", 0)) {
+    case 1: T_LAUNCH(1); break;
+    case 4: T_LAUNCH(4); break;
+    case 5: T_LAUNCH(5); break;
+    case 6: T_LAUNCH(6); break;
+    default: T_LAUNCH(0); break;
+  }
+#else
+  T_LAUNCH(0);
+#endif
+#undef T_LAUNCH
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
