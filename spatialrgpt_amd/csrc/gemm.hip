@@ -502,10 +502,10 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
     const int nk = K / 64;
     const int gx = cdiv(N, 128);
     const int mode = SRGPT_KNOB("SRGPT_GEMM_288", 1);  // tuning build: 0 = never, 2 = for any M <= 272, > 2 = forced split count
-    // measured at M = 259 (profiles/r04_gemm288.txt): gate/up 106.5 -> 96.5 us, down 64.8 -> 53.8; q/k/v 33.8 vs 33.6 and o 27.5 vs
-    // 29.2 stay on the small tiles (too few K tiles per block once K is split for 256 CUs: three of them are pipeline fill)
+    // measured at M = 259 (profiles/r04_gemm288.txt): gate/up 106.5 -> 84.2 us, down 64.8 -> 50.6, q/k/v 33.8 -> 32.0; o (27.5 vs
+    // 27.9: 8 K tiles per block once K is split for 256 CUs, three of them pipeline fill) stays on the small tiles
     bool use288 = mode != 0 && K % 64 == 0 && nk >= 4 &&
-                  ((M > 224 && M <= 272 && (int64_t)N * K >= (int64_t)40 << 20) || (mode >= 2 && M <= 272));
+                  ((M > 224 && M <= 272 && (int64_t)N * K >= (int64_t)24 << 20) || (mode >= 2 && M <= 272));
     int sp = 1;
     if (use288) {
       if (gx < cus * 3 / 4 && ws) {

@@ -41,6 +41,18 @@ def _tol(ref, dtype, k=1.0):
                                    (259, 6144, 4096), (300, 1000, 1024), (383, 4096, 512), (257, 128, 2048), (352, 264, 4096),
                                    (320, 4096, 14336)])
 def test_gemm_plain(dtype, M, N, K):
+    _gemm_case(dtype, M, N, K)
+
+
+# The whole-M prefill kernel (gemm288.hip: 225 .. 272 rows, N * K >= 40 Mi elements): split-K 3 with 22 / 21 / 21 K tiles, an odd
+# tile count (65: the three-stage ring wraps mid-split), split-K 8 over K = 14336, no tail rows (M = 225), one tail row + ragged N.
+@pytest.mark.parametrize("M,N,K", [(259, 12288, 4096), (272, 10240, 4160), (259, 4096, 14336), (225, 28672, 1536), (257, 45000, 1024),
+                                   (259, 28672, 4096)])
+def test_gemm_whole_m_tile(M, N, K):
+    _gemm_case(torch.bfloat16, M, N, K)
+
+
+def _gemm_case(dtype, M, N, K):
     ops, L = _ops()
     if dtype == torch.float32 and K % 4:
         pytest.skip("K % 4")
