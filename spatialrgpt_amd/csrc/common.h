@@ -276,7 +276,6 @@ __device__ __forceinline__ void srgpt_prefetch_block(const SrgptPrefetch& pf, in
 }
 
 extern "C" int srgpt_device_cus(void);
-
 // descriptor for "the next launch is the batch-`batch` decode GEMV over W [N (2N if swiglu), K]" (bf16 rows, or fp8 bytes).
 // Mirrors the grid / unit mapping of gemv.hip's and gemv_w8.hip's launchers for one row (the VALU kernels); anything else
 // gets no prefetch: fp8 SwiGLU units of four rows, and 2+ rows (the skinny kernel -- its mapping, 4-row groups of block p's

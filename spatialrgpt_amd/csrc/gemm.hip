@@ -347,22 +347,116 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(Epilogue e) {
   }
 }
 
-// launches the reduction that fits the epilogue (returns through SRGPT_LAUNCH_CHECK at the call site)
+// The same pass with the RMSNorm of the finished rows behind it (LlamaDecoderLayer: o_proj / down_proj + residual, then the next
+// RMSNorm -- modeling_llama.py:611-684): one block per row, thread t owns the 8-element chunks t, t + 256, ... exactly as
+// rmsnorm_kernel (norm.hip) does, sums the slabs in slab order, applies the epilogue with reduce4's roundings, stores the row of C,
+// and accumulates the squares of the ROUNDED values in rmsnorm_kernel's order through the same block_sum -- so C and the normalised
+// row are bit-identical to [splitk_reduce4_kernel -> rmsnorm_kernel], one launch and one read of the row less.
+template <int MAXS, int CH>  // CH chunks of 8 per thread: N <= 2048 * CH
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(Epilogue e) {
+  __shared__ float red[16];
+  const int m = blockIdx.x, nch = e.N / 8;
+  const size_t total = (size_t)e.M * e.N;
+  float x[CH][8];
+  float ssq = 0.f;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    if (c < nch) {
+      const int n = c * 8;
+      f32x4 p[MAXS][2];
+#pragma unroll
+      for (int z = 0; z < MAXS; ++z) {
+        const float* src = e.partial + (size_t)min(z, e.splits - 1) * total + (size_t)m * e.N + n;
+        p[z][0] = *reinterpret_cast<const f32x4*>(src);
+        p[z][1] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int z = 0; z < MAXS; ++z)
+        if (z < e.splits) {
+          a0 += p[z][0];
+          a1 += p[z][1];
+        }
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = a0[q];
+        v[4 + q] = a1[q];
+      }
+      if (e.wscale) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= e.wscale[n + q];
+      }
+      if (e.bias) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += to_f(reinterpret_cast<const bf16_t*>(e.bias)[n + q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = rnd<bf16_t>(v[q]);
+      if (e.act != SRGPT_ACT_NONE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = rnd<bf16_t>(apply_act<bf16_t>(v[q], e.act));
+      }
+      if (e.residual) {
+        const Vec16<bf16_t> r = *reinterpret_cast<const Vec16<bf16_t>*>(reinterpret_cast<const bf16_t*>(e.residual) + (size_t)m * e.N + n);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = rnd<bf16_t>(v[q] + r.get(q));
+      }
+      Vec16<bf16_t> o;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        o.set(q, v[q]);
+        x[k][q] = v[q];
+        ssq += v[q] * v[q];
+      }
+      *reinterpret_cast<Vec16<bf16_t>*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n) = o;
+    }
+  }
+  const float r = rsqrtf(block_sum(ssq, red) / (float)e.N + e.norm_eps);
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = threadIdx.x + 256 * k;
+    if (c < nch) {
+      const Vec16<bf16_t> g = *reinterpret_cast<const Vec16<bf16_t>*>(reinterpret_cast<const bf16_t*>(e.norm_w) + c * 8);
+      Vec16<bf16_t> o;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o.set(q, g.get(q) * rnd<bf16_t>(x[k][q] * r));  // weight * h.to(input_dtype)
+      *reinterpret_cast<Vec16<bf16_t>*>(reinterpret_cast<bf16_t*>(e.norm_y) + (size_t)m * e.N + c * 8) = o;
+    }
+  }
+}
+
+// launches the reduction that fits the epilogue (returns through SRGPT_LAUNCH_CHECK at the call site); true when the RMSNorm the
+// epilogue asks for went into it
 template <typename T>
-static inline void launch_splitk_reduce(const Epilogue& e, hipStream_t s) {
+static inline bool launch_splitk_reduce(const Epilogue& e, hipStream_t s) {
   const size_t total = (size_t)e.M * e.N;
   const bool vec4 = e.N % 4 == 0 && e.ldc % 4 == 0 && e.out_mode != SRGPT_OUT_DECONV2X && e.bias_mod <= 0 && e.res_mod <= 0 &&
                     e.splits <= 8 && ((uintptr_t)e.C % 16 == 0);
+  if (e.norm_y && std::is_same<T, bf16_t>::value && vec4 && !e.out_f32 && e.N % 8 == 0 && e.ldc % 8 == 0 && e.N <= 8192 &&
+      ((uintptr_t)e.norm_y % 16 == 0) && ((uintptr_t)e.norm_w % 16 == 0) && (!e.residual || (uintptr_t)e.residual % 16 == 0)) {
+    const bool wide = e.N > 4096;
+    if (e.splits <= 4) {
+      if (wide) hipLaunchKernelGGL((splitk_reduce_norm_kernel<4, 4>), dim3(e.M), dim3(256), 0, s, e);
+      else hipLaunchKernelGGL((splitk_reduce_norm_kernel<4, 2>), dim3(e.M), dim3(256), 0, s, e);
+    } else {
+      if (wide) hipLaunchKernelGGL((splitk_reduce_norm_kernel<8, 4>), dim3(e.M), dim3(256), 0, s, e);
+      else hipLaunchKernelGGL((splitk_reduce_norm_kernel<8, 2>), dim3(e.M), dim3(256), 0, s, e);
+    }
+    return true;
+  }
   if (vec4) {
     int rgrid = (int)((total / 4 + 255) / 256);
     if (rgrid > 2048) rgrid = 2048;
     if (e.splits <= 4) hipLaunchKernelGGL((splitk_reduce4_kernel<T, 4>), dim3(rgrid), dim3(256), 0, s, e);
     else hipLaunchKernelGGL((splitk_reduce4_kernel<T, 8>), dim3(rgrid), dim3(256), 0, s, e);
-    return;
+    return false;
   }
   int rgrid = (int)((total + 255) / 256);
   if (rgrid > 2048) rgrid = 2048;
   hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(rgrid), dim3(256), 0, s, e);
+  return false;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -471,9 +565,10 @@ int srgpt_splitk_reduce_bf16(const Epilogue& e, hipStream_t s) {
 
 extern "C" int64_t srgpt_gemm_ws_bytes(int M, int N) { return (int64_t)8 * M * N * 4; }
 
-extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const void* residual, void* C, int M,
-                          int N, int K, int lda, int ldc, int act, int bias_mod, int res_mod, int out_f32,
-                          int out_mode, int gw, void* ws, int64_t ws_bytes, int dtype, srgpt_stream_t stream) {
+// norm_w / norm_y / norm_eps: the RMSNorm of the output rows (srgpt_gemm_rmsnorm below); *norm_done = it went into the reduction
+static int gemm_impl(const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K, int lda,
+                     int ldc, int act, int bias_mod, int res_mod, int out_f32, int out_mode, int gw, void* ws, int64_t ws_bytes,
+                     int dtype, srgpt_stream_t stream, const void* norm_w, void* norm_y, float norm_eps, bool* norm_done) {
   SRGPT_CHECK(A && W && C, SRGPT_ERR_ARG, "srgpt_gemm: null pointer");
   SRGPT_CHECK(M > 0 && N > 0 && K > 0, SRGPT_ERR_ARG, "srgpt_gemm: bad shape M=%d N=%d K=%d", M, N, K);
   SRGPT_CHECK(dtype == SRGPT_F32 || dtype == SRGPT_BF16, SRGPT_ERR_ARG, "srgpt_gemm: bad dtype %d", dtype);
@@ -487,7 +582,7 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
     SRGPT_CHECK(out_mode == SRGPT_OUT_PLAIN, SRGPT_ERR_ARG, "srgpt_gemm: unknown out_mode %d", out_mode);
     SRGPT_CHECK(ldc >= N, SRGPT_ERR_ARG, "srgpt_gemm: ldc < N");
   }
-  Epilogue e{bias, residual, C, M, N, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw, nullptr, 1, 0, nullptr};
+  Epilogue e{bias, residual, C, M, N, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw, nullptr, 1, 0, nullptr, norm_w, norm_y, norm_eps};
   hipStream_t s = as_stream(stream);
   if (dtype == SRGPT_F32) {
     dim3 grid(cdiv(N, 64), cdiv(M, 64));
@@ -530,7 +625,10 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
       }
       SRGPT_TRY(srgpt_gemm288_launch(A, W, K, lda, e, s));
       if (e.splits > 1) {
-        launch_splitk_reduce<bf16_t>(e, s);
+        {
+          const bool fused = launch_splitk_reduce<bf16_t>(e, s);
+          if (norm_done) *norm_done = fused;
+        }
         SRGPT_LAUNCH_CHECK();
       }
       return SRGPT_OK;
@@ -573,7 +671,10 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
       }
       SRGPT_TRY(srgpt_gemm256_launch(A, W, K, lda, e, s));
       if (e.splits > 1) {
-        launch_splitk_reduce<bf16_t>(e, s);
+        {
+          const bool fused = launch_splitk_reduce<bf16_t>(e, s);
+          if (norm_done) *norm_done = fused;
+        }
         SRGPT_LAUNCH_CHECK();
       }
       return SRGPT_OK;
@@ -659,7 +760,10 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
   }
   SRGPT_LAUNCH_CHECK();
   if (e.splits > 1) {
-    launch_splitk_reduce<bf16_t>(e, s);
+    {
+          const bool fused = launch_splitk_reduce<bf16_t>(e, s);
+          if (norm_done) *norm_done = fused;
+        }
     SRGPT_LAUNCH_CHECK();
   }
   return SRGPT_OK;
@@ -668,6 +772,28 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
 // C = epilogue((A @ fp8(W8)^T) * wscale): bf16 activations, OCP e4m3fn weight bytes, one fp32 scale per weight row -- the
 // prefill-side companion of srgpt_gemv_w8 (BASELINE config 5).  Always the 256 x 256 kernel (W tile staged as bytes, widened
 // to bf16 between LDS and the MFMA operands); K splits (deterministic slabs) when the tiles do not fill the chip.
+extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const void* residual, void* C, int M,
+                          int N, int K, int lda, int ldc, int act, int bias_mod, int res_mod, int out_f32,
+                          int out_mode, int gw, void* ws, int64_t ws_bytes, int dtype, srgpt_stream_t stream) {
+  return gemm_impl(A, W, bias, residual, C, M, N, K, lda, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw, ws, ws_bytes, dtype,
+                   stream, nullptr, nullptr, 0.f, nullptr);
+}
+
+// C = A W^T + residual (row-major, ldc == N) and norm_y = RMSNorm(C) * norm_w in one call (include/srgpt.h; the prefill layer loop
+// of model.hip).  The norm rides in the split-K reduction when the product is split; otherwise it is the ordinary srgpt_rmsnorm
+// launch -- either way the two outputs are bit-identical to srgpt_gemm followed by srgpt_rmsnorm.
+extern "C" int srgpt_gemm_rmsnorm(const void* A, const void* W, const void* residual, void* C, int M, int N, int K, void* ws,
+                                  int64_t ws_bytes, const void* norm_w, void* norm_y, float norm_eps, int dtype,
+                                  srgpt_stream_t stream) {
+  SRGPT_CHECK(norm_w && norm_y, SRGPT_ERR_ARG, "srgpt_gemm_rmsnorm: null pointer");
+  SRGPT_CHECK(norm_y != C && norm_y != A, SRGPT_ERR_ARG, "srgpt_gemm_rmsnorm: Y must not alias A or C");
+  bool fused = false;
+  SRGPT_TRY(gemm_impl(A, W, nullptr, residual, C, M, N, K, K, N, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, ws, ws_bytes, dtype,
+                      stream, norm_w, norm_y, norm_eps, &fused));
+  if (!fused) SRGPT_TRY(srgpt_rmsnorm(C, norm_w, norm_y, M, N, norm_eps, dtype, stream));
+  return SRGPT_OK;
+}
+
 extern "C" int srgpt_gemm_w8(const void* A, const void* W8, const float* wscale, const void* bias, const void* residual,
                              void* C, int M, int N, int K, int lda, int ldc, int act, int out_f32, void* ws,
                              int64_t ws_bytes, srgpt_stream_t stream) {

@@ -425,6 +425,8 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
     return srgpt_gemm_w8a8(l.a8, l.a8s, W8p, sc, nullptr, res, out, rows, N, K, K, N, 0, l.gws, (int64_t)l.gws_bytes, stream);
   };
   const bool fuse8 = a8 && Hd <= 16384 && I <= 16384;
+  const bool plain = !w8;  // dtype matrices: srgpt_gemm
+  bool h_ready = false;   // l.h already holds RMSNorm(l.x) under the coming layer's attn_norm
   for (int i = 0; i < w->layers; ++i) {
     char* kc = reinterpret_cast<char*>(st->kcache) + (size_t)i * layer_kv;
     char* vc = reinterpret_cast<char*>(st->vcache) + (size_t)i * layer_kv;
@@ -432,7 +434,7 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
       SRGPT_TRY(srgpt_quant_rows_e4m3_rmsnorm(l.x, w->attn_norm[i], w->rms_eps, l.a8, l.a8s, rows, Hd, Hd, stream));
       SRGPT_TRY(mm8(w->wqkv8[i], w->wqkv_scale[i], nullptr, l.qkv, QW, Hd));
     } else {
-      SRGPT_TRY(srgpt_rmsnorm(l.x, w->attn_norm[i], l.h, rows, Hd, w->rms_eps, dt, stream));
+      if (!h_ready) SRGPT_TRY(srgpt_rmsnorm(l.x, w->attn_norm[i], l.h, rows, Hd, w->rms_eps, dt, stream));
       SRGPT_TRY(mm(l.h, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, nullptr, l.qkv, QW, Hd, 0, l.gws,
                    (int64_t)l.gws_bytes));
     }
@@ -441,20 +443,31 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
     SRGPT_TRY(srgpt_attention(l.qkv, kc, vc, l.attn, B, T, T, Hq, Hkv, D, (int64_t)T * QW, QW, D,
                               (int64_t)Hkv * st->max_pos * D, D, (int64_t)st->max_pos * D,
                               (int64_t)Hkv * st->max_pos * D, D, (int64_t)st->max_pos * D, scale, 1, nullptr, dt, stream));
-    SRGPT_TRY(mm(l.attn, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, l.x, l.x, Hd, Hq * D, 0, l.gws,
-                 (int64_t)l.gws_bytes));
+    // plain weights: the RMSNorm that follows o_proj / down_proj rides in the product's split-K reduction (srgpt_gemm_rmsnorm:
+    // bit-identical to the two launches, one launch and one pass over the rows less per norm)
+    if (plain)
+      SRGPT_TRY(srgpt_gemm_rmsnorm(l.attn, w->wo[i], l.x, l.x, (int)rows, Hd, Hq * D, l.gws, (int64_t)l.gws_bytes, w->mlp_norm[i], l.h,
+                                w->rms_eps, dt, stream));
+    else
+      SRGPT_TRY(mm(l.attn, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, l.x, l.x, Hd, Hq * D, 0, l.gws,
+                   (int64_t)l.gws_bytes));
     if (fuse8) {
       SRGPT_TRY(srgpt_quant_rows_e4m3_rmsnorm(l.x, w->mlp_norm[i], w->rms_eps, l.a8, l.a8s, rows, Hd, Hd, stream));
       SRGPT_TRY(mm8(w->wgu8[i], w->wgu_scale[i], nullptr, l.gu, 2 * I, Hd));
       SRGPT_TRY(srgpt_quant_rows_e4m3_swiglu(l.gu, l.a8, l.a8s, rows, I, stream));
       SRGPT_TRY(mm8(w->wdown8[i], w->wdown_scale[i], l.x, l.x, Hd, I));
     } else {
-      SRGPT_TRY(srgpt_rmsnorm(l.x, w->mlp_norm[i], l.h, rows, Hd, w->rms_eps, dt, stream));
+      if (!plain) SRGPT_TRY(srgpt_rmsnorm(l.x, w->mlp_norm[i], l.h, rows, Hd, w->rms_eps, dt, stream));
       SRGPT_TRY(mm(l.h, w->wgu[i], w8 ? w->wgu8[i] : nullptr, w8 ? w->wgu_scale[i] : nullptr, nullptr, l.gu, 2 * I, Hd, 0, l.gws,
                    (int64_t)l.gws_bytes));
       SRGPT_TRY(srgpt_silu_mul(l.gu, l.act, rows, I, dt, stream));
-      SRGPT_TRY(mm(l.act, w->wdown[i], w8 ? w->wdown8[i] : nullptr, w8 ? w->wdown_scale[i] : nullptr, l.x, l.x, Hd, I, 0, l.gws,
-                   (int64_t)l.gws_bytes));
+      h_ready = plain && i + 1 < w->layers;
+      if (h_ready)
+        SRGPT_TRY(srgpt_gemm_rmsnorm(l.act, w->wdown[i], l.x, l.x, (int)rows, Hd, I, l.gws, (int64_t)l.gws_bytes, w->attn_norm[i + 1],
+                                  l.h, w->rms_eps, dt, stream));
+      else
+        SRGPT_TRY(mm(l.act, w->wdown[i], w8 ? w->wdown8[i] : nullptr, w8 ? w->wdown_scale[i] : nullptr, l.x, l.x, Hd, I, 0, l.gws,
+                     (int64_t)l.gws_bytes));
     }
     if (hidden_out)
       SRGPT_HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(hidden_out) + (size_t)(i + 1) * hid_bytes, l.x, hid_bytes,

@@ -80,6 +80,24 @@ def gemm(a, w, bias=None, residual=None, act=L.ACT_NONE, out=None, out_f32=False
     return out
 
 
+def gemm_rmsnorm(a, w, residual, norm_w, eps, out=None, y=None):
+    """(a @ w.T + residual, rmsnorm(that) * norm_w): the tail of a decoder block and the next block's input norm in one call.
+    `out` may be `residual` (in place).  Bit-identical to gemm(...) followed by rmsnorm(...)."""
+    _dev(a, w, residual, norm_w)
+    _same_dtype("gemm_rmsnorm", a, weight=w, residual=residual, norm_weight=norm_w)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.is_contiguous() and w.is_contiguous() and (residual is None or residual.is_contiguous())
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=a.dtype)
+    if y is None:
+        y = torch.empty((M, N), device=a.device, dtype=a.dtype)
+    ws = _splitk_ws(a.device, M, N) if (a.dtype == torch.bfloat16 and M * N <= (1 << 24)) else None
+    L.check(L.load().srgpt_gemm_rmsnorm(_p(a), _p(w), _p(residual), _p(out), M, N, K, _p(ws), 0 if ws is None else ws.numel(),
+                                        _p(norm_w), _p(y), float(eps), dt_code(a), _stream()))
+    return out, y
+
+
 def gemv(x, w, norm_w=None, eps=0.0, residual=None, swiglu=False, out=None, out_f32=False):
     """decode GEMV: x [B,K], w [N(,2N if swiglu),K] -> [B,N]."""
     _dev(x, w, norm_w, residual)

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/srgpt.h but not exported"
     assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.srgpt_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.srgpt_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_struct_layouts_match_header():

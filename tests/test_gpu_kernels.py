@@ -70,6 +70,28 @@ def _gemm_case(dtype, M, N, K):
     assert_close(out3, F.gelu((ref + b.float()).to(dtype).float()), _tol(ref, dtype), 0, "gemm f32 out")
 
 
+# o_proj / down_proj + residual + the next RMSNorm in one call: the norm inside the split-K reduction (small tiles split 2, the
+# whole-M kernel split 8, a 256-row-tile shape), the wide-row variant (N = 8192), and the fallbacks (no split; N > 8192; fp32)
+@pytest.mark.parametrize("dtype,M,N,K", [(torch.bfloat16, 259, 4096, 4096), (torch.bfloat16, 259, 4096, 14336),
+                                         (torch.bfloat16, 707, 4096, 4096), (torch.bfloat16, 259, 8192, 2048),
+                                         (torch.bfloat16, 300, 2560, 6912), (torch.bfloat16, 259, 28672, 512),
+                                         (torch.bfloat16, 64, 16384, 256), (torch.float32, 130, 512, 256)])
+def test_gemm_rmsnorm_equals_the_two_launches(dtype, M, N, K):
+    ops, L = _ops()
+    a, w = _rand((M, K), dtype, 11), _rand((N, K), dtype, 12, 0.05)
+    r, g = _rand((M, N), dtype, 13), (1 + 0.1 * _rand((N,), torch.float32, 14)).to(dtype)
+    a, w, r, g = a.to(DEV), w.to(DEV), r.to(DEV), g.to(DEV)
+    c_ref = ops.gemm(a, w, residual=r)
+    y_ref = ops.rmsnorm(c_ref, g, 1e-5)
+    c, y = ops.gemm_rmsnorm(a, w, r, g, 1e-5)
+    assert torch.equal(c, c_ref) and torch.equal(y, y_ref)
+    x = r.clone()  # in place on the residual stream, as the prefill loop calls it
+    c2, y2 = ops.gemm_rmsnorm(a, w, x, g, 1e-5, out=x)
+    assert c2.data_ptr() == x.data_ptr() and torch.equal(x, c_ref) and torch.equal(y2, y_ref)
+    ref = (a.float() @ w.float().T).to(dtype).float() + r.float()
+    assert_close(c, ref, _tol(ref, dtype), 0, "gemm_rmsnorm C")
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_strided_a_and_row_modulo_residual(dtype):
     ops, L = _ops()
