@@ -72,13 +72,18 @@ int srgpt_gemm(const void* A, const void* W, const void* bias, const void* resid
                int M, int N, int K, int lda, int ldc, int act, int bias_mod, int res_mod,
                int out_f32, int out_mode, int gw, void* ws, int64_t ws_bytes, int dtype, srgpt_stream_t stream);
 
-/* C[M,N] = A[M,K] @ W[N,K]^T + residual[M,N] and Y[M,N] = RMSNorm(C) * norm_w from one call -- the tail of a decoder layer's
- * attention / MLP block followed by the next block's input norm (LlamaDecoderLayer.forward modeling_llama.py:611-684: o_proj or
- * down_proj, the residual add, then LlamaRMSNorm :61-75).  Dense rows (lda = K, ldc = N), no bias.  When the product is split over
- * K the norm rides in the slab reduction (one launch and one pass over the rows less); otherwise it is the srgpt_rmsnorm launch.
- * Either way C and Y are bit-identical to srgpt_gemm followed by srgpt_rmsnorm.  C may alias residual.  ws as for srgpt_gemm. */
-int srgpt_gemm_rmsnorm(const void* A, const void* W, const void* residual, void* C, int M, int N, int K, void* ws,
-                       int64_t ws_bytes, const void* norm_w, void* Y, float norm_eps, int dtype, srgpt_stream_t stream);
+/* C[M,N] = A[M,K] @ W[N,K]^T + bias[n] + residual[M,N] and Y[M,N] = norm(C) from one call -- the tail of an attention / MLP block
+ * followed by the next block's input norm: LlamaDecoderLayer.forward modeling_llama.py:611-684 (o_proj or down_proj, the residual
+ * add, then LlamaRMSNorm :61-75; norm_kind SRGPT_NORM_RMS, bias and norm_b NULL) and the HF SigLIP / CLIP encoder layer (out_proj
+ * or fc2 + bias, the residual add, then nn.LayerNorm; SRGPT_NORM_LAYER).  Dense rows (lda = K, ldc = N), no activation.  When the
+ * product is split over K the norm rides in the slab reduction (one launch and one pass over the rows less); otherwise it is the
+ * srgpt_rmsnorm / srgpt_layernorm launch.  Either way C and Y are bit-identical to srgpt_gemm followed by the norm.  C may alias
+ * residual, Y may alias A (not C).  ws as for srgpt_gemm. */
+#define SRGPT_NORM_RMS 1
+#define SRGPT_NORM_LAYER 2
+int srgpt_gemm_norm(const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K, void* ws,
+                    int64_t ws_bytes, int norm_kind, const void* norm_w, const void* norm_b, void* Y, float norm_eps, int dtype,
+                    srgpt_stream_t stream);
 
 /* GEMM with weight-only fp8 quantisation (the prefill-side companion of srgpt_gemv_w8, BASELINE config 5):
  *   C[M,N] = act( (A[M,K] @ fp8(W8[N,K])^T) * wscale[n] + bias[n] ) + residual[M,N]

@@ -67,6 +67,7 @@ SAMPLING_TOP_K_MAX = 64        # sample.hip SMP_K
 SAMPLING_KEPT_MAX = 256        # sample.hip SMP_LIST
 SAMPLING_VOCAB_MAX = 128 * 2048
 
+NORM_RMS, NORM_LAYER = 1, 2  # srgpt_gemm_norm
 ABI_VERSION = 7  # include/srgpt.h; bumped with every export / layout change
 
 _SIGNATURES = {
@@ -75,7 +76,7 @@ _SIGNATURES = {
     "srgpt_device_cus": (i32, []),
     "srgpt_gemm_ws_bytes": (i64, [i32, i32]),
     "srgpt_gemm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
-    "srgpt_gemm_rmsnorm": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, i64, vp, vp, f32, i32, vp]),
+    "srgpt_gemm_norm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, i32, vp, vp, vp, f32, i32, vp]),
     "srgpt_gemm_w8": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp]),
     "srgpt_quant_rows_e4m3": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "srgpt_quant_rows_e4m3_rmsnorm": (i32, [vp, vp, f32, vp, vp, i32, i32, i32, vp]),

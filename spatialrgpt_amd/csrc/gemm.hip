@@ -347,18 +347,19 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(Epilogue e) {
   }
 }
 
-// The same pass with the RMSNorm of the finished rows behind it (LlamaDecoderLayer: o_proj / down_proj + residual, then the next
-// RMSNorm -- modeling_llama.py:611-684): one block per row, thread t owns the 8-element chunks t, t + 256, ... exactly as
-// rmsnorm_kernel (norm.hip) does, sums the slabs in slab order, applies the epilogue with reduce4's roundings, stores the row of C,
-// and accumulates the squares of the ROUNDED values in rmsnorm_kernel's order through the same block_sum -- so C and the normalised
-// row are bit-identical to [splitk_reduce4_kernel -> rmsnorm_kernel], one launch and one read of the row less.
+// The same pass with the norm of the finished rows behind it (LlamaDecoderLayer: o_proj / down_proj + residual, then the next
+// RMSNorm -- modeling_llama.py:611-684; the ViT encoder layer: out_proj / fc2 + residual, then the next LayerNorm): one block per
+// row, thread t owns the 8-element chunks t, t + 256, ... exactly as rmsnorm_kernel / layernorm_kernel (norm.hip) do, sums the slabs
+// in slab order, applies the epilogue with reduce4's roundings, stores the row of C, and runs the norm's statistics over the
+// ROUNDED values in the norm kernels' element order through the same block_sum -- so C and the normalised row are bit-identical to
+// [splitk_reduce4_kernel -> rmsnorm_kernel / layernorm_kernel], one launch and one read of the row less.
 template <int MAXS, int CH>  // CH chunks of 8 per thread: N <= 2048 * CH
 __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(Epilogue e) {
   __shared__ float red[16];
   const int m = blockIdx.x, nch = e.N / 8;
   const size_t total = (size_t)e.M * e.N;
   float x[CH][8];
-  float ssq = 0.f;
+  float ssq = 0.f, sum = 0.f;  // rmsnorm_kernel's / layernorm_kernel's first accumulation, in their element order
 #pragma unroll
   for (int k = 0; k < CH; ++k) {
     const int c = threadIdx.x + 256 * k;
@@ -409,20 +410,50 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(Epilogue e) {
         o.set(q, v[q]);
         x[k][q] = v[q];
         ssq += v[q] * v[q];
+        sum += v[q];
       }
       *reinterpret_cast<Vec16<bf16_t>*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n) = o;
     }
   }
-  const float r = rsqrtf(block_sum(ssq, red) / (float)e.N + e.norm_eps);
+  if (e.norm_kind == SRGPT_NORM_RMS) {
+    const float r = rsqrtf(block_sum(ssq, red) / (float)e.N + e.norm_eps);
 #pragma unroll
-  for (int k = 0; k < CH; ++k) {
-    const int c = threadIdx.x + 256 * k;
-    if (c < nch) {
-      const Vec16<bf16_t> g = *reinterpret_cast<const Vec16<bf16_t>*>(reinterpret_cast<const bf16_t*>(e.norm_w) + c * 8);
-      Vec16<bf16_t> o;
+    for (int k = 0; k < CH; ++k) {
+      const int c = threadIdx.x + 256 * k;
+      if (c < nch) {
+        const Vec16<bf16_t> g = *reinterpret_cast<const Vec16<bf16_t>*>(reinterpret_cast<const bf16_t*>(e.norm_w) + c * 8);
+        Vec16<bf16_t> o;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) o.set(q, g.get(q) * rnd<bf16_t>(x[k][q] * r));  // weight * h.to(input_dtype)
-      *reinterpret_cast<Vec16<bf16_t>*>(reinterpret_cast<bf16_t*>(e.norm_y) + (size_t)m * e.N + c * 8) = o;
+        for (int q = 0; q < 8; ++q) o.set(q, g.get(q) * rnd<bf16_t>(x[k][q] * r));  // weight * h.to(input_dtype)
+        *reinterpret_cast<Vec16<bf16_t>*>(reinterpret_cast<bf16_t*>(e.norm_y) + (size_t)m * e.N + c * 8) = o;
+      }
+    }
+  } else {  // LayerNorm: layernorm_kernel's three passes over the row, from registers
+    const float mean = block_sum(sum, red) / (float)e.N;
+    float qv = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = threadIdx.x + 256 * k;
+      if (c < nch) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float d = x[k][q] - mean;
+          qv += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(block_sum(qv, red) / (float)e.N + e.norm_eps);
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = threadIdx.x + 256 * k;
+      if (c < nch) {
+        const Vec16<bf16_t> g = *reinterpret_cast<const Vec16<bf16_t>*>(reinterpret_cast<const bf16_t*>(e.norm_w) + c * 8);
+        const Vec16<bf16_t> be = *reinterpret_cast<const Vec16<bf16_t>*>(reinterpret_cast<const bf16_t*>(e.norm_b) + c * 8);
+        Vec16<bf16_t> o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o.set(q, (x[k][q] - mean) * rstd * g.get(q) + be.get(q));
+        *reinterpret_cast<Vec16<bf16_t>*>(reinterpret_cast<bf16_t*>(e.norm_y) + (size_t)m * e.N + c * 8) = o;
+      }
     }
   }
 }
@@ -435,7 +466,8 @@ static inline bool launch_splitk_reduce(const Epilogue& e, hipStream_t s) {
   const bool vec4 = e.N % 4 == 0 && e.ldc % 4 == 0 && e.out_mode != SRGPT_OUT_DECONV2X && e.bias_mod <= 0 && e.res_mod <= 0 &&
                     e.splits <= 8 && ((uintptr_t)e.C % 16 == 0);
   if (e.norm_y && std::is_same<T, bf16_t>::value && vec4 && !e.out_f32 && e.N % 8 == 0 && e.ldc % 8 == 0 && e.N <= 8192 &&
-      ((uintptr_t)e.norm_y % 16 == 0) && ((uintptr_t)e.norm_w % 16 == 0) && (!e.residual || (uintptr_t)e.residual % 16 == 0)) {
+      ((uintptr_t)e.norm_y % 16 == 0) && ((uintptr_t)e.norm_w % 16 == 0) && (!e.norm_b || (uintptr_t)e.norm_b % 16 == 0) &&
+      (!e.residual || (uintptr_t)e.residual % 16 == 0)) {
     const bool wide = e.N > 4096;
     if (e.splits <= 4) {
       if (wide) hipLaunchKernelGGL((splitk_reduce_norm_kernel<4, 4>), dim3(e.M), dim3(256), 0, s, e);
@@ -568,7 +600,8 @@ extern "C" int64_t srgpt_gemm_ws_bytes(int M, int N) { return (int64_t)8 * M * N
 // norm_w / norm_y / norm_eps: the RMSNorm of the output rows (srgpt_gemm_rmsnorm below); *norm_done = it went into the reduction
 static int gemm_impl(const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K, int lda,
                      int ldc, int act, int bias_mod, int res_mod, int out_f32, int out_mode, int gw, void* ws, int64_t ws_bytes,
-                     int dtype, srgpt_stream_t stream, const void* norm_w, void* norm_y, float norm_eps, bool* norm_done) {
+                     int dtype, srgpt_stream_t stream, int norm_kind, const void* norm_w, const void* norm_b, void* norm_y, float norm_eps,
+                     bool* norm_done) {
   SRGPT_CHECK(A && W && C, SRGPT_ERR_ARG, "srgpt_gemm: null pointer");
   SRGPT_CHECK(M > 0 && N > 0 && K > 0, SRGPT_ERR_ARG, "srgpt_gemm: bad shape M=%d N=%d K=%d", M, N, K);
   SRGPT_CHECK(dtype == SRGPT_F32 || dtype == SRGPT_BF16, SRGPT_ERR_ARG, "srgpt_gemm: bad dtype %d", dtype);
@@ -582,7 +615,7 @@ static int gemm_impl(const void* A, const void* W, const void* bias, const void*
     SRGPT_CHECK(out_mode == SRGPT_OUT_PLAIN, SRGPT_ERR_ARG, "srgpt_gemm: unknown out_mode %d", out_mode);
     SRGPT_CHECK(ldc >= N, SRGPT_ERR_ARG, "srgpt_gemm: ldc < N");
   }
-  Epilogue e{bias, residual, C, M, N, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw, nullptr, 1, 0, nullptr, norm_w, norm_y, norm_eps};
+  Epilogue e{bias, residual, C, M, N, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw, nullptr, 1, 0, nullptr, norm_w, norm_b, norm_y, norm_eps, norm_kind};
   hipStream_t s = as_stream(stream);
   if (dtype == SRGPT_F32) {
     dim3 grid(cdiv(N, 64), cdiv(M, 64));
@@ -776,21 +809,26 @@ extern "C" int srgpt_gemm(const void* A, const void* W, const void* bias, const 
                           int N, int K, int lda, int ldc, int act, int bias_mod, int res_mod, int out_f32,
                           int out_mode, int gw, void* ws, int64_t ws_bytes, int dtype, srgpt_stream_t stream) {
   return gemm_impl(A, W, bias, residual, C, M, N, K, lda, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw, ws, ws_bytes, dtype,
-                   stream, nullptr, nullptr, 0.f, nullptr);
+                   stream, 0, nullptr, nullptr, nullptr, 0.f, nullptr);
 }
 
-// C = A W^T + residual (row-major, ldc == N) and norm_y = RMSNorm(C) * norm_w in one call (include/srgpt.h; the prefill layer loop
-// of model.hip).  The norm rides in the split-K reduction when the product is split; otherwise it is the ordinary srgpt_rmsnorm
-// launch -- either way the two outputs are bit-identical to srgpt_gemm followed by srgpt_rmsnorm.
-extern "C" int srgpt_gemm_rmsnorm(const void* A, const void* W, const void* residual, void* C, int M, int N, int K, void* ws,
-                                  int64_t ws_bytes, const void* norm_w, void* norm_y, float norm_eps, int dtype,
-                                  srgpt_stream_t stream) {
-  SRGPT_CHECK(norm_w && norm_y, SRGPT_ERR_ARG, "srgpt_gemm_rmsnorm: null pointer");
-  SRGPT_CHECK(norm_y != C && norm_y != A, SRGPT_ERR_ARG, "srgpt_gemm_rmsnorm: Y must not alias A or C");
+// C = A W^T + bias + residual (dense rows) and Y = norm(C) in one call (include/srgpt.h; the layer loops of model.hip).  The norm
+// rides in the split-K reduction when the product is split; otherwise it is the ordinary srgpt_rmsnorm / srgpt_layernorm launch --
+// either way the two outputs are bit-identical to srgpt_gemm followed by the norm.
+extern "C" int srgpt_gemm_norm(const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K,
+                               void* ws, int64_t ws_bytes, int norm_kind, const void* norm_w, const void* norm_b, void* Y,
+                               float norm_eps, int dtype, srgpt_stream_t stream) {
+  SRGPT_CHECK(norm_kind == SRGPT_NORM_RMS || norm_kind == SRGPT_NORM_LAYER, SRGPT_ERR_ARG, "srgpt_gemm_norm: unknown norm kind %d",
+              norm_kind);
+  SRGPT_CHECK(norm_w && Y && (norm_kind == SRGPT_NORM_RMS || norm_b), SRGPT_ERR_ARG, "srgpt_gemm_norm: null pointer");
+  SRGPT_CHECK(Y != C, SRGPT_ERR_ARG, "srgpt_gemm_norm: Y must not alias C");  // Y may be A: the norm runs after the product
   bool fused = false;
-  SRGPT_TRY(gemm_impl(A, W, nullptr, residual, C, M, N, K, K, N, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, ws, ws_bytes, dtype,
-                      stream, norm_w, norm_y, norm_eps, &fused));
-  if (!fused) SRGPT_TRY(srgpt_rmsnorm(C, norm_w, norm_y, M, N, norm_eps, dtype, stream));
+  SRGPT_TRY(gemm_impl(A, W, bias, residual, C, M, N, K, K, N, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, ws, ws_bytes, dtype, stream,
+                      norm_kind, norm_w, norm_b, Y, norm_eps, &fused));
+  if (!fused) {
+    if (norm_kind == SRGPT_NORM_RMS) SRGPT_TRY(srgpt_rmsnorm(C, norm_w, Y, M, N, norm_eps, dtype, stream));
+    else SRGPT_TRY(srgpt_layernorm(C, norm_w, norm_b, Y, M, N, norm_eps, SRGPT_ACT_NONE, dtype, stream));
+  }
   return SRGPT_OK;
 }
 

@@ -12,11 +12,13 @@ struct SrgptGemmEpilogue {
   float* partial;  // split-K: fp32 slabs [splits][M][N] (deterministic: reduced in slab order by splitk_reduce_kernel)
   int splits, tiles_per_split;
   const float* wscale;  // fp8 weights (srgpt_gemm_w8): one fp32 scale per output column, applied to the accumulator; else NULL
-  // RMSNorm of the OUTPUT rows, written beside C (srgpt_gemm_rmsnorm: the residual stream and the next block's normalised input from
-  // one pass): fused into the split-K reduction when there is one, a separate srgpt_rmsnorm launch otherwise.  NULL = none.
+  // RMSNorm / LayerNorm of the OUTPUT rows, written beside C (srgpt_gemm_norm: the residual stream and the next block's normalised
+  // input from one pass): fused into the split-K reduction when there is one, a separate norm launch otherwise.  norm_y NULL = none.
   const void* norm_w;
+  const void* norm_b;  // LayerNorm bias (norm_kind SRGPT_NORM_LAYER)
   void* norm_y;
   float norm_eps;
+  int norm_kind;
 };
 typedef SrgptGemmEpilogue Epilogue;
 

@@ -323,20 +323,25 @@ extern "C" int srgpt_vit_forward(const srgpt_vit_weights* w, const void* images,
     SRGPT_HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(v.mlp) + (size_t)I * es, (size_t)IP * es, 0, (size_t)(IP - I) * es,
                                    (size_t)rows, as_stream(stream)),
                   "srgpt_vit_forward: zeroing the activation pad");
+  // The LayerNorm that follows out_proj / fc2 rides in the product's split-K reduction when there is one (srgpt_gemm_norm: bit-identical
+  // to the two launches); ln1 of the first layer is the only stand-alone norm.
   for (int l = 0; l < w->n_layers_run; ++l) {
-    SRGPT_TRY(srgpt_layernorm(x, w->ln1_w[l], w->ln1_b[l], v.h, rows, C, w->eps, SRGPT_ACT_NONE, dt, stream));
+    if (l == 0) SRGPT_TRY(srgpt_layernorm(x, w->ln1_w[l], w->ln1_b[l], v.h, rows, C, w->eps, SRGPT_ACT_NONE, dt, stream));
     SRGPT_TRY(srgpt_gemm(v.h, w->wqkv[l], w->bqkv[l], nullptr, v.qkv, rows, 3 * C, C, C, 3 * C, SRGPT_ACT_NONE, 0, 0, 0,
                          SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt, stream));
     SRGPT_TRY(srgpt_attention(qkv, qkv + (size_t)C * es, qkv + (size_t)2 * C * es, v.h, n_img, L, L, H, H, hd,
                               (int64_t)L * 3 * C, 3 * C, hd, (int64_t)L * 3 * C, 3 * C, hd, (int64_t)L * 3 * C, 3 * C, hd,
                               scale, 0, nullptr, dt, stream));
-    SRGPT_TRY(srgpt_gemm(v.h, w->wo[l], w->bo[l], x, x, rows, C, C, C, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt,
-                         stream));
-    SRGPT_TRY(srgpt_layernorm(x, w->ln2_w[l], w->ln2_b[l], v.h, rows, C, w->eps, SRGPT_ACT_NONE, dt, stream));
+    SRGPT_TRY(srgpt_gemm_norm(v.h, w->wo[l], w->bo[l], x, x, rows, C, C, v.gws, (int64_t)v.gws_bytes, SRGPT_NORM_LAYER, w->ln2_w[l],
+                              w->ln2_b[l], v.h, w->eps, dt, stream));
     SRGPT_TRY(srgpt_gemm(v.h, w->w1[l], w->b1[l], nullptr, v.mlp, rows, I, C, C, IP, w->act, 0, 0, 0,
                          SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt, stream));
-    SRGPT_TRY(srgpt_gemm(v.mlp, w->w2[l], w->b2[l], x, x, rows, C, IP, IP, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, v.gws, (int64_t)v.gws_bytes, dt,
-                         stream));
+    if (l + 1 < w->n_layers_run)
+      SRGPT_TRY(srgpt_gemm_norm(v.mlp, w->w2[l], w->b2[l], x, x, rows, C, IP, v.gws, (int64_t)v.gws_bytes, SRGPT_NORM_LAYER,
+                                w->ln1_w[l + 1], w->ln1_b[l + 1], v.h, w->eps, dt, stream));
+    else
+      SRGPT_TRY(srgpt_gemm(v.mlp, w->w2[l], w->b2[l], x, x, rows, C, IP, IP, C, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, v.gws,
+                           (int64_t)v.gws_bytes, dt, stream));
   }
   return SRGPT_OK;
 }
@@ -443,11 +448,11 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
     SRGPT_TRY(srgpt_attention(l.qkv, kc, vc, l.attn, B, T, T, Hq, Hkv, D, (int64_t)T * QW, QW, D,
                               (int64_t)Hkv * st->max_pos * D, D, (int64_t)st->max_pos * D,
                               (int64_t)Hkv * st->max_pos * D, D, (int64_t)st->max_pos * D, scale, 1, nullptr, dt, stream));
-    // plain weights: the RMSNorm that follows o_proj / down_proj rides in the product's split-K reduction (srgpt_gemm_rmsnorm:
+    // plain weights: the RMSNorm that follows o_proj / down_proj rides in the product's split-K reduction (srgpt_gemm_norm:
     // bit-identical to the two launches, one launch and one pass over the rows less per norm)
     if (plain)
-      SRGPT_TRY(srgpt_gemm_rmsnorm(l.attn, w->wo[i], l.x, l.x, (int)rows, Hd, Hq * D, l.gws, (int64_t)l.gws_bytes, w->mlp_norm[i], l.h,
-                                w->rms_eps, dt, stream));
+      SRGPT_TRY(srgpt_gemm_norm(l.attn, w->wo[i], nullptr, l.x, l.x, (int)rows, Hd, Hq * D, l.gws, (int64_t)l.gws_bytes, SRGPT_NORM_RMS,
+                                w->mlp_norm[i], nullptr, l.h, w->rms_eps, dt, stream));
     else
       SRGPT_TRY(mm(l.attn, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, l.x, l.x, Hd, Hq * D, 0, l.gws,
                    (int64_t)l.gws_bytes));
@@ -463,8 +468,8 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
       SRGPT_TRY(srgpt_silu_mul(l.gu, l.act, rows, I, dt, stream));
       h_ready = plain && i + 1 < w->layers;
       if (h_ready)
-        SRGPT_TRY(srgpt_gemm_rmsnorm(l.act, w->wdown[i], l.x, l.x, (int)rows, Hd, I, l.gws, (int64_t)l.gws_bytes, w->attn_norm[i + 1],
-                                  l.h, w->rms_eps, dt, stream));
+        SRGPT_TRY(srgpt_gemm_norm(l.act, w->wdown[i], nullptr, l.x, l.x, (int)rows, Hd, I, l.gws, (int64_t)l.gws_bytes, SRGPT_NORM_RMS,
+                                  w->attn_norm[i + 1], nullptr, l.h, w->rms_eps, dt, stream));
       else
         SRGPT_TRY(mm(l.act, w->wdown[i], w8 ? w->wdown8[i] : nullptr, w8 ? w->wdown_scale[i] : nullptr, l.x, l.x, Hd, I, 0, l.gws,
                      (int64_t)l.gws_bytes));

@@ -80,11 +80,12 @@ def gemm(a, w, bias=None, residual=None, act=L.ACT_NONE, out=None, out_f32=False
     return out
 
 
-def gemm_rmsnorm(a, w, residual, norm_w, eps, out=None, y=None):
-    """(a @ w.T + residual, rmsnorm(that) * norm_w): the tail of a decoder block and the next block's input norm in one call.
-    `out` may be `residual` (in place).  Bit-identical to gemm(...) followed by rmsnorm(...)."""
-    _dev(a, w, residual, norm_w)
-    _same_dtype("gemm_rmsnorm", a, weight=w, residual=residual, norm_weight=norm_w)
+def gemm_norm(a, w, residual, norm_w, eps, bias=None, norm_b=None, out=None, y=None):
+    """(a @ w.T + bias + residual, norm(that)): the tail of an attention / MLP block and the next block's input norm in one call --
+    RMSNorm (norm_b None: Llama) or LayerNorm (ViT).  `out` may be `residual` (in place), `y` may be `a`.  Bit-identical to gemm(...)
+    followed by rmsnorm(...) / layernorm(...)."""
+    _dev(a, w, residual, norm_w, bias, norm_b)
+    _same_dtype("gemm_norm", a, weight=w, residual=residual, norm_weight=norm_w, bias=bias, norm_bias=norm_b)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and a.is_contiguous() and w.is_contiguous() and (residual is None or residual.is_contiguous())
@@ -93,8 +94,9 @@ def gemm_rmsnorm(a, w, residual, norm_w, eps, out=None, y=None):
     if y is None:
         y = torch.empty((M, N), device=a.device, dtype=a.dtype)
     ws = _splitk_ws(a.device, M, N) if (a.dtype == torch.bfloat16 and M * N <= (1 << 24)) else None
-    L.check(L.load().srgpt_gemm_rmsnorm(_p(a), _p(w), _p(residual), _p(out), M, N, K, _p(ws), 0 if ws is None else ws.numel(),
-                                        _p(norm_w), _p(y), float(eps), dt_code(a), _stream()))
+    kind = L.NORM_RMS if norm_b is None else L.NORM_LAYER
+    L.check(L.load().srgpt_gemm_norm(_p(a), _p(w), _p(bias), _p(residual), _p(out), M, N, K, _p(ws), 0 if ws is None else ws.numel(),
+                                     kind, _p(norm_w), _p(norm_b), _p(y), float(eps), dt_code(a), _stream()))
     return out, y
 
 

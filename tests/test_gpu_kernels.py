@@ -70,26 +70,38 @@ def _gemm_case(dtype, M, N, K):
     assert_close(out3, F.gelu((ref + b.float()).to(dtype).float()), _tol(ref, dtype), 0, "gemm f32 out")
 
 
-# o_proj / down_proj + residual + the next RMSNorm in one call: the norm inside the split-K reduction (small tiles split 2, the
-# whole-M kernel split 8, a 256-row-tile shape), the wide-row variant (N = 8192), and the fallbacks (no split; N > 8192; fp32)
-@pytest.mark.parametrize("dtype,M,N,K", [(torch.bfloat16, 259, 4096, 4096), (torch.bfloat16, 259, 4096, 14336),
-                                         (torch.bfloat16, 707, 4096, 4096), (torch.bfloat16, 259, 8192, 2048),
-                                         (torch.bfloat16, 300, 2560, 6912), (torch.bfloat16, 259, 28672, 512),
-                                         (torch.bfloat16, 64, 16384, 256), (torch.float32, 130, 512, 256)])
-def test_gemm_rmsnorm_equals_the_two_launches(dtype, M, N, K):
+# o_proj / down_proj (+ bias) + residual + the next norm in one call: the norm inside the split-K reduction (small tiles split 2, the
+# whole-M kernel split 8, a 256-row-tile shape, the ViT's out_proj / fc2 with LayerNorm), the wide-row variant (N = 8192), and the
+# fallbacks (no split; N > 8192; fp32)
+@pytest.mark.parametrize("dtype,M,N,K,layer", [(torch.bfloat16, 259, 4096, 4096, False), (torch.bfloat16, 259, 4096, 14336, False),
+                                               (torch.bfloat16, 707, 4096, 4096, False), (torch.bfloat16, 259, 8192, 2048, True),
+                                               (torch.bfloat16, 300, 2560, 6912, False), (torch.bfloat16, 259, 28672, 512, False),
+                                               (torch.bfloat16, 64, 16384, 256, True), (torch.float32, 130, 512, 256, False),
+                                               (torch.bfloat16, 1458, 1152, 1152, True), (torch.bfloat16, 1458, 1152, 4304, True),
+                                               (torch.bfloat16, 1154, 1024, 4096, True), (torch.float32, 100, 256, 128, True)])
+def test_gemm_norm_equals_the_two_launches(dtype, M, N, K, layer):
     ops, L = _ops()
     a, w = _rand((M, K), dtype, 11), _rand((N, K), dtype, 12, 0.05)
     r, g = _rand((M, N), dtype, 13), (1 + 0.1 * _rand((N,), torch.float32, 14)).to(dtype)
+    bias = _rand((N,), dtype, 15) if layer else None
+    nb = _rand((N,), dtype, 16) if layer else None
     a, w, r, g = a.to(DEV), w.to(DEV), r.to(DEV), g.to(DEV)
-    c_ref = ops.gemm(a, w, residual=r)
-    y_ref = ops.rmsnorm(c_ref, g, 1e-5)
-    c, y = ops.gemm_rmsnorm(a, w, r, g, 1e-5)
+    bias, nb = (bias.to(DEV), nb.to(DEV)) if layer else (None, None)
+    c_ref = ops.gemm(a, w, bias, r)
+    y_ref = ops.layernorm(c_ref, g, nb, 1e-6) if layer else ops.rmsnorm(c_ref, g, 1e-5)
+    eps = 1e-6 if layer else 1e-5
+    c, y = ops.gemm_norm(a, w, r, g, eps, bias=bias, norm_b=nb)
     assert torch.equal(c, c_ref) and torch.equal(y, y_ref)
-    x = r.clone()  # in place on the residual stream, as the prefill loop calls it
-    c2, y2 = ops.gemm_rmsnorm(a, w, x, g, 1e-5, out=x)
+    x = r.clone()  # in place on the residual stream and the normalised rows over the product's input, as the layer loops call it
+    if N == K:
+        a2 = a.clone()
+        c2, y2 = ops.gemm_norm(a2, w, x, g, eps, bias=bias, norm_b=nb, out=x, y=a2)
+        assert y2.data_ptr() == a2.data_ptr()
+    else:
+        c2, y2 = ops.gemm_norm(a, w, x, g, eps, bias=bias, norm_b=nb, out=x)
     assert c2.data_ptr() == x.data_ptr() and torch.equal(x, c_ref) and torch.equal(y2, y_ref)
-    ref = (a.float() @ w.float().T).to(dtype).float() + r.float()
-    assert_close(c, ref, _tol(ref, dtype), 0, "gemm_rmsnorm C")
+    ref = (a.float() @ w.float().T + (bias.float() if layer else 0)).to(dtype).float() + r.float()
+    assert_close(c, ref, _tol(ref, dtype), 0, "gemm_norm C")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
