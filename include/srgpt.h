@@ -85,6 +85,14 @@ int srgpt_gemm_norm(const void* A, const void* W, const void* bias, const void* 
                     int64_t ws_bytes, int norm_kind, const void* norm_w, const void* norm_b, void* Y, float norm_eps, int dtype,
                     srgpt_stream_t stream);
 
+/* qkv[B*T, (Hq + 2 Hkv) D] = A[B*T, K] @ W^T, then RoPE on the q and k heads and the append of k / v to the caches -- the q/k/v
+ * projection of a prefill and srgpt_rope_kv_append (below: same arguments, same arithmetic) in one call
+ * (LlamaFlashAttention2.forward modeling_llama.py:398-456).  When the product is split over K the rotation rides in the slab
+ * reduction; otherwise it is the srgpt_rope_kv_append launch.  Every byte written (qkv, kcache, vcache) is the same either way. */
+int srgpt_gemm_rope_kv_append(const void* A, const void* W, void* qkv, int K, void* ws, int64_t ws_bytes, void* kcache,
+                              void* vcache, const int* pos0, const void* cos_tab, const void* sin_tab, int B, int T, int Hq,
+                              int Hkv, int D, int max_pos, int dtype, srgpt_stream_t stream);
+
 /* GEMM with weight-only fp8 quantisation (the prefill-side companion of srgpt_gemv_w8, BASELINE config 5):
  *   C[M,N] = act( (A[M,K] @ fp8(W8[N,K])^T) * wscale[n] + bias[n] ) + residual[M,N]
  * A / bias / residual / C bf16 (C fp32 if out_f32), W8 = OCP e4m3fn bytes, wscale = one fp32 scale per weight row, fp32

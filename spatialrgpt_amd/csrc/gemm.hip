@@ -458,6 +458,69 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(Epilogue e) {
   }
 }
 
+// The slab reduction of the prefill's q/k/v projection with rope_kv_append_kernel (misc.hip) behind it: one block per token row, the
+// reduced row (rounded to bf16 as the plain reduction stores it) goes to LDS, then every (head, pair) is rotated with
+// rope_kv_append_kernel's arithmetic -- q back into the q/k/v buffer, k into the cache at the token's position -- and v is copied
+// into the cache.  The un-rotated k and the v columns are stored to the q/k/v buffer as well, so every byte the two launches write
+// is the same (tests compare all three buffers).
+template <int MAXS>
+__global__ __launch_bounds__(256) void splitk_reduce_rope_kernel(Epilogue e) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t rrow[];
+  const int m = blockIdx.x, nch = e.N / 8;
+  const size_t total = (size_t)e.M * e.N;
+  const int D = e.rope_D, half = D >> 1, Hq = e.rope_Hq, Hkv = e.rope_Hkv;
+  for (int c = threadIdx.x; c < nch; c += 256) {
+    const int n = c * 8;
+    f32x4 p[MAXS][2];
+#pragma unroll
+    for (int z = 0; z < MAXS; ++z) {
+      const float* src = e.partial + (size_t)min(z, e.splits - 1) * total + (size_t)m * e.N + n;
+      p[z][0] = *reinterpret_cast<const f32x4*>(src);
+      p[z][1] = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int z = 0; z < MAXS; ++z)
+      if (z < e.splits) {
+        a0 += p[z][0];
+        a1 += p[z][1];
+      }
+    Vec16<bf16_t> o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      o.set(q, a0[q]);
+      o.set(4 + q, a1[q]);
+    }
+    *reinterpret_cast<Vec16<bf16_t>*>(rrow + n) = o;
+    if (n >= Hq * D) *reinterpret_cast<Vec16<bf16_t>*>(reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc + n) = o;  // k (un-rotated), v
+  }
+  __syncthreads();
+  const int b = m / e.rope_T, t = m - b * e.rope_T;
+  const int pos = (e.rope_pos0 ? e.rope_pos0[b] : 0) + t;
+  const bf16_t* cos_tab = reinterpret_cast<const bf16_t*>(e.rope_cos);
+  const bf16_t* sin_tab = reinterpret_cast<const bf16_t*>(e.rope_sin);
+  bf16_t* qrow = reinterpret_cast<bf16_t*>(e.C) + (size_t)m * e.ldc;
+  const int nrot = (Hq + Hkv) * half;
+  for (int w = threadIdx.x; w < nrot; w += 256) {
+    const int h = w / half, i = w - h * half;
+    const float c = to_f(cos_tab[(size_t)pos * half + i]), s = to_f(sin_tab[(size_t)pos * half + i]);
+    const float x1 = to_f(rrow[h * D + i]), x2 = to_f(rrow[h * D + i + half]);
+    // q*cos + rotate_half(q)*sin with every intermediate materialised in bf16
+    const float o1 = rnd<bf16_t>(rnd<bf16_t>(x1 * c) + rnd<bf16_t>(-x2 * s));
+    const float o2 = rnd<bf16_t>(rnd<bf16_t>(x2 * c) + rnd<bf16_t>(x1 * s));
+    bf16_t* dst = h < Hq ? qrow + (size_t)h * D
+                         : reinterpret_cast<bf16_t*>(e.rope_k) + (((size_t)b * Hkv + (h - Hq)) * e.rope_max_pos + pos) * D;
+    dst[i] = from_f<bf16_t>(o1);
+    dst[i + half] = from_f<bf16_t>(o2);
+  }
+  const bf16_t* vsrc = rrow + (size_t)(Hq + Hkv) * D;
+  bf16_t* vc = reinterpret_cast<bf16_t*>(e.rope_v);
+  for (int w = threadIdx.x; w < Hkv * D; w += 256) {
+    const int h = w / D, i = w - h * D;
+    vc[(((size_t)b * Hkv + h) * e.rope_max_pos + pos) * D + i] = vsrc[w];
+  }
+}
+
 // launches the reduction that fits the epilogue (returns through SRGPT_LAUNCH_CHECK at the call site); true when the RMSNorm the
 // epilogue asks for went into it
 template <typename T>
@@ -465,6 +528,13 @@ static inline bool launch_splitk_reduce(const Epilogue& e, hipStream_t s) {
   const size_t total = (size_t)e.M * e.N;
   const bool vec4 = e.N % 4 == 0 && e.ldc % 4 == 0 && e.out_mode != SRGPT_OUT_DECONV2X && e.bias_mod <= 0 && e.res_mod <= 0 &&
                     e.splits <= 8 && ((uintptr_t)e.C % 16 == 0);
+  if (e.rope_k && std::is_same<T, bf16_t>::value && vec4 && !e.out_f32 && !e.bias && !e.residual && !e.wscale &&
+      e.act == SRGPT_ACT_NONE && e.N % 8 == 0 && e.ldc % 8 == 0 && e.N <= 24576) {
+    const size_t lds = (size_t)e.N * sizeof(bf16_t);  // <= 48 KB
+    if (e.splits <= 4) hipLaunchKernelGGL((splitk_reduce_rope_kernel<4>), dim3(e.M), dim3(256), lds, s, e);
+    else hipLaunchKernelGGL((splitk_reduce_rope_kernel<8>), dim3(e.M), dim3(256), lds, s, e);
+    return true;
+  }
   if (e.norm_y && std::is_same<T, bf16_t>::value && vec4 && !e.out_f32 && e.N % 8 == 0 && e.ldc % 8 == 0 && e.N <= 8192 &&
       ((uintptr_t)e.norm_y % 16 == 0) && ((uintptr_t)e.norm_w % 16 == 0) && (!e.norm_b || (uintptr_t)e.norm_b % 16 == 0) &&
       (!e.residual || (uintptr_t)e.residual % 16 == 0)) {
@@ -601,7 +671,7 @@ extern "C" int64_t srgpt_gemm_ws_bytes(int M, int N) { return (int64_t)8 * M * N
 static int gemm_impl(const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K, int lda,
                      int ldc, int act, int bias_mod, int res_mod, int out_f32, int out_mode, int gw, void* ws, int64_t ws_bytes,
                      int dtype, srgpt_stream_t stream, int norm_kind, const void* norm_w, const void* norm_b, void* norm_y, float norm_eps,
-                     bool* norm_done) {
+                     bool* norm_done, const Epilogue* rope = nullptr) {
   SRGPT_CHECK(A && W && C, SRGPT_ERR_ARG, "srgpt_gemm: null pointer");
   SRGPT_CHECK(M > 0 && N > 0 && K > 0, SRGPT_ERR_ARG, "srgpt_gemm: bad shape M=%d N=%d K=%d", M, N, K);
   SRGPT_CHECK(dtype == SRGPT_F32 || dtype == SRGPT_BF16, SRGPT_ERR_ARG, "srgpt_gemm: bad dtype %d", dtype);
@@ -616,6 +686,11 @@ static int gemm_impl(const void* A, const void* W, const void* bias, const void*
     SRGPT_CHECK(ldc >= N, SRGPT_ERR_ARG, "srgpt_gemm: ldc < N");
   }
   Epilogue e{bias, residual, C, M, N, ldc, act, bias_mod, res_mod, out_f32, out_mode, gw, nullptr, 1, 0, nullptr, norm_w, norm_b, norm_y, norm_eps, norm_kind};
+  if (rope) {
+    e.rope_k = rope->rope_k, e.rope_v = rope->rope_v, e.rope_pos0 = rope->rope_pos0, e.rope_cos = rope->rope_cos;
+    e.rope_sin = rope->rope_sin, e.rope_T = rope->rope_T, e.rope_Hq = rope->rope_Hq, e.rope_Hkv = rope->rope_Hkv;
+    e.rope_D = rope->rope_D, e.rope_max_pos = rope->rope_max_pos;
+  }
   hipStream_t s = as_stream(stream);
   if (dtype == SRGPT_F32) {
     dim3 grid(cdiv(N, 64), cdiv(M, 64));
@@ -829,6 +904,26 @@ extern "C" int srgpt_gemm_norm(const void* A, const void* W, const void* bias, c
     if (norm_kind == SRGPT_NORM_RMS) SRGPT_TRY(srgpt_rmsnorm(C, norm_w, Y, M, N, norm_eps, dtype, stream));
     else SRGPT_TRY(srgpt_layernorm(C, norm_w, norm_b, Y, M, N, norm_eps, SRGPT_ACT_NONE, dtype, stream));
   }
+  return SRGPT_OK;
+}
+
+// qkv = A W^T for the B * T token rows of a prefill, then RoPE on q (in place) and k, k and v appended to the caches -- the
+// projection and srgpt_rope_kv_append in one call (include/srgpt.h).  The rotation rides in the split-K reduction when the product is
+// split; otherwise it is the ordinary srgpt_rope_kv_append launch.  Every byte written is the same either way.
+extern "C" int srgpt_gemm_rope_kv_append(const void* A, const void* W, void* qkv, int K, void* ws, int64_t ws_bytes, void* kcache,
+                                         void* vcache, const int* pos0, const void* cos_tab, const void* sin_tab, int B, int T_,
+                                         int Hq, int Hkv, int D, int max_pos, int dtype, srgpt_stream_t stream) {
+  SRGPT_CHECK(qkv && kcache && vcache && cos_tab && sin_tab, SRGPT_ERR_ARG, "srgpt_gemm_rope_kv_append: null pointer");
+  SRGPT_CHECK(B > 0 && T_ > 0 && Hq > 0 && Hkv > 0 && D > 0 && (D & 1) == 0 && T_ <= max_pos, SRGPT_ERR_ARG,
+              "srgpt_gemm_rope_kv_append: bad shape");
+  const int M = B * T_, N = (Hq + 2 * Hkv) * D;
+  Epilogue r{};
+  r.rope_k = kcache, r.rope_v = vcache, r.rope_pos0 = pos0, r.rope_cos = cos_tab, r.rope_sin = sin_tab;
+  r.rope_T = T_, r.rope_Hq = Hq, r.rope_Hkv = Hkv, r.rope_D = D, r.rope_max_pos = max_pos;
+  bool fused = false;
+  SRGPT_TRY(gemm_impl(A, W, nullptr, nullptr, qkv, M, N, K, K, N, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, ws, ws_bytes, dtype,
+                      stream, 0, nullptr, nullptr, nullptr, 0.f, &fused, &r));
+  if (!fused) SRGPT_TRY(srgpt_rope_kv_append(qkv, kcache, vcache, pos0, cos_tab, sin_tab, B, T_, Hq, Hkv, D, max_pos, dtype, stream));
   return SRGPT_OK;
 }
 

@@ -19,6 +19,13 @@ struct SrgptGemmEpilogue {
   void* norm_y;
   float norm_eps;
   int norm_kind;
+  // RoPE + KV-cache append of the OUTPUT rows (srgpt_gemm_rope_kv_append: the q/k/v projection of the prefill): rope_k NULL = none
+  void* rope_k;
+  void* rope_v;
+  const int* rope_pos0;
+  const void* rope_cos;
+  const void* rope_sin;
+  int rope_T, rope_Hq, rope_Hkv, rope_D, rope_max_pos;
 };
 typedef SrgptGemmEpilogue Epilogue;
 

@@ -440,11 +440,16 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
       SRGPT_TRY(mm8(w->wqkv8[i], w->wqkv_scale[i], nullptr, l.qkv, QW, Hd));
     } else {
       if (!h_ready) SRGPT_TRY(srgpt_rmsnorm(l.x, w->attn_norm[i], l.h, rows, Hd, w->rms_eps, dt, stream));
-      SRGPT_TRY(mm(l.h, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, nullptr, l.qkv, QW, Hd, 0, l.gws,
-                   (int64_t)l.gws_bytes));
+      if (!plain)
+        SRGPT_TRY(mm(l.h, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, nullptr, l.qkv, QW, Hd, 0, l.gws,
+                     (int64_t)l.gws_bytes));
     }
-    SRGPT_TRY(srgpt_rope_kv_append(l.qkv, kc, vc, nullptr, w->rope_cos, w->rope_sin, B, T, Hq, Hkv, D, st->max_pos, dt,
-                                   stream));
+    if (plain && !fuse8)  // projection + RoPE + cache append: the rotation rides in the split-K reduction
+      SRGPT_TRY(srgpt_gemm_rope_kv_append(l.h, w->wqkv[i], l.qkv, Hd, l.gws, (int64_t)l.gws_bytes, kc, vc, nullptr, w->rope_cos,
+                                          w->rope_sin, B, T, Hq, Hkv, D, st->max_pos, dt, stream));
+    else
+      SRGPT_TRY(srgpt_rope_kv_append(l.qkv, kc, vc, nullptr, w->rope_cos, w->rope_sin, B, T, Hq, Hkv, D, st->max_pos, dt,
+                                     stream));
     SRGPT_TRY(srgpt_attention(l.qkv, kc, vc, l.attn, B, T, T, Hq, Hkv, D, (int64_t)T * QW, QW, D,
                               (int64_t)Hkv * st->max_pos * D, D, (int64_t)st->max_pos * D,
                               (int64_t)Hkv * st->max_pos * D, D, (int64_t)st->max_pos * D, scale, 1, nullptr, dt, stream));

@@ -258,6 +258,22 @@ def attention(q, k, v, causal=False, scale=None, kv_len=None):
     return o
 
 
+def gemm_rope_kv_append(a, w, kcache, vcache, cos_tab, sin_tab, B, T, Hq, Hkv, D, pos0=None, qkv=None):
+    """qkv = a @ w.T for the B * T token rows, RoPE on q (in qkv) and k, k / v appended to the caches: gemm + rope_kv_append in one call."""
+    _dev(a, w, kcache, vcache, cos_tab, sin_tab)
+    M, K = a.shape
+    N = (Hq + 2 * Hkv) * D
+    assert M == B * T and w.shape == (N, K) and a.is_contiguous() and w.is_contiguous()
+    if qkv is None:
+        qkv = torch.empty((M, N), device=a.device, dtype=a.dtype)
+    ws = _splitk_ws(a.device, M, N) if (a.dtype == torch.bfloat16 and M * N <= (1 << 24)) else None
+    max_pos = kcache.shape[-2]
+    L.check(L.load().srgpt_gemm_rope_kv_append(_p(a), _p(w), _p(qkv), K, _p(ws), 0 if ws is None else ws.numel(), _p(kcache),
+                                               _p(vcache), _p(pos0), _p(cos_tab), _p(sin_tab), B, T, Hq, Hkv, D, max_pos,
+                                               dt_code(a), _stream()))
+    return qkv
+
+
 def rope_kv_append(qkv, kcache, vcache, cos_tab, sin_tab, B, T, Hq, Hkv, D, pos0=None):
     _dev(qkv, kcache, vcache, cos_tab, sin_tab)
     max_pos = kcache.shape[-2]

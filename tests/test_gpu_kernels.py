@@ -104,6 +104,35 @@ def test_gemm_norm_equals_the_two_launches(dtype, M, N, K, layer):
     assert_close(c, ref, _tol(ref, dtype), 0, "gemm_norm C")
 
 
+# the prefill's q/k/v projection with RoPE + cache append inside the split-K reduction: Llama-3 geometry (whole-M kernel, 5 splits),
+# Llama-2-7B (MHA: N = 12288), a 2 x 100-row batch with a position offset (small tiles), 707 rows, and the fallbacks (no split; fp32)
+@pytest.mark.parametrize("dtype,B,T,Hq,Hkv,D,K,off", [(torch.bfloat16, 1, 259, 32, 8, 128, 4096, False),
+                                                      (torch.bfloat16, 1, 259, 32, 32, 128, 4096, False),
+                                                      (torch.bfloat16, 2, 100, 32, 8, 128, 4096, True),
+                                                      (torch.bfloat16, 1, 707, 32, 8, 128, 4096, False),
+                                                      (torch.bfloat16, 1, 300, 20, 20, 128, 2560, False),
+                                                      (torch.bfloat16, 3, 40, 4, 2, 64, 128, True),
+                                                      (torch.float32, 2, 30, 4, 2, 32, 64, True)])
+def test_gemm_rope_kv_append_equals_the_two_launches(dtype, B, T, Hq, Hkv, D, K, off):
+    ops, L = _ops()
+    from spatialrgpt_amd.config import SrgptConfig as PC
+    from spatialrgpt_amd.weights import rope_tables
+    max_pos = 1024
+    N = (Hq + 2 * Hkv) * D
+    cos_t, sin_t = rope_tables(PC(hidden=Hq * D, heads=Hq, kv_heads=Hkv, rope_theta=500000.0), max_pos, dtype, DEV)
+    a, w = _rand((B * T, K), dtype, 21).to(DEV), _rand((N, K), dtype, 22, 0.05).to(DEV)
+    pos0 = torch.tensor([7 * (b + 1) for b in range(B)], dtype=torch.int32, device=DEV) if off else None
+    kc_ref = torch.zeros((B, Hkv, max_pos, D), device=DEV, dtype=dtype)
+    vc_ref = torch.zeros_like(kc_ref)
+    qkv_ref = ops.gemm(a, w)
+    ops.rope_kv_append(qkv_ref, kc_ref, vc_ref, cos_t, sin_t, B, T, Hq, Hkv, D, pos0=pos0)
+    kc, vc = torch.zeros_like(kc_ref), torch.zeros_like(kc_ref)
+    qkv = ops.gemm_rope_kv_append(a, w, kc, vc, cos_t, sin_t, B, T, Hq, Hkv, D, pos0=pos0)
+    assert torch.equal(qkv[:, :Hq * D], qkv_ref[:, :Hq * D]), "rotated q"
+    assert torch.equal(kc, kc_ref) and torch.equal(vc, vc_ref), "caches"
+    assert torch.equal(qkv, qkv_ref), "the k / v columns of the q/k/v buffer"
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_strided_a_and_row_modulo_residual(dtype):
     ops, L = _ops()
