@@ -85,6 +85,14 @@ int srgpt_gemm_norm(const void* A, const void* W, const void* bias, const void* 
                     int64_t ws_bytes, int norm_kind, const void* norm_w, const void* norm_b, void* Y, float norm_eps, int dtype,
                     srgpt_stream_t stream);
 
+/* out[M, I] = silu(A @ Wg^T) * (A @ Wu^T) for the stacked weight Wgu = [Wg; Wu] ([2 I, K], the layout srgpt_gemv's swiglu mode
+ * reads) -- LlamaMLP's gate / up products and srgpt_silu_mul (below) in one call (modeling_llama.py:194-223).  At 225 .. 272 rows
+ * (the bs = 1 prefill) the activation is the epilogue of the product and the [M, 2 I] intermediate is never written; every other
+ * shape runs srgpt_gemm into gu_scratch ([M, 2 I], may be NULL only when the fused form applies) and srgpt_silu_mul.  Either way
+ * the result is srgpt_gemm + srgpt_silu_mul to the last bit. */
+int srgpt_gemm_swiglu(const void* A, const void* Wgu, void* out, int M, int I, int K, void* gu_scratch, void* ws,
+                      int64_t ws_bytes, int dtype, srgpt_stream_t stream);
+
 /* qkv[B*T, (Hq + 2 Hkv) D] = A[B*T, K] @ W^T, then RoPE on the q and k heads and the append of k / v to the caches -- the q/k/v
  * projection of a prefill and srgpt_rope_kv_append (below: same arguments, same arithmetic) in one call
  * (LlamaFlashAttention2.forward modeling_llama.py:398-456).  When the product is split over K the rotation rides in the slab

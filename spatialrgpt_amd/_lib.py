@@ -78,6 +78,7 @@ _SIGNATURES = {
     "srgpt_gemm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
     "srgpt_gemm_norm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, i32, vp, vp, vp, f32, i32, vp]),
     "srgpt_gemm_rope_kv_append": (i32, [vp, vp, vp, i32, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "srgpt_gemm_swiglu": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, i64, i32, vp]),
     "srgpt_gemm_w8": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i64, vp]),
     "srgpt_quant_rows_e4m3": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "srgpt_quant_rows_e4m3_rmsnorm": (i32, [vp, vp, f32, vp, vp, i32, i32, i32, vp]),

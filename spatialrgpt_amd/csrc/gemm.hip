@@ -927,6 +927,29 @@ extern "C" int srgpt_gemm_rope_kv_append(const void* A, const void* W, void* qkv
   return SRGPT_OK;
 }
 
+// out[M, I] = rnd(rnd(silu(A Wg^T)) * (A Wu^T)) for the stacked weight Wgu = [Wg; Wu] ([2 I, K]) -- LlamaMLP's gate / up products and
+// srgpt_silu_mul in one call (include/srgpt.h).  On the whole-M kernel (225 .. 272 rows: the bs = 1 prefill) a block multiplies 64
+// gate columns and the 64 matching up columns and the activation is its epilogue: the [M, 2 I] intermediate is neither written nor
+// read.  Every other shape runs srgpt_gemm into `gu_scratch` and srgpt_silu_mul -- the result is the same to the last bit.
+extern "C" int srgpt_gemm_swiglu(const void* A, const void* Wgu, void* out, int M, int I, int K, void* gu_scratch, void* ws,
+                                 int64_t ws_bytes, int dtype, srgpt_stream_t stream) {
+  SRGPT_CHECK(A && Wgu && out, SRGPT_ERR_ARG, "srgpt_gemm_swiglu: null pointer");
+  SRGPT_CHECK(M > 0 && I > 0 && K > 0, SRGPT_ERR_ARG, "srgpt_gemm_swiglu: bad shape M=%d I=%d K=%d", M, I, K);
+  const int mode = SRGPT_KNOB("SRGPT_GEMM_SWIGLU", 1);  // tuning build: 0 = always the two launches
+  const bool fused = mode != 0 && dtype == SRGPT_BF16 && M > 224 && M <= 272 && K % 64 == 0 && K / 64 >= 4 && I % 64 == 0 &&
+                     I / 64 >= srgpt_device_cus() / 2 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)Wgu % 16 == 0);
+  if (fused) {
+    Epilogue e{};
+    e.C = out, e.M = M, e.N = I, e.ldc = I, e.act = SRGPT_ACT_NONE, e.splits = 1, e.swiglu_inter = I;
+    SRGPT_TRY(srgpt_gemm288_launch(A, Wgu, K, K, e, as_stream(stream)));
+    return SRGPT_OK;
+  }
+  SRGPT_CHECK(gu_scratch, SRGPT_ERR_ARG, "srgpt_gemm_swiglu: this shape needs the [M, 2 I] scratch buffer");
+  SRGPT_TRY(srgpt_gemm(A, Wgu, nullptr, nullptr, gu_scratch, M, 2 * I, K, K, 2 * I, SRGPT_ACT_NONE, 0, 0, 0, SRGPT_OUT_PLAIN, 0, ws,
+                       ws_bytes, dtype, stream));
+  return srgpt_silu_mul(gu_scratch, out, M, I, dtype, stream);
+}
+
 extern "C" int srgpt_gemm_w8(const void* A, const void* W8, const float* wscale, const void* bias, const void* residual,
                              void* C, int M, int N, int K, int lda, int ldc, int act, int out_f32, void* ws,
                              int64_t ws_bytes, srgpt_stream_t stream) {

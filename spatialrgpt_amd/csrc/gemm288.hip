@@ -49,7 +49,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_288_kernel(const bf16_t* __r
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = blockIdx.x * T_BN, m0 = blockIdx.z * T_BM;
+  // SwiGLU mode: the block's 128 W rows are 64 gate rows and the 64 up rows of the same outputs (tile rows 64 .. 127)
+  const int swi = e.swiglu_inter;
+  const int n0 = blockIdx.x * (swi ? T_BN / 2 : T_BN), m0 = blockIdx.z * T_BM;
 
   const int nk_all = K / T_BK;
   const int kt0 = e.splits > 1 ? (int)blockIdx.y * e.tiles_per_split : 0;
@@ -68,7 +70,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_288_kernel(const bf16_t* __r
 #pragma unroll
   for (int i = 0; i < 4; ++i) pa[i] = A + (size_t)min(m0 + (wave + 8 * i) * 8 + lr, e.M - 1) * lda + lc * 8;  // A groups 0 .. 31
 #pragma unroll
-  for (int i = 0; i < 2; ++i) pw[i] = W + (size_t)min(n0 + (wave + 8 * i) * 8 + lr, e.N - 1) * K + lc * 8;    // W groups 0 .. 15
+  for (int i = 0; i < 2; ++i) {  // W groups 0 .. 15
+    const int r = (wave + 8 * i) * 8 + lr;  // row of the W tile
+    const int wrow = swi ? (r < 64 ? n0 + r : swi + n0 + r - 64) : min(n0 + r, e.N - 1);
+    pw[i] = W + (size_t)wrow * K + lc * 8;
+  }
   const bf16_t* ptl = A + (size_t)min(m0 + T_MAIN + wave * 8 + lr, e.M - 1) * lda + lc * 8;                    // A group 32 + wave
   auto dma = [&](const void* s_, int lds_off) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,
@@ -266,6 +272,52 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_288_kernel(const bf16_t* __r
 }
 
   // ---- epilogue.  32x32 D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
+  if (swi) {
+    // gate lives in the waves with wn = 0 (tail: waves 0 - 3), up in their partners: the bf16-rounded products change hands through
+    // the LDS the K tiles no longer need (every wave has passed the last barrier: all stages are read and all requests have landed),
+    // then each wave finishes half of the pair's tiles with silu_mul_kernel's arithmetic: rnd(rnd(silu(g)) * u)
+    float* xw = reinterpret_cast<float*>(lds) + (size_t)wave * (4 * 16 + 4) * 64;  // [tile][reg][lane] + the tail's [reg][lane]
+    T_BARRIER();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xw[(t * 16 + r) * 64 + lane] = rnd<bf16_t>(acc[t][r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xw[(64 + r) * 64 + lane] = rnd<bf16_t>(acct[r]);
+    T_BARRIER();
+    const float* xp = reinterpret_cast<const float*>(lds) + (size_t)(wave ^ 1) * (4 * 16 + 4) * 64;  // the partner (wm, wn ^ 1)
+    bf16_t* C = reinterpret_cast<bf16_t*>(e.C);
+    auto finish = [&](auto t_c, auto mine_is_gate) {  // static tile index: a run-time index would move the accumulators to scratch
+      constexpr int t = decltype(t_c)::value;
+      constexpr bool own_gate = decltype(mine_is_gate)::value;
+      const int n = n0 + (t & 1) * 32 + l31;
+      const int mb = m0 + wm * 64 + (t >> 1) * 32 + 4 * hi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float own = rnd<bf16_t>(acc[t][r]), oth = xp[(t * 16 + r) * 64 + lane];
+        const float gv = own_gate ? own : oth, uv = own_gate ? oth : own;
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m < e.M) C[(size_t)m * e.ldc + n] = (bf16_t)(rnd<bf16_t>(silu(gv)) * uv);
+      }
+    };
+    if (wn == 0) {  // wn = 0 finishes tiles 0, 1 of the pair, wn = 1 tiles 2, 3
+      finish(std::integral_constant<int, 0>{}, std::true_type{});
+      finish(std::integral_constant<int, 1>{}, std::true_type{});
+    } else {
+      finish(std::integral_constant<int, 2>{}, std::false_type{});
+      finish(std::integral_constant<int, 3>{}, std::false_type{});
+    }
+    if (has_tail && wave < 4) {  // tail columns 16 w .. 16 w + 15: gate in wave w, up in wave w + 4
+      const float* xt = reinterpret_cast<const float*>(lds) + (size_t)(wave + 4) * (4 * 16 + 4) * 64;
+      const int n = n0 + wave * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + T_MAIN + 4 * g4 + r;
+        if (m < e.M) C[(size_t)m * e.ldc + n] = (bf16_t)(rnd<bf16_t>(silu(rnd<bf16_t>(acct[r]))) * xt[(64 + r) * 64 + lane]);
+      }
+    }
+    return;
+  }
   float* slab = e.splits > 1 ? e.partial + (size_t)blockIdx.y * e.M * e.N : nullptr;
 #pragma clang loop unroll(full)
   for (int t = 0; t < 4; ++t) {
@@ -306,7 +358,7 @@ int srgpt_gemm288_launch(const void* A, const void* W, int K, int lda, const Epi
   do {                                                                                                                          \
     static std::atomic<uint64_t> attr_done{0};                                                                                  \
     SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)gemm_bf16_288_kernel<AB, ST>, T_LDS));                                   \
-    hipLaunchKernelGGL((gemm_bf16_288_kernel<AB, ST>), dim3(cdiv(e.N, T_BN), e.splits > 1 ? e.splits : 1, cdiv(e.M, T_BM)), dim3(512), \
+    hipLaunchKernelGGL((gemm_bf16_288_kernel<AB, ST>), dim3(e.swiglu_inter ? e.swiglu_inter / (T_BN / 2) : cdiv(e.N, T_BN), e.splits > 1 ? e.splits : 1, cdiv(e.M, T_BM)), dim3(512), \
                        T_LDS, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);                                                \
   } while (0)
 #ifdef SRGPT_TUNING_KNOBS

@@ -26,6 +26,9 @@ struct SrgptGemmEpilogue {
   const void* rope_cos;
   const void* rope_sin;
   int rope_T, rope_Hq, rope_Hkv, rope_D, rope_max_pos;
+  // SwiGLU of a stacked [gate; up] weight (srgpt_gemm_swiglu, whole-M kernel only): W is [2 * swiglu_inter, K], a block multiplies 64
+  // gate and the 64 matching up columns, C is [M, swiglu_inter] = rnd(rnd(silu(gate)) * up).  0 = none.
+  int swiglu_inter;
 };
 typedef SrgptGemmEpilogue Epilogue;
 

@@ -468,9 +468,13 @@ static int prefill_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, const v
       SRGPT_TRY(mm8(w->wdown8[i], w->wdown_scale[i], l.x, l.x, Hd, I));
     } else {
       if (!plain) SRGPT_TRY(srgpt_rmsnorm(l.x, w->mlp_norm[i], l.h, rows, Hd, w->rms_eps, dt, stream));
-      SRGPT_TRY(mm(l.h, w->wgu[i], w8 ? w->wgu8[i] : nullptr, w8 ? w->wgu_scale[i] : nullptr, nullptr, l.gu, 2 * I, Hd, 0, l.gws,
-                   (int64_t)l.gws_bytes));
-      SRGPT_TRY(srgpt_silu_mul(l.gu, l.act, rows, I, dt, stream));
+      if (plain) {  // gate / up + SiLU * up: the activation is the product's epilogue on the whole-M kernel
+        SRGPT_TRY(srgpt_gemm_swiglu(l.h, w->wgu[i], l.act, (int)rows, I, Hd, l.gu, l.gws, (int64_t)l.gws_bytes, dt, stream));
+      } else {
+        SRGPT_TRY(mm(l.h, w->wgu[i], w8 ? w->wgu8[i] : nullptr, w8 ? w->wgu_scale[i] : nullptr, nullptr, l.gu, 2 * I, Hd, 0, l.gws,
+                     (int64_t)l.gws_bytes));
+        SRGPT_TRY(srgpt_silu_mul(l.gu, l.act, rows, I, dt, stream));
+      }
       h_ready = plain && i + 1 < w->layers;
       if (h_ready)
         SRGPT_TRY(srgpt_gemm_norm(l.act, w->wdown[i], nullptr, l.x, l.x, (int)rows, Hd, I, l.gws, (int64_t)l.gws_bytes, SRGPT_NORM_RMS,

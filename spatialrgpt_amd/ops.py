@@ -258,6 +258,22 @@ def attention(q, k, v, causal=False, scale=None, kv_len=None):
     return o
 
 
+def gemm_swiglu(a, wgu, out=None):
+    """silu(a @ wg.T) * (a @ wu.T) for the stacked weight wgu = [wg; wu] ([2 I, K]): gemm + silu_mul in one call."""
+    _dev(a, wgu)
+    _same_dtype("gemm_swiglu", a, weight=wgu)
+    M, K = a.shape
+    I = wgu.shape[0] // 2
+    assert wgu.shape == (2 * I, K) and a.is_contiguous() and wgu.is_contiguous()
+    if out is None:
+        out = torch.empty((M, I), device=a.device, dtype=a.dtype)
+    scratch = torch.empty((M, 2 * I), device=a.device, dtype=a.dtype)
+    ws = _splitk_ws(a.device, M, 2 * I) if (a.dtype == torch.bfloat16 and M * 2 * I <= (1 << 24)) else None
+    L.check(L.load().srgpt_gemm_swiglu(_p(a), _p(wgu), _p(out), M, I, K, _p(scratch), _p(ws), 0 if ws is None else ws.numel(),
+                                       dt_code(a), _stream()))
+    return out
+
+
 def gemm_rope_kv_append(a, w, kcache, vcache, cos_tab, sin_tab, B, T, Hq, Hkv, D, pos0=None, qkv=None):
     """qkv = a @ w.T for the B * T token rows, RoPE on q (in qkv) and k, k / v appended to the caches: gemm + rope_kv_append in one call."""
     _dev(a, w, kcache, vcache, cos_tab, sin_tab)

@@ -133,6 +133,20 @@ def test_gemm_rope_kv_append_equals_the_two_launches(dtype, B, T, Hq, Hkv, D, K,
     assert torch.equal(qkv, qkv_ref), "the k / v columns of the q/k/v buffer"
 
 
+# LlamaMLP's gate / up products + SiLU * up in one call: the whole-M kernel with the activation as its epilogue (Llama-3, Llama-2-7B
+# and a no-tail-row shape), and the shapes that fall back to the two launches (too few columns; other row counts; fp32)
+@pytest.mark.parametrize("dtype,M,I,K", [(torch.bfloat16, 259, 14336, 4096), (torch.bfloat16, 272, 11008, 4096),
+                                         (torch.bfloat16, 240, 8192, 1024), (torch.bfloat16, 259, 6912, 2560),
+                                         (torch.bfloat16, 1036, 2048, 512), (torch.bfloat16, 100, 512, 256),
+                                         (torch.float32, 64, 256, 128)])
+def test_gemm_swiglu_equals_the_two_launches(dtype, M, I, K):
+    ops, L = _ops()
+    a, w = _rand((M, K), dtype, 31).to(DEV), _rand((2 * I, K), dtype, 32, 0.05).to(DEV)
+    ref = ops.silu_mul(ops.gemm(a, w))
+    out = ops.gemm_swiglu(a, w)
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_strided_a_and_row_modulo_residual(dtype):
     ops, L = _ops()
