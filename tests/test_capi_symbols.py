@@ -88,3 +88,18 @@ def test_argument_validation_without_gpu():
     assert lib.srgpt_sample_ws_bytes(2) == 2 * 128 * 64 * 8 + 2 * 128 * 8 + 256
     rc = lib.srgpt_sample(16, 16, 16, 16, 1, 128 * 2048 + 1, None)  # vocabulary beyond 128 slices x 2048 entries
     assert rc == _lib.ERR_UNSUPPORTED and b"vocabulary" in lib.srgpt_last_error()
+    # ABI 7: the fused prefill entry points validate on the host before any launch
+    rc = lib.srgpt_gemm_norm(16, 16, None, None, 16, 4, 8, 8, None, 0, 3, 16, None, 32, 1e-5, _lib.BF16, None)  # unknown norm kind
+    assert rc == _lib.ERR_ARG and b"norm kind" in lib.srgpt_last_error()
+    rc = lib.srgpt_gemm_norm(16, 16, None, None, 16, 4, 8, 8, None, 0, _lib.NORM_LAYER, 16, None, 32, 1e-5, _lib.BF16, None)  # LayerNorm without its bias
+    assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
+    rc = lib.srgpt_gemm_norm(16, 16, None, None, 32, 4, 8, 8, None, 0, _lib.NORM_RMS, 16, None, 32, 1e-5, _lib.BF16, None)  # Y aliases C
+    assert rc == _lib.ERR_ARG and b"alias" in lib.srgpt_last_error()
+    rc = lib.srgpt_gemm_rope_kv_append(16, 16, 16, 64, None, 0, None, 16, None, 16, 16, 1, 4, 2, 1, 32, 8, _lib.BF16, None)  # no k cache
+    assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
+    rc = lib.srgpt_gemm_rope_kv_append(16, 16, 16, 64, None, 0, 16, 16, None, 16, 16, 1, 9, 2, 1, 32, 8, _lib.BF16, None)  # T > max_pos
+    assert rc == _lib.ERR_ARG and b"bad shape" in lib.srgpt_last_error()
+    rc = lib.srgpt_gemm_swiglu(16, None, 16, 4, 64, 64, None, None, 0, _lib.BF16, None)
+    assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
+    rc = lib.srgpt_gemm_swiglu(16, 16, 16, 4, 64, 64, None, None, 0, _lib.BF16, None)  # a shape that needs the [M, 2 I] scratch
+    assert rc == _lib.ERR_ARG and b"scratch" in lib.srgpt_last_error()
