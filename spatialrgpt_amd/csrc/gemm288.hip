@@ -1,21 +1,27 @@
-// bf16 MFMA GEMM for the bs = 1 prefill products: ALL rows of a 257..288-row activation (T = 259 at BASELINE configs[1]) in one
-// block.  C[M,N] = epilogue(A[M,K] @ W[N,K]^T), both operands K-contiguous, 288 x 128 x 64 block tile, 9 waves.
+// bf16 MFMA GEMM for the bs = 1 prefill products: ALL rows of a 225 .. 272-row activation (T = 259 at BASELINE configs[1]) in one
+// block.  C[M,N] = epilogue(A[M,K] @ W[N,K]^T), both operands K-contiguous, 272 x 128 x 64 block tile, 8 waves.
 //
 // Why a kernel of its own: at M = 259 the product sits on the ridge (259 flop per weight byte against ~312 for the chip), so it
 // has to stream W at HBM rate AND keep the matrix pipe fed.  The 96 x 128 tiles of gemm.hip read every W tile three times (once
 // per row tile; L2 absorbs most of it) and move 17.8 B through the global -> LDS path per kFLOP; here W crosses that path once
-// (11 B / kFLOP) and a block's HBM requests are three K tiles deep:
-//   * waves: 9 x (32 rows x 128 columns) = 4 accumulators of v_mfma_f32_32x32x16_bf16 each (64 VGPRs); a SIMD holds 2 - 3 waves
-//   * LDS: THREE stages x (A 288 x 64 + W 128 x 64) bf16 = 156 KiB (+ 2 KiB scratch), rows of 128 B in 16-byte slots,
-//     slot ^ ((row >> 1) & 7) (gemm256's conflict-free ds_read_b128 layout), filled by LDS-DMA (global_load_lds_dwordx4: one
-//     wave-instruction = 8 rows x 128 B).  Per K tile a wave issues 4 A groups + 2 W groups (wave 8, which has no W group left
-//     of the 16, aims its two at the scratch area so that every wave's counted wait is the same immediate)
-//   * one barrier per K tile: top of tile t = [vmcnt(6): my groups of tile t landed, tile t + 1's may fly] -> barrier -> request
-//     tile t + 2 into the stage tile t - 1 just left -> 4 k-steps of (fragment reads one step ahead, 4 MFMAs).  A request is two
-//     whole K tiles old when it is waited for.  (The round-4 probe of this shape -- profiles/r04_tall_gemm_probe.txt -- kept A out
-//     of LDS and W one tile deep: A fragments from L2 bound it, and one tile of prefetch per CU cannot cover HBM latency.)
-//   * split-K over blockIdx.y for the narrow products (deterministic fp32 slabs, reduced by splitk_reduce_kernel of gemm.hip)
-// Requirements (checked by the launcher): K % 64 == 0.  Selected by srgpt_gemm for 224 < M <= 288 when the grid fills the chip.
+// (11 B / kFLOP) and a block's requests are two K tiles ahead.  profiles/r04_gemm288.txt has the build-up with numbers (9 waves x
+// 32 rows -> this form; lockstep -> staggered; the variants that lost) and the ablations that name the two ceilings: the L2 -> LDS
+// path (717 MB per gate/up launch, 71 us alone) and the matrix pipe (49 us alone at the sustained clock).
+//   * waves 4 (M) x 2 (N): a wave owns 64 x 64 of C = 2 x 2 tiles of v_mfma_f32_32x32x16_bf16 (64 accumulator VGPRs, 8 A + 8 W
+//     fragment reads per K tile); rows 256 .. 271 (3 of them exist at T = 259) are one extra 16 x 16 tile per wave
+//     (v_mfma_f32_16x16x32_bf16 on W rows 16 w .. 16 w + 15) -- a ninth wave would put three waves on one SIMD
+//   * LDS: THREE stages x (A 272 x 64 + W 128 x 64) bf16 = 150 KiB, rows of 128 B in 16-byte slots, slot ^ ((row >> 1) & 7)
+//     (gemm256's conflict-free ds_read_b128 layout), filled by LDS-DMA (global_load_lds_dwordx4: one wave-instruction = 8 rows
+//     x 128 B).  Per K tile a wave requests 4 A groups + 2 W groups; waves 0 and 1 also carry the two tail groups (a wave-uniform
+//     branch picks their wait immediate: 7 instead of 6)
+//   * the wave halves run half a K tile apart: a wave alternates a LOAD part (its 16 + 4 fragments into registers) and a MULTIPLY
+//     part (16 + 2 MFMAs, the requests of a later tile between them), one workgroup barrier after each; waves 4 - 7 take one extra
+//     barrier first, so one wave of every SIMD multiplies while the other reads.  The protocol (which part requests which tile,
+//     where each share is waited for, why a stage is free when it is overwritten) is spelled out at the loop
+//   * split-K over blockIdx.y for the narrow products (deterministic fp32 slabs, reduced by the split-K kernels of gemm.hip, which
+//     also carry the norm / RoPE that follows); SwiGLU mode for the stacked gate / up weight (srgpt_gemm_swiglu): the block's 128 W
+//     rows are 64 gate rows and the 64 matching up rows, the activation is the epilogue
+// Requirements (checked by the callers in gemm.hip): K % 64 == 0, at least 4 K tiles, M <= 272 per row tile.
 #include <type_traits>
 
 #include "common.h"
@@ -43,7 +49,6 @@ constexpr int T_LDS = T_NS * T_STAGE;        // 150 KiB
     __builtin_amdgcn_sched_barrier(0);                        \
   } while (0)
 
-template <int ablate, bool STAG>  // STAG: the two wave halves run half a K tile apart (below); ablate 0 = the kernel; tuning build only (wrong results): 1 no DMA in the loop, 4 no MFMA, 5 no barrier, 6 no DMA wait
 __global__ __launch_bounds__(512, 1) void gemm_bf16_288_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, int K,
                                                                int lda, Epilogue e) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -131,145 +136,84 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_288_kernel(const bf16_t* __r
   }
   f32x4 acct = {0.f, 0.f, 0.f, 0.f};
 
-  if constexpr (STAG) {
-    // Two wave halves half a K tile apart (gemm256's idea on this tile): a wave alternates a LOAD part (all 16 + 4 fragments of the
-    // K tile into registers) and a MULTIPLY part (its 16 + 2 MFMAs, the requests of a later tile between them), one workgroup
-    // barrier after each.  Waves 4 - 7 ("late"; wave w + 4 shares a SIMD with wave w) take one extra barrier first, so while one
-    // wave of a SIMD multiplies the other reads -- the matrix pipe does not idle through the barrier + LDS latency at the top of
-    // every tile (the lockstep form kept it 54 % busy with NO memory traffic at all: profiles/r04_gemm288.txt).
-    // Parts are numbered by barrier interval p.  Early: LOAD(t) at p = 2t, MULT(t) at 2t + 1; late: LOAD(t) at 2t + 1, MULT(t) at
-    // 2t + 2.  Stage t % 3 is read last at p = 2t + 1, so tile t + 3 may be requested into it from p = 2t + 2 on:
-    //   early MULT(t) (p = 2t + 1) requests its share of tile t + 2 (stage of t - 1, free since 2t);  lead 3 parts
-    //   late  MULT(t) (p = 2t + 2) requests its share of tile t + 3 (stage of t, free since 2t + 2); lead 4 parts
-    // and a tile must have landed before p = 2T: early waves wait for their share of T at the end of MULT(T - 1) (p = 2T - 1, the
-    // share of T + 1 just requested stays in flight), late waves in LOAD(T - 1) (p = 2T - 1, their share of T + 1 stays in flight).
-    const bool late = wave >= 4;
+  // Two wave halves half a K tile apart (gemm256's idea on this tile): a wave alternates a LOAD part (all 16 + 4 fragments of the
+  // K tile into registers) and a MULTIPLY part (its 16 + 2 MFMAs, the requests of a later tile between them), one workgroup
+  // barrier after each.  Waves 4 - 7 ("late"; wave w + 4 shares a SIMD with wave w) take one extra barrier first, so while one
+  // wave of a SIMD multiplies the other reads -- the matrix pipe does not idle through the barrier + LDS latency at the top of
+  // every tile (the lockstep form kept it 54 % busy with NO memory traffic at all: profiles/r04_gemm288.txt).
+  // Parts are numbered by barrier interval p.  Early: LOAD(t) at p = 2t, MULT(t) at 2t + 1; late: LOAD(t) at 2t + 1, MULT(t) at
+  // 2t + 2.  Stage t % 3 is read last at p = 2t + 1, so tile t + 3 may be requested into it from p = 2t + 2 on:
+  //   early MULT(t) (p = 2t + 1) requests its share of tile t + 2 (stage of t - 1, free since 2t);  lead 3 parts
+  //   late  MULT(t) (p = 2t + 2) requests its share of tile t + 3 (stage of t, free since 2t + 2); lead 4 parts
+  // and a tile must have landed before p = 2T: early waves wait for their share of T at the end of MULT(T - 1) (p = 2T - 1, the
+  // share of T + 1 just requested stays in flight), late waves in LOAD(T - 1) (p = 2T - 1, their share of T + 1 stays in flight).
+  const bool late = wave >= 4;
 #define T_WAIT_SHARE(more)              \
-  do {                                  \
-    if (!(more)) T_VMCNT(0);            \
-    else if (tail_wave) T_VMCNT(7);     \
-    else T_VMCNT(6);                    \
-  } while (0)
-    request(kt0);
-    if (kt0 + 1 < nk) request(kt0 + 1);
-    if (late && kt0 + 2 < nk) request(kt0 + 2);
-    if (!late) {
-      T_WAIT_SHARE(kt0 + 1 < nk);
-    } else {  // late waves carry no tail group: 6 requests per tile
-      const int later = nk - 1 - kt0;
-      if (later >= 2) T_VMCNT(12);
-      else if (later == 1) T_VMCNT(6);
-      else T_VMCNT(0);
-    }
-    T_BARRIER();
-    if (late) T_BARRIER();
-    for (int kt = kt0; kt < nk; ++kt) {
-      // ---- LOAD part ----
-      const char* buf = lds + (kt % T_NS) * T_STAGE;
-      bf16x8 fa[4][2], fw[4][2], fta[2], ftw[2];
+do {                                  \
+  if (!(more)) T_VMCNT(0);            \
+  else if (tail_wave) T_VMCNT(7);     \
+  else T_VMCNT(6);                    \
+} while (0)
+  request(kt0);
+  if (kt0 + 1 < nk) request(kt0 + 1);
+  if (late && kt0 + 2 < nk) request(kt0 + 2);
+  if (!late) {
+    T_WAIT_SHARE(kt0 + 1 < nk);
+  } else {  // late waves carry no tail group: 6 requests per tile
+    const int later = nk - 1 - kt0;
+    if (later >= 2) T_VMCNT(12);
+    else if (later == 1) T_VMCNT(6);
+    else T_VMCNT(0);
+  }
+  T_BARRIER();
+  if (late) T_BARRIER();
+  for (int kt = kt0; kt < nk; ++kt) {
+    // ---- LOAD part ----
+    const char* buf = lds + (kt % T_NS) * T_STAGE;
+    bf16x8 fa[4][2], fw[4][2], fta[2], ftw[2];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          fa[ks][i] = *reinterpret_cast<const bf16x8*>(buf + a_base + i * 32 * 128 + koff[ks]);
-          fw[ks][i] = *reinterpret_cast<const bf16x8*>(buf + w_base + i * 32 * 128 + koff[ks]);
-        }
-      if (has_tail) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          fta[s2] = *reinterpret_cast<const bf16x8*>(buf + taoff[s2]);
-          ftw[s2] = *reinterpret_cast<const bf16x8*>(buf + toff[s2]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (late) T_WAIT_SHARE(kt + 2 < nk);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments land before the barrier: whoever passes it may overwrite the stage
-      T_BARRIER();
-      // ---- MULTIPLY part ----
-      const int rq = late ? kt + 3 : kt + 2;
-      const bool do_rq = rq < nk;
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int jn = 0; jn < 2; ++jn)
-            acc[2 * mi + jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mi], fw[ks][jn], acc[2 * mi + jn], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (do_rq && ks < 3) request_part(rq, ks);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (has_tail) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) acct = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fta[s2], ftw[s2], acct, 0, 0, 0);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if (!late) T_WAIT_SHARE(kt + 2 < nk);
-      T_BARRIER();
-    }
-    if (!late) T_BARRIER();  // pairs with the last barrier of the late half
-#undef T_WAIT_SHARE
-  } else {
-  // ---- prologue: K tiles kt0 and kt0 + 1 requested ----
-    request(kt0);
-    if (kt0 + 1 < nk) request(kt0 + 1);
-  
-    for (int kt = kt0; kt < nk; ++kt) {
-      // my groups of tile kt have landed (those of tile kt + 1 may fly)
-      if (ablate != 6 && ablate != 1) {
-        if (kt + 1 >= nk) T_VMCNT(0);
-        else if (tail_wave) T_VMCNT(7);
-        else T_VMCNT(6);
-      }
-      if (ablate != 5) T_BARRIER();  // everyone's have; everyone is done reading tile kt - 1
-      if (ablate != 1 && kt + 2 < nk) request(kt + 2);  // into the stage tile kt - 1 occupied
-      const char* buf = lds + (kt % T_NS) * T_STAGE;
-      const char* bufw = buf + T_A;
-      // fragments one k-step ahead of their products, in program order the compiler may not change (sched_barrier): left alone it
-      // read each fragment right before its MFMA (lgkmcnt(0) in front of every product)
-      bf16x8 fa[2][2], fw[2][2], fta[2], ftw[2];
-  #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        fa[0][i] = *reinterpret_cast<const bf16x8*>(buf + a_base + i * 32 * 128 + koff[0]);
-        fw[0][i] = *reinterpret_cast<const bf16x8*>(buf + w_base + i * 32 * 128 + koff[0]);
+        fa[ks][i] = *reinterpret_cast<const bf16x8*>(buf + a_base + i * 32 * 128 + koff[ks]);
+        fw[ks][i] = *reinterpret_cast<const bf16x8*>(buf + w_base + i * 32 * 128 + koff[ks]);
       }
-  #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int c = ks & 1, nx = c ^ 1;
-        if (ks < 3) {
-  #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            fa[nx][i] = *reinterpret_cast<const bf16x8*>(buf + a_base + i * 32 * 128 + koff[ks + 1]);
-            fw[nx][i] = *reinterpret_cast<const bf16x8*>(buf + w_base + i * 32 * 128 + koff[ks + 1]);
-          }
-        } else if (has_tail) {
-  #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            fta[s2] = *reinterpret_cast<const bf16x8*>(buf + taoff[s2]);
-            ftw[s2] = *reinterpret_cast<const bf16x8*>(buf + toff[s2]);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-  #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-  #pragma unroll
-          for (int jn = 0; jn < 2; ++jn) {
-            if (ablate != 4) acc[2 * mi + jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][mi], fw[c][jn], acc[2 * mi + jn], 0, 0, 0);
-            else asm volatile("" ::"v"(fa[c][mi]), "v"(fw[c][jn]));
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (has_tail) {
-  #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          if (ablate != 4) acct = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fta[s2], ftw[s2], acct, 0, 0, 0);
-          else asm volatile("" ::"v"(fta[s2]), "v"(ftw[s2]));
-        }
+    if (has_tail) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        fta[s2] = *reinterpret_cast<const bf16x8*>(buf + taoff[s2]);
+        ftw[s2] = *reinterpret_cast<const bf16x8*>(buf + toff[s2]);
       }
     }
-  
-}
+    __builtin_amdgcn_sched_barrier(0);
+    if (late) T_WAIT_SHARE(kt + 2 < nk);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments land before the barrier: whoever passes it may overwrite the stage
+    T_BARRIER();
+    // ---- MULTIPLY part ----
+    const int rq = late ? kt + 3 : kt + 2;
+    const bool do_rq = rq < nk;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+          acc[2 * mi + jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mi], fw[ks][jn], acc[2 * mi + jn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (do_rq && ks < 3) request_part(rq, ks);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (has_tail) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) acct = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fta[s2], ftw[s2], acct, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (!late) T_WAIT_SHARE(kt + 2 < nk);
+    T_BARRIER();
+  }
+  if (!late) T_BARRIER();  // pairs with the last barrier of the late half
+#undef T_WAIT_SHARE
 
   // ---- epilogue.  32x32 D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
   if (swi) {
@@ -354,26 +298,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_288_kernel(const bf16_t* __r
 // e.splits / e.tiles_per_split / e.partial are set by the caller (srgpt_gemm) when it wants split-K; the deterministic slab
 // reduction (splitk_reduce_kernel in gemm.hip) follows there.
 int srgpt_gemm288_launch(const void* A, const void* W, int K, int lda, const Epilogue& e, hipStream_t s) {
-#define T_LAUNCH(AB, ST)                                                                                                            \
-  do {                                                                                                                          \
-    static std::atomic<uint64_t> attr_done{0};                                                                                  \
-    SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)gemm_bf16_288_kernel<AB, ST>, T_LDS));                                   \
-    hipLaunchKernelGGL((gemm_bf16_288_kernel<AB, ST>), dim3(e.swiglu_inter ? e.swiglu_inter / (T_BN / 2) : cdiv(e.N, T_BN), e.splits > 1 ? e.splits : 1, cdiv(e.M, T_BM)), dim3(512), \
-                       T_LDS, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);                                                \
-  } while (0)
-#ifdef SRGPT_TUNING_KNOBS
-  switch (SRGPT_KNOB("SRGPT_GEMM288_ABLATE", 0)) {
-    case 1: T_LAUNCH(1, false); break;
-    case 4: T_LAUNCH(4, false); break;
-    case 5: T_LAUNCH(5, false); break;
-    case 6: T_LAUNCH(6, false); break;
-    case 7: T_LAUNCH(0, false); break;  // the lockstep form
-    default: T_LAUNCH(0, true); break;
-  }
-#else
-  T_LAUNCH(0, true);
-#endif
-#undef T_LAUNCH
+  static std::atomic<uint64_t> attr_done{0};
+  SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)gemm_bf16_288_kernel, T_LDS));
+  hipLaunchKernelGGL(gemm_bf16_288_kernel,
+                     dim3(e.swiglu_inter ? e.swiglu_inter / (T_BN / 2) : cdiv(e.N, T_BN), e.splits > 1 ? e.splits : 1, cdiv(e.M, T_BM)),
+                     dim3(512), T_LDS, s, (const bf16_t*)A, (const bf16_t*)W, K, lda, e);
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }
