@@ -590,12 +590,15 @@ static int region_pool_impl(const void* feat, const void* masks, void* out, floa
     if (raw) RW(bf16_t, unsigned char, true);
     else if (mask_dtype == SRGPT_BF16) RW(bf16_t, bf16_t, false);
     else RW(bf16_t, float, false);
-    const int mode = SRGPT_KNOB("SRGPT_REGION_MFMA", 3);  // tuning build: 0 = the VALU kernel, 1 / 2 / 4 = that many chunks per wave
+    int ch = region_mfma_chunks((size_t)L);
+#ifdef SRGPT_TUNING_KNOBS  // A/B (scripts/ab_region_pool.sh): 0 = the VALU kernel on bf16 features, 1 / 2 / 4 = that many chunks per wave
+    const int mode = SRGPT_KNOB("SRGPT_REGION_MFMA", 3);
+    if ((mode == 1 || mode == 2 || mode == 4) && cdiv(L, 128 * mode) <= lay.nslab_cap) ch = mode;  // if the partials fit
     if (mode == 0) {
       if (M <= 8) RP(bf16_t, 8); else RP(bf16_t, 16);
-    } else {
-      int ch = region_mfma_chunks((size_t)L);
-      if ((mode == 1 || mode == 2 || mode == 4) && cdiv(L, 128 * mode) <= lay.nslab_cap) ch = mode;  // forced (tuning build), if the partials fit
+    } else
+#endif
+    {
       const dim3 mgrid(ncslab, cdiv(L, 4 * ch * 32));
 #define RPM(CHV)                                                                                                              \
   hipLaunchKernelGGL((region_pool_mfma_kernel<CHV>), mgrid, dim3(256), 0, s, (const bf16_t*)feat, v, psum, lay.n_psum, partial, \
