@@ -7,7 +7,7 @@
 //     (the conflict-free ds_read_b128 fragment layout of gemm.hip), filled by LDS-DMA (global_load_lds_dwordx4: one
 //     wave-instruction = 8 rows x 128 B = 1 KiB, full cache lines; the swizzle permutes which 16-byte chunk a lane fetches)
 //   * a K tile is consumed in 2 PHASES, phase P = m-tiles 2P, 2P+1 of the wave (64 rows) x both n-tiles x K = 64 -> 16 MFMAs
-//     on four accumulators (512 matrix-pipe cycles).  Measured (scripts/ubench_gemm256_ablate.sh): with 8-MFMA clusters on TWO
+//     on four accumulators (512 matrix-pipe cycles).  Measured (profiles/r02_gemm256_*.txt; the ablations were template arguments of this kernel while it was built): with 8-MFMA clusters on TWO
 //     accumulators the MFMAs alone ran at 44 instead of 32 cycles each -- a dependent 32x32x16 MFMA two issue slots behind its
 //     producer stalls.  The W fragments of the whole K tile are read in phase 0 and kept in 32 VGPRs, the A fragments of the
 //     phase's two m-tiles in 32 more.  Every LDS region therefore has ONE reading phase (W and A rows 0,1: phase 0; A rows 2,3:
@@ -39,7 +39,7 @@ constexpr int G_LDS = 2 * G_BUF;          // 128 KiB
 #define G_BARRIER()                          \
   do {                                       \
     __builtin_amdgcn_sched_barrier(0);       \
-    if (ablate != 9) __builtin_amdgcn_s_barrier(); \
+    __builtin_amdgcn_s_barrier();            \
     __builtin_amdgcn_sched_barrier(0);       \
   } while (0)
 #define G_VMCNT(N)                                                   \
@@ -54,9 +54,7 @@ constexpr int G_LDS = 2 * G_BUF;          // 128 KiB
 // ds_read_b128), one 16-byte read = 16 consecutive k of a row = the B operands of TWO MFMAs after v_cvt_scalef32_pk_bf16_fp8
 // (scale 1), so the A operand takes its 16-byte chunks in the matching order (chunk 4j + 2 hi + e for MFMA 2j + e);
 // the row scale multiplies the accumulator in the epilogue (exact: the bf16 value of code * 2^k is code * 2^k).
-template <int ablate, bool W8>  // ablate 0 = the kernel; 1..4 = timing-only ablations, instantiated in the tuning build only (wrong results):
-                       // 1 no DMA in the loop, 2 no DMA waits, 3 no fragment reads after the first tile, 4 no MFMA,
-                       // 7 no stagger (lockstep), 9 MFMAs only, 10 MFMAs + barriers only
+template <bool W8>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __restrict__ A, const void* __restrict__ Wv,
                                                                int K, int lda, Epilogue e, int gx, int gy) {
   const bf16_t* W = reinterpret_cast<const bf16_t*>(Wv);
@@ -182,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
   }
   G_BARRIER();
   // the late half runs one phase behind the early half; the two waves of a SIMD must be in different halves
-  const bool late = ablate == 7 ? false : wr == 1;
+  const bool late = wr == 1;
   if (late) G_BARRIER();
 
   // Phase P (0 / 1) of K tile kt = m-tiles 2P, 2P+1 of the wave x both n-tiles x K = 64: 16 MFMAs on FOUR accumulators (the same
@@ -195,13 +193,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
   // phase later -> vmcnt(6) (the 6 of the previous P1 may fly); P1 needs W + A rows 0,1 of the NEXT tile one phase later
   // -> vmcnt(2) (the 2 of this tile's P0 may fly).
   auto phase = [&](auto p_c, int kt, bool more1, bool more2) {
-#define G_WAIT(N)                                                                  \
-  do {                                                                             \
-    if (ablate != 2 && ablate != 1 && ablate != 9 && ablate != 10) G_VMCNT(N);     \
-  } while (0)
+#define G_WAIT(N) G_VMCNT(N)
     constexpr int P = decltype(p_c)::value;
     const char* buf = lds + (kt & 1) * G_BUF;
-    if ((ablate != 3 && ablate != 9 && ablate != 10) || kt == kt0) {
+    {
       if constexpr (P == 0 && !W8) {
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn)
@@ -222,7 +217,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
           fa[mi][ks] = *reinterpret_cast<const bf16x8*>(buf + a_base + (2 * P + mi) * 32 * 128 + koff[ks]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (ablate == 1 || ablate == 9 || ablate == 10) more1 = more2 = false;
     if constexpr (P == 0) {
       if (more1) {
         if constexpr (W8) G_WAIT(4); else G_WAIT(6);
@@ -255,36 +249,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
     G_BARRIER();
     // -------- multiply part --------
     __builtin_amdgcn_s_setprio(1);
-    if (ablate != 4) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int jn = 0; jn < 2; ++jn)
-            acc[2 * P + mi][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fw[jn][ks], acc[2 * P + mi][jn], 0, 0, 0);
-        // DMA in the matrix pipe's shadow: P0 one instruction after MFMA 4 and 12; P1 two after MFMA 4, 8, 12
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (P == 0) {
-          if (more1 && (ks == 0 || ks == 2)) stage(S3{}, kt + 1, ks >> 1);
-        } else {
-          if (more2) {
-            if (ks == 0) stage(S0{}, kt + 2, 2);
-            if (ks == 1) stage(S1{}, kt + 2, 2);
-            if (ks == 2) stage(S2{}, kt + 2, 2);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      asm volatile("" ::"v"(fa[0][0]), "v"(fa[0][3]), "v"(fa[1][0]), "v"(fa[1][3]), "v"(fw[0][0]), "v"(fw[1][3]));
+        for (int jn = 0; jn < 2; ++jn)
+          acc[2 * P + mi][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][ks], fw[jn][ks], acc[2 * P + mi][jn], 0, 0, 0);
+      // DMA in the matrix pipe's shadow: P0 one instruction after MFMA 4 and 12; P1 two after MFMA 4, 8, 12
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (P == 0) {
-        if (more1) stage(S3{}, kt + 1, 2);
-      } else if (more2) {
-        stage(S0{}, kt + 2, 2);
-        stage(S1{}, kt + 2, 2);
-        stage(S2{}, kt + 2, 2);
+        if (more1 && (ks == 0 || ks == 2)) stage(S3{}, kt + 1, ks >> 1);
+      } else {
+        if (more2) {
+          if (ks == 0) stage(S0{}, kt + 2, 2);
+          if (ks == 1) stage(S1{}, kt + 2, 2);
+          if (ks == 2) stage(S2{}, kt + 2, 2);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
     G_BARRIER();
@@ -297,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
     phase(P0{}, kt, more1, more2);
     phase(P1{}, kt, more1, more2);
   }
-  if (!late && ablate != 7) G_BARRIER();  // pairs with the last barrier of the late half
+  if (!late) G_BARRIER();  // pairs with the last barrier of the late half
 
   // ---- epilogue.  D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
 #pragma clang loop unroll(full)
@@ -327,29 +310,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
 int srgpt_gemm256_launch(const void* A, const void* W, int K, int lda, const Epilogue& e, hipStream_t s) {
   const int gx = cdiv(e.N, G_BN), gy = cdiv(e.M, G_BM);
   const bool w8 = e.wscale != nullptr;  // fp8 weight bytes + per-row scales
-#define G_LAUNCH(AB, W8V)                                                                                                    \
+#define G_LAUNCH(W8V)                                                                                                     \
   do {                                                                                                                    \
     static std::atomic<uint64_t> attr_done{0};                                                                            \
-    SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)gemm_bf16_256_kernel<AB, W8V>, G_LDS));                        \
-    hipLaunchKernelGGL((gemm_bf16_256_kernel<AB, W8V>), dim3(gx * gy, e.splits > 1 ? e.splits : 1), dim3(512), G_LDS, s,  \
+    SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)gemm_bf16_256_kernel<W8V>, G_LDS));                            \
+    hipLaunchKernelGGL((gemm_bf16_256_kernel<W8V>), dim3(gx * gy, e.splits > 1 ? e.splits : 1), dim3(512), G_LDS, s,      \
                        (const bf16_t*)A, W, K, lda, e, gx, gy);                                                           \
   } while (0)
-#ifdef SRGPT_TUNING_KNOBS
-  switch (SRGPT_KNOB("SRGPT_GEMM256_ABLATE", 0)) {
-    case 1: G_LAUNCH(1, false); break;
-    case 2: G_LAUNCH(2, false); break;
-    case 3: G_LAUNCH(3, false); break;
-    case 4: G_LAUNCH(4, false); break;
-    case 7: G_LAUNCH(7, false); break;
-    case 9: G_LAUNCH(9, false); break;    // MFMAs only: no fragment reads, no DMA, no barriers
-    case 10: G_LAUNCH(10, false); break;  // MFMAs + barriers only
-    default:
-      if (w8) G_LAUNCH(0, true); else G_LAUNCH(0, false);
-      break;
-  }
-#else
-  if (w8) G_LAUNCH(0, true); else G_LAUNCH(0, false);
-#endif
+  if (w8) G_LAUNCH(true); else G_LAUNCH(false);
 #undef G_LAUNCH
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
