@@ -394,6 +394,17 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         dec_ms = e0.elapsed_time(e1) / G
+        # the request prefix (both ViT passes, refinement, pooling, projector, splice, prefill, first id): whole requests of ONE new token
+        pre = []
+        for _ in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            model.generate(req[0], images=req[1], depths=req[2], masks=req[3], do_sample=False, max_new_tokens=1, eos_token_id=None)
+            e1.record()
+            torch.cuda.synchronize()
+            pre.append(e0.elapsed_time(e1))
+        prefix_ms = min(pre[1:])  # the first call re-captures nothing but warms the 1-token buffers
         wbytes = eng.w.llm_weight_bytes()
         # HBM bytes per launch: PMC counters cannot be read from inside this process -- the figure comes from the tracked
         # summary of a separate `rocprofv3 --pmc FETCH_SIZE` pass over this same command (x2 gfx950 correction), and says so
@@ -418,7 +429,9 @@ def main():
                 "how": "hip events around each launch on the launch stream, 3 sweeps over the 32 layers' matrices (cold in L3)",
                 "decode_ms_per_step": round(dec_ms, 4), "decode_ms_per_token": round(dec_ms / rows, 4), "decode_rows": rows, "decode_weight_bytes_per_token": wbytes,
                 "decode_hbm_gbs_whole_step": round(wbytes / (dec_ms * 1e-3) / 1e9, 1),
-                "decode_frac_whole_step": round(wbytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                "decode_frac_whole_step": round(wbytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "prefix_ms_per_call": round(prefix_ms, 3),
+                "prefix_how": "hip events around generate(max_new_tokens=1) with this run's requests: vision x2, refinement, pooling, projector, splice, prefill, first id (best of 3)"}
 
     cpu = None
     if sd_cpu is not None:
