@@ -27,6 +27,22 @@ def test_header_symbols_are_exported():
     assert lib.srgpt_abi_version() == _lib.ABI_VERSION == 7
 
 
+def test_product_library_exports_nothing_but_the_header():
+    """The product library carries no experiment residue: every exported `srgpt_*` C symbol is declared in include/srgpt.h (one
+    internal cross-file helper apart), and nothing of the tuning build (debug stamps, environment knobs, the VALU pooling kernel's
+    bf16 instances) is in it."""
+    import subprocess
+
+    from spatialrgpt_amd import _lib
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("srgpt_")}
+    assert exported - set(_declared()) <= {"srgpt_sample_slices"}, exported - set(_declared())
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for residue in (b"debug_stamps", b"SRGPT_GEMM_", b"SRGPT_REGION_", b"SRGPT_DECODE_", b"region_pool_kernelIDF16b"):
+        assert residue not in blob, residue
+
+
 def test_struct_layouts_match_header():
     """field order of the ctypes mirrors == field order in the header (guards silent ABI drift)."""
     from spatialrgpt_amd import _lib
