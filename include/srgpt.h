@@ -152,6 +152,22 @@ int srgpt_gemv(const void* x, const void* W, const void* norm_w, float norm_eps,
 int srgpt_gemv_w8(const void* x, const void* W8, const float* wscale, const void* norm_w, float norm_eps,
                   const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32,
                   srgpt_stream_t stream);
+/* ABI 8: the two products above with the ROW-STATISTICS HAND-OFF the batched decode step runs on (2+ bf16 rows: the MFMA kernel).
+ * LlamaRMSNorm (modeling_llama.py:61-75) needs mean(x^2) of every row of the residual stream; the product that WRITES that row
+ * (o_proj / down_proj with the residual add, modeling_llama.py:650-684) has each element in a register, so it publishes per-block
+ * partial sums and the product that normalises (q/k/v, gate/up, lm_head) adds them in a fixed order instead of re-reading the
+ * rows in every block.  A table is [batch][SRGPT_ROWSS_STRIDE] fp32.
+ *   W8 != NULL      : fp8 weights (+ wscale), W ignored; else W bf16
+ *   rowss_out       : this product's bf16 output rows get their table written (not with swiglu / out_f32)
+ *   rowss_in        : the table of x's rows, published by the call that wrote x (requires norm_w); NULL: computed from x
+ * srgpt_gemv_rowss_supported: 1 when (batch, dtype, fp8) takes the kernel that can do this (else call srgpt_gemv / _w8).
+ * The statistics' summation order differs from srgpt_gemv's own, so the normalised rows may differ from it by one bf16 ulp;
+ * srgpt_llm_decode_step == the composition of THESE entries bit for bit (tests/test_gpu_kernels.py). */
+#define SRGPT_ROWSS_STRIDE 512
+int srgpt_gemv_rowss_supported(int batch, int dtype, int fp8);
+int srgpt_gemv_rowss(const void* x, const void* W, const void* W8, const float* wscale, const void* norm_w, float norm_eps,
+                     const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32, const float* rowss_in,
+                     float* rowss_out, srgpt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Normalisations.

@@ -36,7 +36,11 @@ extern "C" void* srgpt_gemv_ts_ptr() {
 #endif
 
 int srgpt_skinny_launch(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
-                        int batch, int N, int K, int swiglu, int out_f32, hipStream_t s);  // skinny.hip
+                        int batch, int N, int K, int swiglu, int out_f32, const float* ss_in, float* ss_out, hipStream_t s);  // skinny.hip
+int srgpt_skinny_w8_launch(const void* x, const void* W8, const float* wscale, const void* norm_w, float norm_eps,
+                           const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32,
+                           const float* ss_in, float* ss_out, hipStream_t s);  // skinny.hip
+int srgpt_w8_valu_max_batch();  // skinny.hip
 
 #ifndef SRGPT_GEMV_REG_PIPE
 #define SRGPT_GEMV_REG_PIPE 0  // the same for the register-resident variant (o_proj: its weights are L2-prefetched; measured
@@ -70,14 +74,16 @@ struct WChunk<float> {
   }
 };
 
-template <typename T, int B, bool SWIGLU, int NXMAX>
+// UB = loads per batch (8; 7 for rows whose chunk iterations are a multiple of 7 and not of 8 -- K = 14336, down_proj: 28 iterations are
+// 4 batches of 7, where batches of 8 spent every row's fourth batch half on clamped re-reads of the row's last chunk)
+template <typename T, int B, bool SWIGLU, int NXMAX, int UB = 8>
 __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, const T* __restrict__ W,
                                                       const T* __restrict__ norm_w, float norm_eps,
                                                       const T* __restrict__ residual, void* __restrict__ out, int N,
                                                       int K, int out_f32) {
   constexpr int VEC = WChunk<T>::VEC;
   constexpr int R = SWIGLU ? 2 : 1;  // weight rows per unit
-  constexpr int U = 8 / R;           // K-chunks per row per batch: 8 loads (8 KiB per wave) in flight, then consumed
+  constexpr int U = UB / R;          // K-chunks per row per batch: 8 loads (8 KiB per wave) in flight, then consumed
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);  // [B][K]
   __shared__ float red[16];
@@ -117,11 +123,14 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
     Vec16<T> xr[NXMAX], gr[NXMAX];
     // residual elements this block will need: fetched with the prologue's loads (a load placed next to its use at
     // the end of a row gets sunk behind the weight stream by the compiler and exposes a full memory latency per row)
-    float res_pre = 0.f;
+    // Round 5: the load is UNCONDITIONAL and its value is not touched until the LDS store below.  Written as
+    // `if (residual) r = to_f(residual[i])` the compiler emitted branch -> load -> s_waitcnt vmcnt(0) -> convert at the very top of
+    // the kernel: o_proj and down_proj spent a whole memory round trip (the row was just written by the launch before: an L2 miss)
+    // before requesting their first activation or weight byte.
     const int rb = tid / (4 * RES_MAXU), rw = (tid / RES_MAXU) & 3, rk = tid % RES_MAXU;
     const int runit = (int)blockIdx.x * 4 + rw + rk * (int)gridDim.x * 4;
     const bool rok = !SWIGLU && residual != nullptr && tid < B * 4 * RES_MAXU && runit < N;
-    if (!SWIGLU && residual != nullptr) res_pre = to_f(residual[rok ? (size_t)rb * N + runit : 0]);
+    const T res_raw = (residual != nullptr ? residual : x)[rok ? (size_t)rb * N + runit : 0];
 #pragma unroll
     for (int j = 0; j < NXMAX; ++j) {
       const int c = (tid + 256 * j) % total;
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
       for (int bb = 0; bb < B; ++bb)
         if (bb == b) ss[bb] += sq;
     }
-    if (rok) res_s[rb][rw][rk] = res_pre;
+    if (rok) res_s[rb][rw][rk] = to_f(res_raw);
     float rs[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) rs[b] = 1.f;
@@ -317,11 +326,12 @@ __global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restri
 
   // ---- prologue: the lane's chunks of x (and gains), straight to registers; nothing here is shared between waves ----
   u32x4 xp[NIT];
-  float res_pre = 0.f;
+  unsigned int res_raw;  // bf16 bits of the residual element of unit `lane` (lanes 0..3); unconditional load, converted at its use
   {
-    if (!SWIGLU && residual != nullptr) {
+    {
       const int ru = (int)blockIdx.x * 4 + wave + min(lane, RES_MAXU - 1) * (int)gridDim.x * 4;
-      res_pre = to_f(residual[min(ru, N - 1)]);
+      const bool has = !SWIGLU && residual != nullptr;  // (see gemv_kernel: a branch here cost a memory round trip per launch)
+      res_raw = *reinterpret_cast<const unsigned short*>((has ? residual : x) + (has ? min(ru, N - 1) : 0));
     }
     u32x4 gr[NORM ? NIT : 1];
 #pragma unroll
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restri
 #pragma unroll
     for (int r = 0; r < R; ++r) a[r] = wave_sum(acc[r]);
     // lane uk of res_pre holds the residual element of this unit (uniform index: v_readlane, not a ds_bpermute)
-    const float res_b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, res_pre), uk < RES_MAXU ? uk : 0));
+    const float res_b = __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)res_raw, uk < RES_MAXU ? uk : 0) << 16);
     if (lane == 0) {
       if (SWIGLU) {
         const float g = rnd<T>(a[0]), u = rnd<T>(a[R - 1]);
@@ -465,16 +475,19 @@ int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, con
       return SRGPT_OK;
     }
   }
-#define SRGPT_GEMV_LAUNCH(SW, NXV)                                                                              \
+#define SRGPT_GEMV_LAUNCH(SW, NXV, ...)                                                                         \
   do {                                                                                                          \
-    auto kfn = gemv_kernel<T, B, SW, NXV>;                                                                      \
+    auto kfn = gemv_kernel<T, B, SW, NXV, ##__VA_ARGS__>;                                                       \
     static std::atomic<uint64_t> attr_done{0};                                                                  \
     SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)kfn, lds > 48 * 1024 ? 150 * 1024 : 0));             \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, s, (const T*)x, (const T*)W, (const T*)norm_w, eps,     \
                        (const T*)residual, out, N, K, out_f32);                                                 \
   } while (0)
+  const int nit = (K / WChunk<T>::VEC + 63) / 64;
   if (swiglu) {
     if (chunks <= 512) SRGPT_GEMV_LAUNCH(true, 2); else SRGPT_GEMV_LAUNCH(true, 8);
+  } else if (B == 1 && sizeof(T) == 2 && nit % 7 == 0 && nit % 8 != 0 && chunks > 512 && SRGPT_KNOB("SRGPT_GEMV_U7", 1)) {
+    SRGPT_GEMV_LAUNCH(false, 8, 7);
   } else {
     if (chunks <= 512) SRGPT_GEMV_LAUNCH(false, 2); else SRGPT_GEMV_LAUNCH(false, 8);
   }
@@ -483,10 +496,13 @@ int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, con
   return SRGPT_OK;
 }
 
+// bf16 rows >= this go to the MFMA kernel of skinny.hip
+inline int skinny_min_batch() { return SRGPT_KNOB("SRGPT_SKINNY_MIN_BATCH", 2); }  // measured (round 3, profiles/r03_skinny_min_batch.txt): VALU wins at 1 row, MFMA from 2
+
 template <typename T>
 int dispatch_b(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
                int batch, int N, int K, int swiglu, int out_f32, hipStream_t s) {
-  const int skinny_min = SRGPT_KNOB("SRGPT_SKINNY_MIN_BATCH", 2);  // measured (round 3, profiles/r03_skinny_min_batch.txt): VALU wins at 1 row, MFMA from 2
+  const int skinny_min = skinny_min_batch();
   if (batch > 4 || (sizeof(T) == 2 && batch >= skinny_min)) {
     // bf16: rows go through the MFMA skinny kernel 16 at a time (skinny.hip); fp32 (parity dtype of the tiny models):
     // 4 rows at a time through the VALU kernel.  Each chunk streams the weights once.
@@ -501,7 +517,7 @@ int dispatch_b(const void* x, const void* W, const void* norm_w, float eps, cons
       const void* rb = residual ? (const char*)residual + (size_t)b0 * N * sizeof(T) : nullptr;
       void* ob = (char*)out + (size_t)b0 * N * on;
       if (mfma && (nb > 4 || nb >= skinny_min))
-        SRGPT_TRY(srgpt_skinny_launch(xb, W, norm_w, eps, rb, ob, nb, N, K, swiglu, out_f32, s));
+        SRGPT_TRY(srgpt_skinny_launch(xb, W, norm_w, eps, rb, ob, nb, N, K, swiglu, out_f32, nullptr, nullptr, s));
       else
         SRGPT_TRY((dispatch_b<T>(xb, W, norm_w, eps, rb, ob, nb, N, K, swiglu, out_f32, s)));
     }
@@ -533,4 +549,35 @@ extern "C" int srgpt_gemv(const void* x, const void* W, const void* norm_w, floa
   if (dtype == SRGPT_BF16)
     return dispatch_b<bf16_t>(x, W, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, s);
   return dispatch_b<float>(x, W, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same products with the row-statistics hand-off of skinny.hip (ABI 8): bf16 activations, 2+ rows (the MFMA kernel).
+// ------------------------------------------------------------------------------------------------
+extern "C" int srgpt_gemv_rowss_supported(int batch, int dtype, int fp8) {
+  if (dtype != SRGPT_BF16 || batch < 2) return 0;
+  if (2 * srgpt_device_cus() > SRGPT_ROWSS_STRIDE) return 0;  // one slot per producer block (two 4-wave blocks per CU)
+  return fp8 ? (batch > srgpt_w8_valu_max_batch() ? 1 : 0) : (batch >= skinny_min_batch() ? 1 : 0);
+}
+
+extern "C" int srgpt_gemv_rowss(const void* x, const void* W, const void* W8, const float* wscale, const void* norm_w,
+                                float norm_eps, const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32,
+                                const float* rowss_in, float* rowss_out, srgpt_stream_t stream) {
+  SRGPT_CHECK(x && (W || W8) && out, SRGPT_ERR_ARG, "srgpt_gemv_rowss: null pointer");
+  SRGPT_CHECK(!W8 || wscale, SRGPT_ERR_ARG, "srgpt_gemv_rowss: fp8 weights without row scales");
+  SRGPT_CHECK(N > 0 && K > 0 && batch > 0 && K % 8 == 0, SRGPT_ERR_ARG, "srgpt_gemv_rowss: bad shape");
+  SRGPT_CHECK(!(swiglu && (residual || out_f32)), SRGPT_ERR_ARG, "srgpt_gemv_rowss: swiglu excludes residual/out_f32");
+  SRGPT_CHECK(srgpt_gemv_rowss_supported(batch, SRGPT_BF16, W8 != nullptr), SRGPT_ERR_UNSUPPORTED,
+              "srgpt_gemv_rowss: %d row(s) of %s weights take a kernel without the statistics hand-off", batch, W8 ? "fp8" : "bf16");
+  hipStream_t s = as_stream(stream);
+  if (W8) return srgpt_skinny_w8_launch(x, W8, wscale, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, rowss_in, rowss_out, s);
+  const size_t on = out_f32 ? sizeof(float) : 2;
+  for (int b0 = 0; b0 < batch; b0 += 16) {
+    const int nb = batch - b0 < 16 ? batch - b0 : 16;
+    SRGPT_TRY(srgpt_skinny_launch((const char*)x + (size_t)b0 * K * 2, W, norm_w, norm_eps,
+                                  residual ? (const char*)residual + (size_t)b0 * N * 2 : nullptr, (char*)out + (size_t)b0 * N * on, nb,
+                                  N, K, swiglu, out_f32, rowss_in ? rowss_in + (size_t)b0 * SRGPT_ROWSS_STRIDE : nullptr,
+                                  rowss_out ? rowss_out + (size_t)b0 * SRGPT_ROWSS_STRIDE : nullptr, s));
+  }
+  return SRGPT_OK;
 }

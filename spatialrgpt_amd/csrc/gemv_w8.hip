@@ -77,12 +77,12 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
     Vec16<T> xr[NXMAX], gr[NXMAX];
     // residual elements this block will need: fetched with the prologue's loads (a load placed next to its use at
     // the end of a row gets sunk behind the weight stream by the compiler and exposes a full memory latency per row)
-    float res_pre = 0.f;
     constexpr int RSLOT = 2 * RES_MAXU;  // (unit, row-of-pair) slots per wave
     const int rb = tid / (4 * RSLOT), rw = (tid / RSLOT) & 3, rk = tid % RSLOT;
     const int runit = ((int)blockIdx.x * 4 + rw + (rk >> 1) * (int)gridDim.x * 4) * 2 + (rk & 1);  // output row
     const bool rok = !SWIGLU && residual != nullptr && tid < B * 4 * RSLOT && runit < N;
-    if (!SWIGLU && residual != nullptr) res_pre = to_f(residual[rok ? (size_t)rb * N + runit : 0]);
+    // unconditional, untouched until the LDS store (gemv.hip: the branchy form cost a memory round trip at the top of the kernel)
+    const T res_raw = (residual != nullptr ? residual : x)[rok ? (size_t)rb * N + runit : 0];
 #pragma unroll
     for (int j = 0; j < NXMAX; ++j) {
       const int c = (tid + 256 * j) % total;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemv_w8_kernel(const T* __restrict__ x
       for (int bb = 0; bb < B; ++bb)
         if (bb == b) ss[bb] += sq;
     }
-    if (rok) res_s[rb][rw][rk] = res_pre;
+    if (rok) res_s[rb][rw][rk] = to_f(res_raw);
     float rs[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) rs[b] = 1.f;

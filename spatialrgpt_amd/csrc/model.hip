@@ -60,6 +60,7 @@ struct LlmWs {
   int64_t* tok_emb;  // [batch] the token whose embedding row currently sits in xd (-1: none)
   void* smp;         // sampling: the slices' top-k candidates (srgpt_sample_ws_bytes)
   int* err;          // sticky error word of the decode step (bit 0: a caller-written st->tok outside the table), read by srgpt_llm_decode_sync_state
+  float* rowss;   // decode, 2+ rows: two row-statistics tables [batch][SRGPT_ROWSS_STRIDE] (o_proj's and down_proj's output rows)
   void* a8;       // fp8_act: the e4m3 bytes of the current GEMM input [rows, max K]
   float* a8s;     // fp8_act: their per-row scales [rows]
   size_t total;
@@ -90,6 +91,7 @@ LlmWs carve_llm(const srgpt_llm_weights* w, int batch, int max_tokens, void* ws)
   l.tok_emb = reinterpret_cast<int64_t*>(c.take((size_t)batch * 8));
   l.err = reinterpret_cast<int*>(c.take(sizeof(int)));
   l.smp = c.take((size_t)srgpt_sample_ws_bytes(batch));
+  l.rowss = reinterpret_cast<float*>(c.take((size_t)2 * batch * SRGPT_ROWSS_STRIDE * sizeof(float)));
   l.a8 = nullptr;
   l.a8s = nullptr;
   if (w->fp8_act) {
@@ -564,8 +566,15 @@ static int decode_step_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, srg
     SRGPT_CHECK(dt == SRGPT_BF16 && w->wo8 && w->wgu8 && w->wdown8 && w->lm_head8 && w->wqkv_scale && w->wo_scale &&
                     w->wgu_scale && w->wdown_scale && w->lm_head_scale,
                 SRGPT_ERR_ARG, "srgpt_llm_decode_step: fp8 weights need bf16 activations and all five matrices + scales");
+  // 2+ bf16 rows (the MFMA kernel): o_proj / down_proj publish the sum of squares of the rows they write, the RMSNorm of the next
+  // product reads 512 partial sums per row instead of re-reading every row in every block (skinny.hip; layer 0's q/k/v normalises
+  // the embedding rows itself).  The per-op form of exactly this sequence is srgpt_gemv_rowss.
+  const bool pub = srgpt_gemv_rowss_supported(B, dt, w8 ? 1 : 0) != 0 && SRGPT_KNOB("SRGPT_DECODE_ROWSS", 1) != 0;
+  float* const ss_attn = d.rowss;                                       // rows after the attention block's residual add
+  float* const ss_mlp = d.rowss + (size_t)B * SRGPT_ROWSS_STRIDE;       // rows after the MLP block's
   auto mv = [&](const void* x, const void* Wd, const void* W8p, const float* sc, const void* norm, const void* res, void* out,
-                int N, int K, int swiglu, int f32) -> int {
+                int N, int K, int swiglu, int f32, const float* ss_in, float* ss_out) -> int {
+    if (pub) return srgpt_gemv_rowss(x, Wd, W8p, sc, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, ss_in, ss_out, stream);
     if (w8) return srgpt_gemv_w8(x, W8p, sc, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, stream);
     return srgpt_gemv(x, Wd, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, dt, stream);
   };
@@ -573,20 +582,21 @@ static int decode_step_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, srg
     char* kc = reinterpret_cast<char*>(st->kcache) + (size_t)i * layer_kv;
     char* vc = reinterpret_cast<char*>(st->vcache) + (size_t)i * layer_kv;
     SRGPT_TRY(mv(d.xd, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, w->attn_norm[i], nullptr,
-                 d.qkvd, QW, Hd, 0, 0));
+                 d.qkvd, QW, Hd, 0, 0, i > 0 ? ss_mlp : nullptr, nullptr));
     // the attention launch also pulls o_proj's weights into L2 (HBM is idle while it runs).  Round 3 built the next step -- o_proj
     // itself inside this launch, weights in registers, agent-scope hand-off -- bit-exact and 3 us per layer SLOWER
     // (profiles/r03_fused_attention_oproj.txt)
     SRGPT_TRY(srgpt_decode_attention_pf(d.qkvd, kc, vc, st->pos, w->rope_cos, w->rope_sin, d.attnd, d.dws, B, Hq, Hkv, D,
                                         st->max_pos, dt, w8 ? w->wo8[i] : w->wo[i], Hd, Hq * D, w8 ? 1 : 0, stream));
     SRGPT_TRY(mv(d.attnd, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, nullptr, d.xd, d.xd, Hd,
-                 Hq * D, 0, 0));
+                 Hq * D, 0, 0, nullptr, ss_attn));
     SRGPT_TRY(mv(d.xd, w->wgu[i], w8 ? w->wgu8[i] : nullptr, w8 ? w->wgu_scale[i] : nullptr, w->mlp_norm[i], nullptr,
-                 d.actd, I, Hd, 1, 0));
+                 d.actd, I, Hd, 1, 0, ss_attn, nullptr));
     SRGPT_TRY(mv(d.actd, w->wdown[i], w8 ? w->wdown8[i] : nullptr, w8 ? w->wdown_scale[i] : nullptr, nullptr, d.xd, d.xd,
-                 Hd, I, 0, 0));
+                 Hd, I, 0, 0, nullptr, ss_mlp));
   }
-  SRGPT_TRY(mv(d.xd, w->lm_head, w->lm_head8, w->lm_head_scale, w->final_norm, nullptr, st->logits, w->vocab, Hd, 0, 1));
+  SRGPT_TRY(mv(d.xd, w->lm_head, w->lm_head8, w->lm_head_scale, w->final_norm, nullptr, st->logits, w->vocab, Hd, 0, 1,
+               w->layers > 0 ? ss_mlp : nullptr, nullptr));
   return greedy_pick(w, st, d, 1, s);
 }
 

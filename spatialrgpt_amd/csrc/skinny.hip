@@ -75,12 +75,23 @@ constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumu
 // (2 rows x 256 bytes each), widened to bf16 (exact) on the way into LDS; the row scale multiplies the fp32 dot product.
 // (Measured and dropped: 512-k fp8 slices with the raw bytes in LDS and the widening behind the fragment read -- a stage of as
 // many bytes as a bf16 one -- 69.2 vs 63.7 us per layer at 8 rows: this kernel is not bound by bytes in flight.)
-template <bool SWIGLU, int NI, int NW, bool W8>
+//
+// Row statistics hand-off (round 5).  The RMSNorm in front of q/k/v, gate/up and lm_head needs sum(x^2) of every batch row; computed
+// in the consumer, EVERY block re-read all rows (8 x 8 KiB at 8 rows) and reduced them through two block barriers before its first
+// weight stage could even be requested: 7.7k of the q/k/v launch's 22k cycles at 8 fp8 rows (profiles/r02_skinny_stamps.txt).  The
+// product that WRITES x (o_proj / down_proj with the residual add) has every element of it in a register: with `ss_out` it publishes,
+// per block, the sum of squares of the columns it owns -- slot [row][block] of a [rows][SRGPT_ROWSS_STRIDE] fp32 table, slots past
+// the grid zeroed, plain stores (the kernel boundary makes them visible).  A consumer instantiated with PUB reads its rows' 512 slots
+// (one wave per row, two 16-byte loads per lane), adds them in a fixed order (lane-local, then the DPP / permlane tree) -- the
+// result does not depend on which block finished first -- and goes straight to its weight stream: the statistics' loads, the first
+// activation slice and the first weight stage are all requested back to back at kernel entry, one memory latency for the three.
+template <bool SWIGLU, int NI, int NW, bool W8, bool PUB>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const bf16_t* __restrict__ x, const void* __restrict__ Wv,
                                                                           const float* __restrict__ wscale,
                                                                           const bf16_t* __restrict__ norm_w, float norm_eps,
                                                                           const bf16_t* __restrict__ residual, void* __restrict__ out,
-                                                                          int B, int N, int K, int out_f32, int cw) {
+                                                                          int B, int N, int K, int out_f32, int cw,
+                                                                          const float* __restrict__ ss_in, float* __restrict__ ss_out) {
   constexpr int SK = 256;                   // k per wave slice
   constexpr int XROWB = WROWB;              // bytes per staged activation row
   constexpr int XL = NI;                    // activation loads per slice: 2 rows x 512 B each
@@ -266,6 +277,30 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     __syncthreads();
   };
 
+  // ---- the same statistics from the producer's published partial sums (PUB) ----
+  // wave w owns rows w, w + NW, ...; `between` runs after the loads have been requested (the first weight stage queues behind them)
+  auto pub_stats = [&](auto&& between) {
+    constexpr int RPW = (2 * NI + NW - 1) / NW;
+    f32x4 sv[RPW][2];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const float* p = ss_in + (size_t)min(wave + j * NW, B - 1) * SRGPT_ROWSS_STRIDE + lane * 8;
+      sv[j][0] = *reinterpret_cast<const f32x4*>(p);
+      sv[j][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    between();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      float t = ((sv[j][0][0] + sv[j][0][1]) + (sv[j][0][2] + sv[j][0][3])) + ((sv[j][1][0] + sv[j][1][1]) + (sv[j][1][2] + sv[j][1][3]));
+      t = wave_sum(t);
+      if (lane == 0 && wave + j * NW < 2 * NI) rs_s[wave + j * NW] = rsqrtf(t / (float)K + norm_eps);
+    }
+    __syncthreads();
+  };
+  float pub_acc = 0.f;  // ss_out: sum of squares of this thread's output elements (all of one batch row: see the epilogue)
+
   // one pass over K for NSU sub-units
   auto run_pass = [&](auto nsu_c, int pass, int nu) {
     constexpr int NSU = decltype(nsu_c)::value;
@@ -280,28 +315,40 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     // register ring of DEPTH weight stages with static slot indices (a trip = DEPTH slices x NSU stages, a multiple of
     // DEPTH): the loads of stage t+DEPTH-1 are issued before stage t is multiplied.  A stage is 8 KiB per wave (fp8: 4 KiB).
     WReg wb[DEPTH][8];
-    // epilogue operands that do not depend on the products -- row scales (W8) and residual elements -- are requested now:
-    // fetched at their use they would each add a memory round trip after the last barrier of the pass
+    // epilogue operands that do not depend on the products -- row scales (W8) and residual elements -- are requested up front
+    // (fetched at their use they would each add a memory round trip after the last barrier of the pass), but BEHIND the first
+    // weight stages and without touching their values: round 4's form, `residual ? (float)residual[i] : 0` in front of the first
+    // weight request, compiled to branch -> load -> s_waitcnt vmcnt(0) -> convert per element -- o_proj and down_proj went
+    // through up to four serialised memory round trips (2.7k cycles, profiles/r05_skinny_stamps.txt) before asking for a weight
     constexpr int EIT0 = ((NSU / R) * 256 + NT - 1) / NT;  // epilogue iterations per thread
     constexpr int EIT = EIT0 > 0 ? EIT0 : 1;               // (odd NSU never occurs with SwiGLU; keep the type valid)
-    float pre_sc[EIT][R], pre_res[EIT];
+    float pre_sc[EIT][R];
+    unsigned short pre_res[EIT];  // bf16 bits
+    auto load_epilogue_operands = [&]() {
+      const bool has_res = !SWIGLU && residual != nullptr;
+      const bf16_t* rp = has_res ? residual : x;
 #pragma unroll
-    for (int i = 0; i < EIT; ++i) {
-      const int e = tid + i * NT;
-      const int u = e >> 8, l2 = e & 63, q = (e >> 6) & 3;
-      const int b = min(4 * (l2 >> 4) + q, B - 1);
-      const int n = min(c0 + (pass * MAXU + u) * 16 + (l2 & 15), c0 + cwb - 1);
+      for (int i = 0; i < EIT; ++i) {
+        const int e = tid + i * NT;
+        const int u = e >> 8, l2 = e & 63, q = (e >> 6) & 3;
+        const int b = min(4 * (l2 >> 4) + q, B - 1);
+        const int n = min(c0 + (pass * MAXU + u) * 16 + (l2 & 15), c0 + cwb - 1);
 #pragma unroll
-      for (int r = 0; r < R; ++r) pre_sc[i][r] = W8 ? wscale[n + r * N] : 1.f;
-      pre_res[i] = (!SWIGLU && residual) ? (float)residual[(size_t)b * N + n] : 0.f;
-    }
+        for (int r = 0; r < R; ++r) pre_sc[i][r] = W8 ? wscale[n + r * N] : 1.f;
+        pre_res[i] = *reinterpret_cast<const unsigned short*>(rp + (has_res ? (size_t)b * N + n : (size_t)0));
+      }
+    };
     // pass 0: the first weight stage goes out behind the statistics' own loads (in-order return: the reduction waits for its
     // activations only), so its HBM latency overlaps the reduction and the two block barriers -- as in the GEMV's prologue
-    if (PRE && pass == 0 && do_norm) rms_stats([&]() { issue_w(wb[0], 0, sl_of(0), 0, cnt > 0); });
+    if (PUB && pass == 0) pub_stats([&]() { issue_w(wb[0], 0, sl_of(0), 0, cnt > 0); });
+    else if (PRE && pass == 0 && do_norm) rms_stats([&]() { issue_w(wb[0], 0, sl_of(0), 0, cnt > 0); });
     else issue_w(wb[0], pass, sl_of(0), 0, cnt > 0);
 #pragma unroll
     for (int f = 1; f < DEPTH - 1; ++f)
       issue_w(wb[f % DEPTH], pass, sl_of(f / NSU), f % NSU, f / NSU < cnt);
+    __builtin_amdgcn_sched_barrier(0);
+    load_epilogue_operands();
+    __builtin_amdgcn_sched_barrier(0);
     if (pass == 0) SK_STAMP(1);
     // one slice (h-th of the trip that starts at slice index i): NSU stages
     // activation fragments of a slice held across its sub-units where the registers are there (fp8 weights: the stage ring is
@@ -407,7 +454,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
           reinterpret_cast<bf16_t*>(out)[(size_t)b * N + n] = (bf16_t)(rnd<bf16_t>(silu(g)) * up);
         } else {
           float v = rnd<bf16_t>(a[0]);
-          if (residual) v = rnd<bf16_t>(pre_res[i] + v);
+          if (residual) v = rnd<bf16_t>(__uint_as_float((unsigned int)pre_res[i] << 16) + v);
+          if constexpr (NW == 4) pub_acc = fmaf(v, v, pub_acc);
           if (out_f32)
             reinterpret_cast<float*>(out)[(size_t)b * N + n] = v;
           else
@@ -419,7 +467,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     __syncthreads();  // the reduction buffer aliases the wave-private stages of the next pass
   };
 
-  if (!PRE && do_norm) rms_stats([]() {});
+  if (!PUB && !PRE && do_norm) rms_stats([]() {});
   for (int pass = 0; pass < npass; ++pass) {
     int nu = 0;
 #pragma unroll
@@ -432,27 +480,41 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
       default: run_pass(std::integral_constant<int, 4>{}, pass, nu); break;
     }
   }
+  if constexpr (!SWIGLU && NW == 4) {  // (the launcher gives a publishing product 4-wave blocks)
+    if (ss_out != nullptr) {
+      // epilogue element e = tid + i NT sits in batch row 4 (lane >> 4) + wave whatever i and the pass are: a thread's pub_acc
+      // belongs to ONE row, and the 16 lanes of a DPP row hold that row's 16 columns of every tile
+      const float tot = lanes_sum<16>(pub_acc);
+      const int b = 4 * (lane >> 4) + wave;
+      if ((lane & 15) == 0 && b < B) {
+        float* row = ss_out + (size_t)b * SRGPT_ROWSS_STRIDE;
+        row[blockIdx.x] = tot;
+        for (int sidx = (int)blockIdx.x + (int)gridDim.x; sidx < SRGPT_ROWSS_STRIDE; sidx += (int)gridDim.x) row[sidx] = 0.f;
+      }
+    }
+  }
 }
 
-template <bool SWIGLU, int NI, int NW, bool W8>
+template <bool SWIGLU, int NI, int NW, bool W8, bool PUB>
 int launch_skinny(const void* x, const void* W, const float* wscale, const void* norm_w, float eps, const void* residual,
-                  void* out, int batch, int N, int K, int out_f32, int grid, int cw, hipStream_t s) {
+                  void* out, int batch, int N, int K, int out_f32, int grid, int cw, const float* ss_in, float* ss_out,
+                  hipStream_t s) {
   constexpr int lds = NW * (2 * NI * WROWB + WSTAGEB);
   static_assert(lds >= NW * MAXSU * 64 * 4 * 4, "reduction buffer must fit");
   static_assert(lds <= 160 * 1024, "LDS");
   static_assert(NW == 8 || 2 * lds <= 160 * 1024, "two 4-wave blocks per CU");
-  auto kfn = skinny_kernel<SWIGLU, NI, NW, W8>;
+  auto kfn = skinny_kernel<SWIGLU, NI, NW, W8, PUB>;
   static std::atomic<uint64_t> attr_done{0};
   SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)kfn, lds));
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * NW), lds, s, (const bf16_t*)x, W, wscale, (const bf16_t*)norm_w, eps,
-                     (const bf16_t*)residual, out, batch, N, K, out_f32, cw);
+                     (const bf16_t*)residual, out, batch, N, K, out_f32, cw, ss_in, ss_out);
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }
 
 template <bool SWIGLU, int NI, bool W8>
 int launch_skinny_nw(const void* x, const void* W, const float* wscale, const void* norm_w, float eps, const void* residual,
-                     void* out, int batch, int N, int K, int out_f32, hipStream_t s) {
+                     void* out, int batch, int N, int K, int out_f32, const float* ss_in, float* ss_out, hipStream_t s) {
   // Two 4-wave blocks per CU, or one 8-wave block per CU; both split the columns evenly over their blocks.  Measured per decode
   // step (profiles/r02_skinny_ab.txt): 4-wave blocks win (o_proj 8.8 vs 9.7 us, fp8 gate/up 27.4 vs 30.4) except where a block
   // would own few columns AND has the RMSNorm statistics to compute first (q/k/v: 24 columns per CU, 14.1 vs 14.3 us bf16,
@@ -460,27 +522,39 @@ int launch_skinny_nw(const void* x, const void* W, const float* wscale, const vo
   const int cus = srgpt_device_cus();
   int waves = SRGPT_KNOB("SRGPT_SKINNY_WAVES", 0);
   if (waves != 4 && waves != 8) waves = (norm_w != nullptr && (N + cus - 1) / cus <= 32) ? 8 : 4;
+  if (ss_out) waves = 4;  // the publishing epilogue is the 4-wave kernel's (one wave per batch-row residue)
   const int blocks = waves == 8 ? cus : 2 * cus;
   int cw = (N + blocks - 1) / blocks;
   if (cw < 16) cw = 16;
   const int grid = (N + cw - 1) / cw;
-  if (waves == 8) return launch_skinny<SWIGLU, NI, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, grid, cw, s);
-  return launch_skinny<SWIGLU, NI, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, grid, cw, s);
+  SRGPT_CHECK(!ss_out || grid <= SRGPT_ROWSS_STRIDE, SRGPT_ERR_UNSUPPORTED, "skinny: %d blocks do not fit the %d row-statistics slots",
+              grid, SRGPT_ROWSS_STRIDE);
+#define SRGPT_SKINNY_GO(NWV, PUBV) \
+  return launch_skinny<SWIGLU, NI, NWV, W8, PUBV>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, grid, cw, ss_in, ss_out, s)
+  if (ss_in != nullptr) {
+    if (waves == 8) SRGPT_SKINNY_GO(8, true);
+    SRGPT_SKINNY_GO(4, true);
+  }
+  if (waves == 8) SRGPT_SKINNY_GO(8, false);
+  SRGPT_SKINNY_GO(4, false);
+#undef SRGPT_SKINNY_GO
 }
 
 template <bool W8>
 int skinny_dispatch(const void* x, const void* W, const float* wscale, const void* norm_w, float eps, const void* residual,
-                    void* out, int batch, int N, int K, int swiglu, int out_f32, hipStream_t s) {
+                    void* out, int batch, int N, int K, int swiglu, int out_f32, const float* ss_in, float* ss_out, hipStream_t s) {
   SRGPT_CHECK(batch >= 1 && batch <= 16, SRGPT_ERR_ARG, "skinny: batch %d outside 1..16", batch);
   SRGPT_CHECK(K % 8 == 0 && K >= 8, SRGPT_ERR_ARG, "skinny: K=%d must be a multiple of 8", K);
+  SRGPT_CHECK(!ss_in || norm_w, SRGPT_ERR_ARG, "skinny: published row statistics are the RMSNorm's input (norm_w is NULL)");
+  SRGPT_CHECK(!ss_out || (!swiglu && !out_f32), SRGPT_ERR_ARG, "skinny: row statistics are published for plain bf16 outputs only");
   if (batch <= 4)
-    return swiglu ? launch_skinny_nw<true, 2, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s)
-                  : launch_skinny_nw<false, 2, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s);
+    return swiglu ? launch_skinny_nw<true, 2, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, nullptr, s)
+                  : launch_skinny_nw<false, 2, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, ss_out, s);
   if (batch <= 8)
-    return swiglu ? launch_skinny_nw<true, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s)
-                  : launch_skinny_nw<false, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s);
-  return swiglu ? launch_skinny_nw<true, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s)
-                : launch_skinny_nw<false, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, s);
+    return swiglu ? launch_skinny_nw<true, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, nullptr, s)
+                  : launch_skinny_nw<false, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, ss_out, s);
+  return swiglu ? launch_skinny_nw<true, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, nullptr, s)
+                : launch_skinny_nw<false, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, ss_out, s);
 }
 
 }  // namespace
@@ -493,9 +567,28 @@ extern "C" int srgpt_skinny_debug_stamps(unsigned long long* host, int n) {
 
 // host entry used by srgpt_gemv (gemv.hip) for batches of up to 16 rows, bf16 weights
 int srgpt_skinny_launch(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
-                        int batch, int N, int K, int swiglu, int out_f32, hipStream_t s) {
-  return skinny_dispatch<false>(x, W, nullptr, norm_w, eps, residual, out, batch, N, K, swiglu, out_f32, s);
+                        int batch, int N, int K, int swiglu, int out_f32, const float* ss_in, float* ss_out, hipStream_t s) {
+  return skinny_dispatch<false>(x, W, nullptr, norm_w, eps, residual, out, batch, N, K, swiglu, out_f32, ss_in, ss_out, s);
 }
+
+// fp8 weights, any batch size (16 rows per weight pass); ss_in / ss_out: the rows' statistics tables (see skinny_kernel)
+int srgpt_skinny_w8_launch(const void* x, const void* W8, const float* wscale, const void* norm_w, float norm_eps,
+                           const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32,
+                           const float* ss_in, float* ss_out, hipStream_t s) {
+  const size_t on = out_f32 ? sizeof(float) : 2;
+  for (int b0 = 0; b0 < batch; b0 += 16) {
+    const int nb = batch - b0 < 16 ? batch - b0 : 16;
+    SRGPT_TRY(skinny_dispatch<true>((const char*)x + (size_t)b0 * K * 2, W8, wscale, norm_w, norm_eps,
+                                    residual ? (const char*)residual + (size_t)b0 * N * 2 : nullptr,
+                                    (char*)out + (size_t)b0 * N * on, nb, N, K, swiglu, out_f32,
+                                    ss_in ? ss_in + (size_t)b0 * SRGPT_ROWSS_STRIDE : nullptr,
+                                    ss_out ? ss_out + (size_t)b0 * SRGPT_ROWSS_STRIDE : nullptr, s));
+  }
+  return SRGPT_OK;
+}
+
+// rows at or below this count take the one-row VALU kernel of gemv_w8.hip (which neither reads nor publishes row statistics)
+int srgpt_w8_valu_max_batch() { return SRGPT_KNOB("SRGPT_W8_VALU_MAX_BATCH", 1); }  // 2 rows: the MFMA kernel is 7 % faster per step (round 3)
 
 // Decode-path product with fp8 (OCP e4m3fn) weights and one fp32 scale per weight row, bf16 activations (W8A16):
 // out[b, n] = bf16( (sum_k x[b, k] * fp8(W8[n, k])) * wscale[n] ), same fusions as srgpt_gemv.  Any batch size
@@ -508,15 +601,8 @@ extern "C" int srgpt_gemv_w8(const void* x, const void* W8, const float* wscale,
   SRGPT_CHECK(K % 8 == 0, SRGPT_ERR_ARG, "srgpt_gemv_w8: K=%d must be a multiple of 8", K);
   SRGPT_CHECK(!(swiglu && (residual || out_f32)), SRGPT_ERR_ARG, "srgpt_gemv_w8: swiglu excludes residual/out_f32");
   hipStream_t s = as_stream(stream);
-  const int valu_max = SRGPT_KNOB("SRGPT_W8_VALU_MAX_BATCH", 1);  // tuning knob; 2 rows: the MFMA kernel is 7 % faster per step (round 3)
+  const int valu_max = srgpt_w8_valu_max_batch();
   if (batch <= valu_max && batch <= 2 && K % 16 == 0)  // one row: VALU kernel (gemv_w8.hip), like the bf16 path
     return srgpt_gemv_w8_valu(x, W8, wscale, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, s);
-  const size_t on = out_f32 ? sizeof(float) : 2;
-  for (int b0 = 0; b0 < batch; b0 += 16) {
-    const int nb = batch - b0 < 16 ? batch - b0 : 16;
-    SRGPT_TRY(skinny_dispatch<true>((const char*)x + (size_t)b0 * K * 2, W8, wscale, norm_w, norm_eps,
-                                    residual ? (const char*)residual + (size_t)b0 * N * 2 : nullptr,
-                                    (char*)out + (size_t)b0 * N * on, nb, N, K, swiglu, out_f32, s));
-  }
-  return SRGPT_OK;
+  return srgpt_skinny_w8_launch(x, W8, wscale, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, nullptr, nullptr, s);
 }

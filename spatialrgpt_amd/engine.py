@@ -554,7 +554,14 @@ class SrgptEngine:
         B = st.batch
         if getattr(self, "_copy_stream", None) is None:
             self._copy_stream = torch.cuda.Stream(device=self.device)
-        host = torch.empty((B, max_new_tokens), dtype=torch.int64).pin_memory()
+        # One step's ids are the COLUMN out_ids[:, t]: a strided source for B > 1, and torch serves a strided D2H through a pageable
+        # temporary plus a host-side copy that no event covers.  So the column is gathered into a contiguous device
+        # scratch on the copy stream and leaves as ONE contiguous copy into a pinned, step-major buffer: the `done` event covers
+        # everything the judge reads.
+        host_t = torch.empty((max_new_tokens, B), dtype=torch.int64).pin_memory()
+        host = host_t.t()  # [B, steps] view for the judge (HF criteria index ids[b, -n:])
+        scratch = torch.empty((B,), dtype=torch.int64, device=self.device)
+        assert host_t.is_pinned() and host_t[0].is_contiguous() and scratch.is_contiguous()
         dec = torch.cuda.current_stream(self.device)
 
         def mark():
@@ -565,7 +572,8 @@ class SrgptEngine:
         def fetch(col, ev):
             with torch.cuda.stream(self._copy_stream):
                 self._copy_stream.wait_event(ev)
-                host[:, col:col + 1].copy_(st.out_ids[:, col:col + 1], non_blocking=True)
+                scratch.copy_(st.out_ids[:, col])                 # device gather (copy stream: ordered behind the previous D2H)
+                host_t[col].copy_(scratch, non_blocking=True)     # contiguous, pinned: truly asynchronous
                 done = torch.cuda.Event()
                 done.record(self._copy_stream)
             return done

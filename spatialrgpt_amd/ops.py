@@ -142,6 +142,34 @@ def gemv_w8(x, w8, wscale, norm_w=None, eps=0.0, residual=None, swiglu=False, ou
     return out
 
 
+def gemv_rowss_supported(batch: int, fp8: bool = False) -> bool:
+    """does a (batch, bf16 activations, bf16 / fp8 weights) decode product take the kernel with the row-statistics hand-off?"""
+    return bool(L.load().srgpt_gemv_rowss_supported(int(batch), L.BF16, int(fp8)))
+
+
+def gemv_rowss(x, w=None, w8=None, wscale=None, norm_w=None, eps=0.0, residual=None, swiglu=False, out=None, out_f32=False,
+               rowss_in=None, publish=False):
+    """srgpt_gemv_rowss: the decode product of 2+ bf16 rows as the batched decode step runs it.  `rowss_in`: the statistics
+    table of x's rows ([B, 512] fp32, from the call that produced x) replaces the RMSNorm's own reduction; `publish`: also
+    return the table of the output rows.  Returns out, or (out, table)."""
+    wt = w8 if w8 is not None else w
+    _dev(x, wt, wscale, norm_w, residual, rowss_in)
+    _same_dtype("gemv_rowss", x, norm_weight=norm_w, residual=residual)
+    if x.dtype != torch.bfloat16:
+        raise ValueError("gemv_rowss: bf16 activations only")
+    B, K = x.shape
+    N = wt.shape[0] // 2 if swiglu else wt.shape[0]
+    if out is None:
+        out = torch.empty((B, N), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    table = torch.empty((B, L.ROWSS_STRIDE), device=x.device, dtype=torch.float32) if publish else None
+    if rowss_in is not None and (rowss_in.dtype != torch.float32 or tuple(rowss_in.shape) != (B, L.ROWSS_STRIDE)
+                                 or not rowss_in.is_contiguous()):
+        raise ValueError("gemv_rowss: rowss_in must be a contiguous fp32 [batch, 512] table")
+    L.check(L.load().srgpt_gemv_rowss(_p(_c(x)), _p(w) if w8 is None else None, _p(w8), _p(wscale), _p(norm_w), float(eps),
+                                      _p(residual), _p(out), B, N, K, int(swiglu), int(out_f32), _p(rowss_in), _p(table), _stream()))
+    return (out, table) if publish else out
+
+
 def gemm_w8(a, w8, wscale, bias=None, residual=None, act=L.ACT_NONE, out=None, out_f32=False):
     """act((a @ fp8(w8).T) * wscale + bias) + residual: a [M,K] bf16 (row stride may exceed K), w8 uint8 [N,K] (OCP e4m3fn),
     wscale fp32 [N]."""

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/srgpt.h but not exported"
     assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.srgpt_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.srgpt_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_product_library_exports_nothing_but_the_header():
@@ -92,6 +92,11 @@ def test_argument_validation_without_gpu():
     assert rc == _lib.ERR_ARG and b"swiglu" in lib.srgpt_last_error()
     rc = lib.srgpt_gemv_w8(16, 16, None, None, 0.0, None, 16, 1, 8, 8, 0, 0, None)  # missing row scales
     assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
+    # ABI 8: the row-statistics products validate before they ask the device anything
+    rc = lib.srgpt_gemv_rowss(16, None, None, None, None, 0.0, None, 16, 4, 8, 8, 0, 0, None, None, None)  # neither bf16 nor fp8 weights
+    assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
+    rc = lib.srgpt_gemv_rowss(16, None, 16, None, None, 0.0, None, 16, 4, 8, 8, 0, 0, None, None, None)  # fp8 bytes without row scales
+    assert rc == _lib.ERR_ARG and b"row scales" in lib.srgpt_last_error()
     assert lib.srgpt_decode_attn_ws_floats(1, 32, 128) == 32 * 64 * 130 + 32  # split partials + arrival tickets
     rc = lib.srgpt_gemm_w8(16, 16, None, None, None, 16, 4, 4, 64, 64, 4, 0, 0, None, 0, None)  # missing row scales
     assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()

@@ -358,6 +358,75 @@ def test_gemv_w8_swiglu(B, N, K):
     assert_close(ops.gemv_w8(x.to(DEV), q8, sc, swiglu=True), ref, _tol(ref, dtype), 0, "swiglu gemv_w8")
 
 
+# ------------------------------------------------------------------------------------------------ row-statistics hand-off (ABI 8)
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("B,N,K,N2", [(2, 4096, 4096, 6144), (8, 4096, 14336, 28672 // 2), (4, 2560, 6912, 1000), (16, 4096, 4096, 333),
+                                      (5, 1000, 1024, 130), (20, 520, 264, 77), (3, 4104, 512, 40)])
+def test_gemv_rowss_handoff(fp8, B, N, K, N2):
+    """srgpt_gemv_rowss: (1) the table a residual product publishes sums, per row, to sum(out^2) of the bf16 rows it wrote -- slots
+    past its grid zero; (2) the output itself is srgpt_gemv's, bit for bit; (3) a consumer normalising from that table agrees with
+    the consumer computing the statistics itself to within one bf16 rounding of a normalised element (the two reductions associate
+    differently), and both sit at the usual distance from fp32 torch; (4) the table is a pure function of the inputs (repeats equal)."""
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    if not ops.gemv_rowss_supported(B, fp8):
+        pytest.skip("no hand-off kernel for this batch")
+    x, w = _rand((B, K), dtype, 31).to(DEV), _rand((N, K), dtype, 32, 0.03).to(DEV)
+    r = _rand((B, N), dtype, 33).to(DEV)
+    g = (1 + 0.1 * _rand((N,), torch.float32, 34)).to(dtype).to(DEV)
+    w2 = _rand((N2, N), dtype, 35, 0.03).to(DEV)
+    if fp8:
+        q8, sc, _ = ops.quantize_fp8_rows(w)
+        q2, sc2, _ = ops.quantize_fp8_rows(w2)
+        kw1, kw2 = dict(w8=q8, wscale=sc), dict(w8=q2, wscale=sc2)
+        plain1 = ops.gemv_w8(x, q8, sc, residual=r)
+    else:
+        kw1, kw2 = dict(w=w), dict(w=w2)
+        plain1 = ops.gemv(x, w, residual=r)
+    h, table = ops.gemv_rowss(x, residual=r, publish=True, **kw1)
+    assert torch.equal(h, plain1)
+    assert table.shape == (B, L.ROWSS_STRIDE) and bool(torch.isfinite(table).all())
+    want = h.double().pow(2).sum(-1)
+    got = table.double().sum(-1)
+    assert float(((got - want).abs() / want).max()) < 2e-6, (got, want)
+    h2, table2 = ops.gemv_rowss(x, residual=r, publish=True, **kw1)
+    assert torch.equal(table, table2) and torch.equal(h, h2)
+    # consumer: published statistics vs its own
+    own = ops.gemv_w8(h, q2, sc2, norm_w=g, eps=1e-5) if fp8 else ops.gemv(h, w2, norm_w=g, eps=1e-5)
+    pub = ops.gemv_rowss(h, norm_w=g, eps=1e-5, rowss_in=table, **kw2)
+    hf = h.float().cpu()
+    xn = g.cpu().float() * (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(dtype).float()
+    wq2 = (q2.cpu().view(torch.float8_e4m3fn).float() * sc2.cpu()[:, None]) if fp8 else w2.float().cpu()
+    ref = xn.to(dtype).float() @ wq2.T
+    assert_close(pub, ref, _tol(ref, dtype), 0, "rowss consumer vs torch")
+    assert_close(pub, own.float().cpu(), _tol(ref, dtype, 0.5), 0, "rowss consumer vs own statistics")
+    # fp32 logits and SwiGLU consumers take the table too
+    lo = ops.gemv_rowss(h, norm_w=g, eps=1e-5, rowss_in=table, out_f32=True, **kw2)
+    assert lo.dtype == torch.float32
+    assert_close(lo, ref, _tol(ref, dtype), 0, "rowss consumer f32")
+    if N2 % 2 == 0:
+        half = N2 // 2
+        gate, up = (xn.to(dtype).float() @ wq2[:half].T).to(dtype), (xn.to(dtype).float() @ wq2[half:].T).to(dtype)
+        refs = F.silu(gate.float()).to(dtype).float() * up.float()
+        assert_close(ops.gemv_rowss(h, norm_w=g, eps=1e-5, rowss_in=table, swiglu=True, **kw2), refs, _tol(refs, dtype), 0, "rowss swiglu")
+
+
+def test_gemv_rowss_rejects_what_it_cannot_do():
+    ops, L = _ops()
+    x = _rand((1, 256), torch.bfloat16, 1).to(DEV)
+    w = _rand((64, 256), torch.bfloat16, 2).to(DEV)
+    assert not ops.gemv_rowss_supported(1) and not ops.gemv_rowss_supported(1, True)
+    with pytest.raises(NotImplementedError):
+        ops.gemv_rowss(x, w=w)
+    x4 = _rand((4, 256), torch.bfloat16, 1).to(DEV)
+    t = torch.zeros((4, L.ROWSS_STRIDE), device=DEV)
+    with pytest.raises(ValueError):  # a table without the RMSNorm it feeds
+        ops.gemv_rowss(x4, w=w, rowss_in=t)
+    w2 = _rand((128, 256), torch.bfloat16, 2).to(DEV)
+    with pytest.raises(ValueError):  # SwiGLU outputs are not residual-stream rows: nothing to publish
+        ops.gemv_rowss(x4, w=w2, swiglu=True, publish=True)
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("rows,cols", [(7, 1152), (3, 4608), (5, 64), (2, 72)])
@@ -629,6 +698,58 @@ def test_decode_step_equals_per_op_composition_bit_for_bit(geom):
         assert torch.equal(got, ref), f"{geom}: step {t} (context {T0 + t}): max diff {float((got - ref).abs().max())}"
     assert torch.equal(st.kcache[:, :, :, :T0 + G], kc[:, :, :, :T0 + G])
     # the arrival tickets of the decode attention are re-armed (zero) between steps
+    assert L.load().srgpt_llm_decode_sync_state(C.byref(w.llm), C.byref(st.c), ops._stream()) == 0, L.last_error()
+
+
+@pytest.mark.parametrize("B,fp8", [(2, False), (8, False), (8, True), (3, True), (20, False)])
+def test_batched_decode_step_equals_rowss_composition_bit_for_bit(B, fp8):
+    """The batched decode step (2+ rows: o_proj / down_proj publish the rows' sums of squares, the next RMSNorm reads them) must be
+    BIT-identical to the same layers composed from srgpt_gemv_rowss + srgpt_decode_attention, step after step; layer 0's q/k/v
+    normalises the embedding rows itself, lm_head takes the last down_proj's table."""
+    import ctypes as C
+
+    from spatialrgpt_amd import _lib as L
+    from spatialrgpt_amd import ops
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.engine import SrgptEngine
+    from spatialrgpt_amd.weights import synth_state_dict
+
+    cfg = SrgptConfig(vit_hidden=64, vit_inter=176, vit_layers=2, vit_heads=4, image_size=42, patch_size=14, layers=3, vocab=4098,
+                      mask_token_id=4096, depth_token_id=4097, hidden=4096, inter=14336, heads=32, kv_heads=8)
+    dt = torch.bfloat16
+    eng = SrgptEngine(cfg, synth_state_dict(cfg, seed=5, dtype=dt, device=DEV), device=DEV, dtype=dt, rope_positions=512,
+                      **({"llm_weight_format": "fp8"} if fp8 else {}))
+    w = eng.w
+    assert ops.gemv_rowss_supported(B, fp8)
+    T0, G = 60, 5
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = (torch.randn((B, T0, cfg.hidden), device=DEV, generator=g) * 0.5).to(dt)
+    st, _, _ = eng.prefill(x, max_new=G + 2)
+    Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
+    toks = torch.randint(3, 4096, (G, B), device=DEV, generator=g)
+    kc, vc = st.kcache.clone(), st.vcache.clone()
+
+    def mat(name, i):
+        if fp8:
+            return dict(w8=w.llm_q[name][0][i], wscale=w.llm_q[name][1][i])
+        return dict(w=w.llm_t[name][i])
+
+    for t in range(G):
+        tok = toks[t].reshape(B, 1)
+        got = eng.step(st, tok)
+        h = ops.embed_rows(w.embed, tok.reshape(-1))
+        pos = torch.full((B,), T0 + t, device=DEV, dtype=torch.int32)
+        ss = None
+        for i in range(cfg.layers):
+            qkv = ops.gemv_rowss(h, norm_w=w.llm_t["attn_norm"][i], eps=cfg.rms_eps, rowss_in=ss, **mat("wqkv", i))
+            a = ops.decode_attention(qkv, kc[i], vc[i], pos, w.rope_cos, w.rope_sin, Hq, Hkv, D)
+            h, ss = ops.gemv_rowss(a, residual=h, publish=True, **mat("wo", i))
+            act = ops.gemv_rowss(h, norm_w=w.llm_t["mlp_norm"][i], eps=cfg.rms_eps, swiglu=True, rowss_in=ss, **mat("wgu", i))
+            h, ss = ops.gemv_rowss(act, residual=h, publish=True, **mat("wdown", i))
+        head = dict(w8=w.lm_head8, wscale=w.lm_head_scale) if fp8 else dict(w=w.lm_head)
+        ref = ops.gemv_rowss(h, norm_w=w.final_norm, eps=cfg.rms_eps, out_f32=True, rowss_in=ss, **head)
+        assert torch.equal(got, ref), f"B={B} fp8={fp8}: step {t}: max diff {float((got - ref).abs().max())}"
+    assert torch.equal(st.kcache[:, :, :, :T0 + G], kc[:, :, :, :T0 + G])
     assert L.load().srgpt_llm_decode_sync_state(C.byref(w.llm), C.byref(st.c), ops._stream()) == 0, L.last_error()
 
 
