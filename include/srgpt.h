@@ -264,6 +264,29 @@ int srgpt_im2col(const void* images, void* out, int n_img, int S, int patch, int
  * --------------------------------------------------------------------------------------------- */
 int srgpt_embed_rows(const void* table, const int64_t* ids, void* out, int n, int cols, int dtype,
                      srgpt_stream_t stream);
+/* ABI 8: the whole splice of prepare_inputs_labels_for_multimodal (llava_arch.py:420-611) on the device, ids never leave it.
+ * srgpt_splice_plan (one block per prompt): from ids [B, P] int64 (+ optional attention mask [B, P] bytes) builds, per prompt, the
+ *   source of every output row -- desc [B][Tcap][2] = {kind | src << 2, prompt position or -1}; kind 0: embedding row `src` (a text
+ *   id), 1: image_features row, 2: mask-embedding row, 3: depth-embedding row -- following the reference rule by rule: masked-out
+ *   positions dropped (:434-447), each -200 sentinel replaced by the nimg_feat rows of the NEXT image over the batch (:453-469,
+ *   :506-511), the <mask> / <depth> ids of a prompt that owns images replaced IN ORDER by the region embeddings of the prompt's first
+ *   image (:470-505; img_info[i] = {rows of image i's region embeddings or -1 if it has none, their first row in the concatenated
+ *   embedding matrix}), the prompt cut at max_len (> 0; :541-547).  stats [B][SRGPT_SPLICE_STATS] ints = {length, length before the
+ *   cut, sentinels, <mask> ids, <depth> ids, first image index, min / max id sent to the embedding table}: what the host reads back
+ *   (the batch's T = max length, and the reference's error / warning conditions).  Tcap >= P + n_images_total * (nimg_feat - 1).
+ *   scratch: srgpt_splice_scratch_ints(B, n_images_total) ints.
+ * srgpt_splice_gather (one block per output row): out [B, T, cols] = the described rows, prompts shorter than T padded with zero
+ *   rows on the right (left_pad: on the left, :549-611); labels_out [B, T] (optional) = labels [B, P] at the row's prompt position,
+ *   ignore_index on image rows and padding; attn_mask_out [B, T] bytes (optional) = 1 on real rows. */
+#define SRGPT_SPLICE_STATS 8
+int64_t srgpt_splice_scratch_ints(int B, int n_images_total);
+int srgpt_splice_plan(const int64_t* ids, const unsigned char* attn_mask, int B, int P, int nimg_feat, int n_images_total,
+                      const int* img_info, int use_masks, int use_depths, int64_t mask_id, int64_t depth_id, int max_len, int Tcap,
+                      int* desc, int* stats, int* scratch, srgpt_stream_t stream);
+int srgpt_splice_gather(const int* desc, const int* stats, int B, int Tcap, int T, int left_pad, int cols, int dtype,
+                        const void* embed, const void* image_features, const void* mask_embeds, const void* depth_embeds,
+                        const int64_t* labels, int P, int64_t ignore_index, void* out, int64_t* labels_out,
+                        unsigned char* attn_mask_out, srgpt_stream_t stream);
 int srgpt_scatter_rows(const void* src, const int* src_idx, const int* idx, void* dst, int n, int cols,
                        int dtype, srgpt_stream_t stream);
 int srgpt_silu_mul(const void* gu, void* out, int rows, int inter, int dtype, srgpt_stream_t stream);

@@ -68,6 +68,7 @@ SAMPLING_KEPT_MAX = 256        # sample.hip SMP_LIST
 SAMPLING_VOCAB_MAX = 128 * 2048
 
 NORM_RMS, NORM_LAYER = 1, 2  # srgpt_gemm_norm
+SPLICE_STATS = 8             # SRGPT_SPLICE_STATS: ints per prompt the splice plan reports
 ROWSS_STRIDE = 512           # SRGPT_ROWSS_STRIDE: slots per row of a row-statistics table
 ABI_VERSION = 8  # include/srgpt.h; bumped with every export / layout change
 
@@ -87,6 +88,9 @@ _SIGNATURES = {
     "srgpt_gemm_w8a8": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, vp]),
     "srgpt_gemv": (i32, [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "srgpt_gemv_w8": (i32, [vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "srgpt_splice_scratch_ints": (i64, [i32, i32]),
+    "srgpt_splice_plan": (i32, [vp, vp, i32, i32, i32, i32, vp, i32, i32, i64, i64, i32, i32, vp, vp, vp, vp]),
+    "srgpt_splice_gather": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp]),
     "srgpt_gemv_rowss_supported": (i32, [i32, i32, i32]),
     "srgpt_gemv_rowss": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "srgpt_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, i32, i32, vp]),

@@ -60,6 +60,13 @@ class SrgptConfig:
         return self.grid ** 2 + (1 if self.tower == "clip" else 0)
 
     @property
+    def llm_image_tokens(self) -> int:
+        """rows one image contributes to the LLM sequence: the mlp_downsample projector folds 2x2 blocks of the (27 x 27 pooled, or
+        raw tower) grid, odd sides zero-padded (base_projector.py:32-52) -- 196 for every recipe of the reference."""
+        g = 27 if self.enable_region else int((self.tower_tokens - (1 if self.select_feature == "patch" else 0)) ** 0.5)
+        return ((g + 1) // 2) ** 2
+
+    @property
     def vit_layers_run(self) -> int:
         """hidden_states[select_layer] = output of this many encoder layers."""
         return self.vit_layers + 1 + self.select_layer if self.select_layer < 0 else self.select_layer

@@ -193,18 +193,18 @@ __global__ __launch_bounds__(SPL_NT) void splice_plan_kernel(const int64_t* __re
   }
 }
 
-template <typename T>
+template <typename E>
 __global__ __launch_bounds__(256) void splice_gather_kernel(const int* __restrict__ desc, const int* __restrict__ stats, int Tcap, int T,
-                                                            int left_pad, int cols, const T* __restrict__ embed,
-                                                            const T* __restrict__ image_features, const T* __restrict__ mask_embeds,
-                                                            const T* __restrict__ depth_embeds, const int64_t* __restrict__ labels, int P,
-                                                            int64_t ignore_index, T* __restrict__ out, int64_t* __restrict__ labels_out,
+                                                            int left_pad, int cols, const E* __restrict__ embed,
+                                                            const E* __restrict__ image_features, const E* __restrict__ mask_embeds,
+                                                            const E* __restrict__ depth_embeds, const int64_t* __restrict__ labels, int P,
+                                                            int64_t ignore_index, E* __restrict__ out, int64_t* __restrict__ labels_out,
                                                             unsigned char* __restrict__ am_out) {
-  constexpr int VEC = Vec16<T>::N;
+  constexpr int VEC = Vec16<E>::N;
   const int b = blockIdx.x / T, jp = blockIdx.x - b * T;
   const int len = stats[(size_t)b * SRGPT_SPLICE_STATS + ST_LEN];
   const int j = jp - (left_pad ? T - len : 0);
-  T* dst = out + (size_t)blockIdx.x * cols;
+  E* dst = out + (size_t)blockIdx.x * cols;
   const bool valid = j >= 0 && j < len;
   if (!valid) {
     const u32x4 z = {0u, 0u, 0u, 0u};
@@ -218,8 +218,8 @@ __global__ __launch_bounds__(256) void splice_gather_kernel(const int* __restric
   const int* d = desc + ((size_t)b * Tcap + j) * 2;
   const int code = d[0], srcpos = d[1];
   const int kind = code & 3, src = code >> 2;
-  const T* table = kind == SPL_TEXT ? embed : kind == SPL_IMAGE ? image_features : kind == SPL_MASK ? mask_embeds : depth_embeds;
-  const T* s = table + (size_t)src * cols;
+  const E* table = kind == SPL_TEXT ? embed : kind == SPL_IMAGE ? image_features : kind == SPL_MASK ? mask_embeds : depth_embeds;
+  const E* s = table + (size_t)src * cols;
   for (int c = threadIdx.x; c < cols / VEC; c += blockDim.x)
     *reinterpret_cast<u32x4*>(dst + c * VEC) = *reinterpret_cast<const u32x4*>(s + c * VEC);
   if (threadIdx.x == 0) {

@@ -86,6 +86,13 @@ class DecodeState:
             pass
 
 
+class SplicePlan:
+    """what srgpt_splice_plan left on the device (row -> source table, per-prompt facts) + the host's copy of the facts"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
 class SrgptEngine:
     def __init__(self, cfg: SrgptConfig, state_dict: Dict[str, torch.Tensor], device="cuda", dtype=torch.bfloat16,
                  rope_positions: int = 0, consume_state_dict: bool = False, llm_weight_format: str = "native", parts=None):
@@ -241,155 +248,124 @@ class SrgptEngine:
         return image_features, mask_embeds, depth_embeds
 
     # ------------------------------------------------------------------ A6
+    def _region_counts(self, masks, n_images: int):
+        """rows of region embeddings each image will get (None: none) -- known from the mask list before any kernel runs"""
+        if not self.cfg.enable_region:
+            return None
+        if masks is None:
+            return [None] * n_images
+        return [None if m is None else int(m.shape[0]) for m in masks]
+
+    def splice_plan(self, input_ids: torch.Tensor, attention_mask, n_images: int, region_counts, have_depths: bool,
+                    nimg_feat: Optional[int] = None) -> "SplicePlan":
+        """Token-stream splice, step 1 (llava_arch.py:420-611): the row -> source table of the whole batch, built ON THE DEVICE from
+        the ids (csrc/splice.hip) -- the ids never travel; what comes back is 8 ints per prompt (lengths, counts, id range) for the
+        batch length T and the reference's error / warning conditions.  prepare_inputs() calls this BEFORE it launches the vision
+        tower, so the one read-back of the request waits for nothing."""
+        cfg, dev = self.cfg, self.device
+        ids = input_ids.detach().to(device=dev, dtype=torch.int64).contiguous()
+        B, P = ids.shape
+        am8 = None
+        if attention_mask is not None:
+            am8 = attention_mask.detach().to(device=dev).ne(0).to(torch.uint8).contiguous()
+        nf = cfg.llm_image_tokens if nimg_feat is None else int(nimg_feat)
+        use_masks = bool(cfg.enable_region and region_counts is not None)
+        use_depths = bool(cfg.enable_region and cfg.enable_depth and have_depths and region_counts is not None)
+        info, off = [], 0
+        for i in range(n_images):
+            c = region_counts[i] if (region_counts is not None and i < len(region_counts)) else None
+            info += [-1 if c is None else c, off]
+            off += 0 if c is None else c
+        info_dev = torch.tensor(info or [0, 0], dtype=torch.int32).to(dev)
+        Tcap = max(P + n_images * max(nf - 1, 0), 1)
+        lib = L.load()
+        desc = torch.empty((B, Tcap, 2), device=dev, dtype=torch.int32)
+        stats = torch.empty((B, L.SPLICE_STATS), device=dev, dtype=torch.int32)
+        scratch = torch.empty((max(int(lib.srgpt_splice_scratch_ints(B, n_images)), 1),), device=dev, dtype=torch.int32)
+        mx = cfg.tokenizer_model_max_length
+        L.check(lib.srgpt_splice_plan(ids.data_ptr(), None if am8 is None else am8.data_ptr(), B, P, nf, n_images, info_dev.data_ptr(),
+                                      int(use_masks), int(use_depths), int(cfg.mask_token_id), int(cfg.depth_token_id),
+                                      int(mx) if mx is not None else 0, Tcap, desc.data_ptr(), stats.data_ptr(), scratch.data_ptr(),
+                                      ops._stream()))
+        host = stats.cpu().tolist()  # the request's one device -> host copy (B x 8 ints)
+        for b, (ln, ln_raw, n_img, n_mask, n_depth, first_img, mn, mxid) in enumerate(host):
+            if n_img > 0:
+                if first_img + n_img > n_images:
+                    raise IndexError(f"index {first_img + n_img - 1} is out of bounds for dimension 0 with size {n_images}: "
+                                     "more <image> tokens than images")
+                me = region_counts[first_img] if region_counts is not None else None
+                if cfg.enable_region and me is None and n_mask > 0:
+                    print("Error: mask embed is None, but the num of <mask> is not 0!!!")
+                if cfg.enable_region and cfg.enable_depth and have_depths and me is None and n_depth > 0:
+                    print("Error: depth embed is None, but the num of <depth> is not 0!!!")
+                if use_masks and me is not None and n_mask > me:
+                    raise RuntimeError(f"shape mismatch: {n_mask} <mask> tokens but only {me} mask embeddings")
+                if use_depths and me is not None and n_depth > me:
+                    raise RuntimeError(f"shape mismatch: {n_depth} <depth> tokens but only {me} depth embeddings")
+        lo, hi = min(r[6] for r in host), max(r[7] for r in host)  # (0, 0) for a prompt without text rows
+        if lo < 0 or hi >= self.w.vocab:
+            raise IndexError(f"index out of range in self: token ids must be in [0, {self.w.vocab}), got [{lo}, {hi}]")
+        if mx is not None and any(r[1] > mx for r in host):
+            warnings.warn("Inputs truncated!")
+        lens = [r[0] for r in host]
+        return SplicePlan(ids=ids, B=B, P=P, nimg_feat=nf, n_images=n_images, Tcap=Tcap, desc=desc, stats=stats, lens=lens,
+                          T=max(max(lens), 1), have_attention_mask=attention_mask is not None,
+                          am_dtype=None if attention_mask is None else attention_mask.dtype,
+                          region_counts=region_counts, have_depths=have_depths, attention_mask=attention_mask)
+
+    def splice_apply(self, plan: "SplicePlan", image_features, mask_embeds, depth_embeds, labels=None):
+        """Token-stream splice, step 2: ONE gather launch writes every row of inputs_embeds [B, T, H] from its source (embedding
+        table, image features, region embeddings, zeros for padding) and, when asked, the spliced labels / attention mask."""
+        cfg, dev = self.cfg, self.device
+        B, T, H = plan.B, plan.T, cfg.hidden
+        out = torch.empty((B * T, H), device=dev, dtype=self.dtype)
+        feats = image_features.reshape(-1, H).to(dtype=self.dtype).contiguous()
+        me = de = None
+        if mask_embeds is not None and any(e is not None for e in mask_embeds):
+            me = torch.cat([e for e in mask_embeds if e is not None], 0).to(self.dtype).contiguous()
+        if depth_embeds is not None and any(e is not None for e in depth_embeds):
+            de = torch.cat([e for e in depth_embeds if e is not None], 0).to(self.dtype).contiguous()
+        lab = None if labels is None else labels.detach().to(device=dev, dtype=torch.int64).contiguous()
+        lab_out = torch.empty((B, T), device=dev, dtype=torch.int64) if labels is not None else None
+        am_out = torch.empty((B, T), device=dev, dtype=torch.uint8) if plan.have_attention_mask else None
+        L.check(L.load().srgpt_splice_gather(plan.desc.data_ptr(), plan.stats.data_ptr(), B, plan.Tcap, T,
+                                             int(cfg.padding_side == "left"), H, ops.dt_code(out), self.w.embed.data_ptr(),
+                                             feats.data_ptr(), None if me is None else me.data_ptr(),
+                                             None if de is None else de.data_ptr(), None if lab is None else lab.data_ptr(), plan.P,
+                                             IGNORE_INDEX, out.data_ptr(), None if lab_out is None else lab_out.data_ptr(),
+                                             None if am_out is None else am_out.data_ptr(), ops._stream()))
+        am = None if am_out is None else am_out.to(plan.am_dtype)
+        if labels is not None:
+            return out.reshape(B, T, H), am, plan.lens, lab_out
+        return out.reshape(B, T, H), am, plan.lens
+
     def splice(self, input_ids: torch.Tensor, attention_mask, image_features, mask_embeds, depth_embeds, have_depths,
                labels=None):
-        """Token-stream splice (llava_arch.py:420-611).  Index arithmetic on the host from the (tiny) id
-        tensor -- ONE device->host copy -- then four row gather/scatter kernels.
+        """plan + gather for callers that already hold the visual features.
         Returns (inputs_embeds [B,T,H], attention_mask|None, lengths list); with `labels` ([B,P] int64) a 4th value: the
         spliced labels [B,T] on the device (IGNORE_INDEX over image rows and padding, llava_arch.py:513-533, :558-611)."""
-        cfg = self.cfg
-        ids_cpu = input_ids.detach().to("cpu")
-        B, P = ids_cpu.shape
-        am_cpu = torch.ones_like(ids_cpu, dtype=torch.bool) if attention_mask is None else attention_mask.detach().to("cpu").bool()
-        nimg_feat = image_features.shape[1]
-        rows_tok: List[int] = []      # flat output row of each kept text token
-        ids_tok: List[int] = []
-        img_src: List[int] = []
-        img_dst: List[int] = []
-        m_src: List[int] = []
-        m_dst: List[int] = []
-        d_src: List[int] = []
-        d_dst: List[int] = []
-        seqs = []  # per sample: list of ("t", id) / ("i", image_idx, r)
-        cur_image_idx = 0
-        mask_off, n_me = [], 0
-        if mask_embeds is not None:
-            for e in mask_embeds:
-                mask_off.append(n_me)
-                n_me += 0 if e is None else e.shape[0]
-        lab_cpu = None if labels is None else labels.detach().to("cpu")
-        labs = []  # per sample: label of every output row (IGNORE_INDEX for image rows)
-        for b in range(B):
-            cur = ids_cpu[b][am_cpu[b]].tolist()
-            cur_lab = [IGNORE_INDEX] * len(cur) if lab_cpu is None else lab_cpu[b][am_cpu[b]].tolist()
-            n_images = sum(1 for t in cur if t == IMAGE_TOKEN_INDEX)
-            seq = []
-            if n_images == 0:
-                seqs.append([("t", t) for t in cur])
-                labs.append(cur_lab)
-                continue
-            lab = []
-            first_img = cur_image_idx
-            nm = nd = 0
-            n_mask_tok = sum(1 for t in cur if t == cfg.mask_token_id)
-            n_depth_tok = sum(1 for t in cur if t == cfg.depth_token_id)
-            me = mask_embeds[first_img] if (cfg.enable_region and mask_embeds is not None) else None
-            de = depth_embeds[first_img] if (cfg.enable_region and cfg.enable_depth and have_depths and depth_embeds is not None) else None
-            if cfg.enable_region and me is None and n_mask_tok > 0:
-                print("Error: mask embed is None, but the num of <mask> is not 0!!!")
-            if cfg.enable_region and cfg.enable_depth and have_depths and de is None and n_depth_tok > 0:
-                print("Error: depth embed is None, but the num of <depth> is not 0!!!")
-            if me is not None and n_mask_tok > me.shape[0]:
-                raise RuntimeError(f"shape mismatch: {n_mask_tok} <mask> tokens but only {me.shape[0]} mask embeddings")
-            if de is not None and n_depth_tok > de.shape[0]:
-                raise RuntimeError(f"shape mismatch: {n_depth_tok} <depth> tokens but only {de.shape[0]} depth embeddings")
-            for t, tl in zip(cur, cur_lab):
-                if t == IMAGE_TOKEN_INDEX:
-                    seq.extend(("i", cur_image_idx, r) for r in range(nimg_feat))
-                    lab.extend([IGNORE_INDEX] * nimg_feat)
-                    cur_image_idx += 1
-                    continue
-                lab.append(tl)
-                if me is not None and t == cfg.mask_token_id:
-                    seq.append(("m", mask_off[first_img] + nm))
-                    nm += 1
-                elif de is not None and t == cfg.depth_token_id:
-                    seq.append(("d", mask_off[first_img] + nd))
-                    nd += 1
-                else:
-                    seq.append(("t", t))
-            seqs.append(seq)
-            labs.append(lab)
-        mx = cfg.tokenizer_model_max_length
-        if mx is not None:
-            if any(len(s) > mx for s in seqs):
-                warnings.warn("Inputs truncated!")
-            seqs = [s[:mx] for s in seqs]
-            labs = [l[:mx] for l in labs]
-        lens = [len(s) for s in seqs]
-        T = max(lens)
-        left = cfg.padding_side == "left"
-        ragged = any(n != T for n in lens)
-        for b, seq in enumerate(seqs):
-            off = b * T + (T - len(seq) if left else 0)
-            for j, item in enumerate(seq):
-                r = off + j
-                if item[0] == "t":
-                    rows_tok.append(r)
-                    ids_tok.append(0 if item[1] == IMAGE_TOKEN_INDEX else item[1])
-                elif item[0] == "i":
-                    img_src.append(item[1] * nimg_feat + item[2])
-                    img_dst.append(r)
-                elif item[0] == "m":
-                    m_src.append(item[1])
-                    m_dst.append(r)
-                else:
-                    d_src.append(item[1])
-                    d_dst.append(r)
-        H = cfg.hidden
-        dev = self.device
-        out = (torch.zeros if ragged else torch.empty)((B * T, H), device=dev, dtype=self.dtype)
-
-        # ONE host -> device copy carries every index list of the splice (token ids, and the source / destination rows of the text,
-        # image, <mask> and <depth> placements); the kernels below take views of it
-        lists = [ids_tok, list(range(len(ids_tok))), rows_tok, img_src, img_dst, m_src, m_dst, d_src, d_dst]
-        flat = torch.tensor([v for l_ in lists for v in l_], dtype=torch.int64)
-        flat_dev = flat.to(dev)
-        idx32 = flat_dev.to(torch.int32)
-        offs, o = [], 0
-        for l_ in lists:
-            offs.append((o, o + len(l_)))
-            o += len(l_)
-
-        def place(src2d, which_src, which_dst):
-            (a0, a1), (b0, b1) = offs[which_src], offs[which_dst]
-            if b1 == b0:
-                return
-            ops.scatter_rows(src2d.contiguous(), idx32[b0:b1], out, src_idx=idx32[a0:a1])
-
-        if ids_tok:
-            self._check_ids(ids_tok)
-            emb = ops.embed_rows(self.w.embed, flat_dev[offs[0][0]:offs[0][1]])
-            place(emb, 1, 2)
-        place(image_features.reshape(-1, H), 3, 4)
-        if m_dst:
-            place(torch.cat([e for e in mask_embeds if e is not None], 0), 5, 6)
-        if d_dst:
-            place(torch.cat([e for e in depth_embeds if e is not None], 0), 7, 8)
-        am_out = None
-        if attention_mask is not None:
-            am = torch.zeros((B, T), dtype=torch.bool)
-            for b, n in enumerate(lens):
-                if left:
-                    am[b, T - n:] = True
-                else:
-                    am[b, :n] = True
-            am_out = am.to(device=dev, dtype=attention_mask.dtype)
-        if labels is not None:
-            new_labels = torch.full((B, T), IGNORE_INDEX, dtype=torch.int64)
-            for b, l in enumerate(labs):
-                if l:
-                    if left:
-                        new_labels[b, T - len(l):] = torch.tensor(l, dtype=torch.int64)
-                    else:
-                        new_labels[b, :len(l)] = torch.tensor(l, dtype=torch.int64)
-            return out.reshape(B, T, H), am_out, lens, new_labels.to(dev)
-        return out.reshape(B, T, H), am_out, lens
+        counts = None
+        if self.cfg.enable_region and mask_embeds is not None:
+            counts = [None if e is None else int(e.shape[0]) for e in mask_embeds]
+        plan = self.splice_plan(input_ids, attention_mask, image_features.shape[0], counts,
+                                have_depths and depth_embeds is not None, nimg_feat=image_features.shape[1])
+        return self.splice_apply(plan, image_features, mask_embeds, depth_embeds, labels)
 
     def prepare_inputs(self, input_ids, images, depths=None, masks=None, attention_mask=None, stages=None, labels=None):
+        # the splice is PLANNED first: its read-back (lengths, the reference's error conditions) happens while the GPU has nothing
+        # queued; then the tower / refinement / pooling / projector launches go out back to back and the gather follows them
+        if isinstance(images, (list, tuple)):
+            n_images = sum(int(im.shape[0]) for im in images)
+        else:
+            n_images = int(images.shape[0] * images.shape[1]) if images.ndim == 5 else int(images.shape[0])
+        counts = self._region_counts(masks, n_images)
+        use_depth = self.cfg.enable_region and self.cfg.enable_depth and depths is not None
+        plan = self.splice_plan(input_ids, attention_mask, n_images, counts, use_depth)
         image_features, mask_embeds, depth_embeds = self.encode_visual(images, depths, masks, stages)
-        res = self.splice(input_ids, attention_mask, image_features, mask_embeds, depth_embeds,
-                          have_depths=depths is not None, labels=labels)
+        if image_features.shape[1] != plan.nimg_feat or image_features.shape[0] != plan.n_images:  # a geometry the config did not predict
+            plan = self.splice_plan(input_ids, attention_mask, image_features.shape[0], counts, use_depth,
+                                    nimg_feat=image_features.shape[1])
+        res = self.splice_apply(plan, image_features, mask_embeds, depth_embeds, labels)
         if stages is not None:
             stages["inputs_embeds"] = res[0]
         return res
