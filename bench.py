@@ -299,7 +299,9 @@ def main():
     sd_cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
-    model = LlavaLlamaModel(cfg, sd, device=device, dtype=dtype, rope_positions=1024, consume_state_dict=True,
+    # RoPE table: the request's positions (spliced prompt + new tokens), at least the 1024 every earlier round's line used
+    rope_positions = max(1024, (spliced_len(cfg, args.prompt_len) + G + 127) // 128 * 128)
+    model = LlavaLlamaModel(cfg, sd, device=device, dtype=dtype, rope_positions=rope_positions, consume_state_dict=True,
                             llm_weight_format=args.weights if args.weights != "bf16" else "native")
     del sd
     model.engine.use_graph = not args.no_graph

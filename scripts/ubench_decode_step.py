@@ -1,5 +1,6 @@
 """decode ms/token of the whole graph-captured step for several (weights, batch) configurations in one process.
-  SRGPT_LIB=<path of a libsrgpt_hip*.so build> python scripts/ubench_decode_step.py fp8:8 fp8:4 bf16:4
+  SRGPT_LIB=<path of a libsrgpt_hip*.so build> python scripts/ubench_decode_step.py fp8:8 fp8:4 bf16:4 bf16:1:2048
+(weights:batch[:T] -- T = cached prompt positions, default 259)
 Knobs of the tuning builds (SRGPT_SKINNY_W8_MODE, SRGPT_DECODE_PREFETCH_ROUNDS, ...) are read from the environment once per
 process by the library itself; this script only reports them."""
 import os, sys
@@ -15,16 +16,17 @@ from spatialrgpt_amd.weights import synth_state_dict
 cfg = SrgptConfig.vila15_8b()
 G, T = 128, 259
 knobs = {k: v for k, v in os.environ.items() if k.startswith("SRGPT_")}
-wanted = [a.split(":") for a in sys.argv[1:]] or [["bf16", "1"]]
-for fmt in sorted({w for w, _ in wanted}):
+wanted = [(a.split(":") + [str(T)])[:3] for a in sys.argv[1:]] or [["bf16", "1", str(T)]]
+rope = max(1024, max(int(t) for _, _, t in wanted) + G + 128)
+for fmt in sorted({w for w, _, _ in wanted}):
     sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device="cuda")
-    eng = SrgptEngine(cfg, sd, device="cuda", dtype=torch.bfloat16, rope_positions=1024, consume_state_dict=True,
+    eng = SrgptEngine(cfg, sd, device="cuda", dtype=torch.bfloat16, rope_positions=rope, consume_state_dict=True,
                       llm_weight_format="fp8" if fmt == "fp8" else "native")
     del sd
-    for w, b in wanted:
+    for w, b, t_ in wanted:
         if w != fmt:
             continue
-        B = int(b)
+        B, T = int(b), int(t_)
         x = torch.randn((B, T, cfg.hidden), device="cuda").to(torch.bfloat16)
         best = 1e9
         for rep in range(3):
@@ -33,7 +35,8 @@ for fmt in sorted({w for w, _ in wanted}):
             torch.cuda.synchronize(); e0.record(); eng.greedy_decode(st, G); e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / G)
         wb = eng.w.llm_weight_bytes()
-        print(f"{os.path.basename(_lib.LIB_PATH)} {knobs} | {fmt} batch {B}: {best:.4f} ms/step = {B / best * 1e3:.0f} tok/s decode-only, "
-              f"{wb / best / 1e9:.2f} TB/s of weights = {wb / best / 1e9 / 8:.3f} of 8 TB/s", flush=True)
+        print(f"{os.path.basename(_lib.LIB_PATH)} {knobs} | {fmt} batch {B}{'' if T == 259 else f' T {T}'}: {best:.4f} ms/step = {B / best * 1e3:.0f} tok/s decode-only, "
+              f"{wb / best / 1e9:.2f} TB/s of weights = {wb / best / 1e9 / 8:.3f} of 8 TB/s"
+              + ("" if T == 259 else f"; + KV {B * 2 * cfg.layers * cfg.kv_heads * cfg.head_dim * 2 * (T + G // 2) / 1e6:.0f} MB/step"), flush=True)
     del eng
     torch.cuda.empty_cache()

@@ -113,6 +113,7 @@ _SIGNATURES = {
     "srgpt_cross_entropy": (i32, [vp, vp, vp, vp, i32, i32, i64, vp]),
     "srgpt_sample_ws_bytes": (i64, [i32]),
     "srgpt_sample": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "srgpt_sample_status": (i32, [vp, i32, vp]),
     "srgpt_image_resize_normalize": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp]),
     "srgpt_mask_resize_nearest": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp]),
     "srgpt_mask_pad_resize": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32, vp]),

@@ -620,6 +620,9 @@ extern "C" int srgpt_llm_decode_sync_state(const srgpt_llm_weights* w, const srg
   const size_t n = host.size() - 1;
   for (size_t i = 0; i < n; ++i)
     SRGPT_CHECK(host[i] == 0, SRGPT_ERR_STATE, "decode step: arrival ticket %zu of %zu is %d between steps (expected 0)", i, n, host[i]);
+  SRGPT_CHECK((host.back() & 4) == 0, SRGPT_ERR_UNSUPPORTED,
+              "decode step: sampling parameters the device sampler does not serve (top_k > 64, or top_p < 1 without top_k): the draws "
+              "used another distribution");
   SRGPT_CHECK((host.back() & 2) == 0, SRGPT_ERR_STATE,
               "decode step: more than 256 vocabulary entries tie at the top-k threshold of a sampling step (kept set truncated)");
   SRGPT_CHECK((host.back() & 1) == 0, SRGPT_ERR_STATE,

@@ -204,6 +204,10 @@ __global__ __launch_bounds__(1024) void sample_select_kernel(const srgpt_samplin
   __shared__ float ss[SMP_LIST];
   __shared__ int sidx[SMP_LIST];
   __shared__ unsigned n_valid, n_list;
+  // settings the device sampler does not serve must not draw from a silently different distribution: top_k beyond the
+  // candidate slots would be clamped, and a top-p filter without top-k would be ignored by the Gumbel path -- sticky error bit 4,
+  // reported by srgpt_llm_decode_sync_state / srgpt_sample_status
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (sp->top_k > SMP_K || (sp->top_k <= 0 && sp->top_p < 1.f))) atomicOr(err, 4);
   const int topk = min(sp->top_k, SMP_K);
   if (topk <= 0) return;  // Gumbel-max mode: the greedy merge (advance_kernel) picks
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -348,6 +352,19 @@ extern "C" int srgpt_sample(const float* logits, srgpt_sampling* sp, int64_t* to
   SRGPT_TRY(srgpt_sample_launch(logits, sp, tok_out, ws, pv, pi, err, B, V, s));
   hipLaunchKernelGGL(sample_bump_kernel, dim3(1), dim3(256), 0, s, sp, pv, pi, SMP_NB, tok_out, B);
   SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
+
+// health of the last srgpt_sample call(s) on this workspace (synchronises `stream`): the sticky error word at the tail of ws
+extern "C" int srgpt_sample_status(const void* ws, int B, srgpt_stream_t stream) {
+  SRGPT_CHECK(ws && B > 0, SRGPT_ERR_ARG, "srgpt_sample_status: bad args");
+  const char* tail = reinterpret_cast<const char*>(ws) + (size_t)B * SMP_NB * SMP_K * 8;
+  int host = 0;
+  SRGPT_HIP_TRY(hipMemcpyAsync(&host, tail + (size_t)B * SMP_NB * 8, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)), "srgpt_sample_status: copy");
+  SRGPT_HIP_TRY(hipStreamSynchronize(as_stream(stream)), "srgpt_sample_status: synchronize");
+  SRGPT_CHECK((host & 4) == 0, SRGPT_ERR_UNSUPPORTED,
+              "sampling: top_k > %d, or a top-p filter without top-k, is not served by the device sampler (the draw used another distribution)", SMP_K);
+  SRGPT_CHECK((host & 2) == 0, SRGPT_ERR_STATE, "sampling: more than %d vocabulary entries tie at the top-k threshold (kept set truncated)", SMP_LIST);
   return SRGPT_OK;
 }
 

@@ -186,6 +186,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   // 8 fp8 -> 8 bf16 (every e4m3 value is exactly representable in bf16)
   auto widen = [&](const u32x2& r) -> u32x4 {
     u32x4 o;
+#if defined(SRGPT_SKINNY_PROBE) && SRGPT_SKINNY_PROBE == 1  // timing probe (WRONG results): what would the K loop cost without the fp8 -> bf16 conversions?
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[0] ^ 0x3c003c00u; o[3] = r[1] ^ 0x3c003c00u;
+    return o;
+#endif
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // v_cvt_scalef32_pk_bf16_fp8 (gfx950): two fp8 -> packed bf16x2 in one instruction, scale 1
       o[2 * h] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(r[h], 1.0f, false));
@@ -368,8 +372,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
               stage_x(sl, true);
               load_x(i + h + 1 < cnt ? sl_of(i + h + 1) : sl_of(0));  // next slice, or the first one of the next pass
             }
+#if !(defined(SRGPT_SKINNY_PROBE) && SRGPT_SKINNY_PROBE == 2)
 #pragma unroll
             for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(wst + (2 * j + lrow) * WROWB + lchunk * 16) = staged(wb[cur][j]);
+#endif
             __builtin_amdgcn_wave_barrier();
             // The fragment reads of FS k steps are issued together in front of their MFMAs, which alternate between two
             // accumulators.  Left to the compiler the unrolled loop became read -> wait -> MFMA per k step on ONE accumulator: a
@@ -391,15 +397,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
                 const int s = s0 + t;
                 if constexpr (XREUSE) xf[t] = xall[s];
                 else xf[t] = *reinterpret_cast<const bf16x8*>(xst + xrow * XROWB + (4 * s + (lane >> 4)) * 16);
+#if defined(SRGPT_SKINNY_PROBE) && SRGPT_SKINNY_PROBE == 2  // timing probe (WRONG results): weights never pass through LDS
+                wfr[t] = __builtin_bit_cast(bf16x8, staged(wb[cur][s & 7]));
+#else
                 wfr[t] = *reinterpret_cast<const bf16x8*>(wst + (lane & 15) * WROWB + (4 * s + (lane >> 4)) * 16);
+#endif
               }
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int t = 0; t < FS; ++t) {
                 const bf16x8 wf = wfr[t];
                 // D[batch row][weight row] += x[batch row][k] * W[weight row][k]
+#if defined(SRGPT_SKINNY_PROBE) && SRGPT_SKINNY_PROBE == 3  // timing probe (WRONG results): no matrix instructions
+                acc[su][0] += (float)xf[t][0] * (float)wf[0];
+                acc[su][1] += (float)xf[t][7] * (float)wf[7];
+#else
                 if (TWO_ACC && (t & 1)) acc2[TWO_ACC ? su : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t], wf, acc2[TWO_ACC ? su : 0], 0, 0, 0);
                 else acc[su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t], wf, acc[su], 0, 0, 0);
+#endif
               }
               __builtin_amdgcn_sched_barrier(0);
             }

@@ -105,9 +105,13 @@ def warp_logits(logits: torch.Tensor, temperature=None, top_k=None, top_p=None, 
     return scores
 
 
-def beam_search(first_logits: torch.Tensor, step, batch: int, num_beams: int, max_new_tokens: int, eos_token_ids: Optional[List[int]],
-                pad_token_id: Optional[int], length_penalty: float = 1.0, early_stopping=False, stopping_criteria=None) -> torch.Tensor:
-    """`generate(num_beams > 1, do_sample=False)` as the reference's callers can ask for it (`--num_beams`: eval_spatial.py:234,
+def beam_search_v5(first_logits: torch.Tensor, step, batch: int, num_beams: int, max_new_tokens: int, eos_token_ids: Optional[List[int]],
+                   pad_token_id: Optional[int], length_penalty: float = 1.0, early_stopping=False, stopping_criteria=None) -> torch.Tensor:
+    """The VECTORISED beam search of the installed transformers (5.x) -- kept because tests/golden/beam_kat.npz could only be minted
+    with the installed release (the reference's generate(num_beams=3) run here); the product path is `beam_generate` below, which
+    follows the reference's PINNED release (4.37.2: BeamSearchScorer) and agrees with this one on the golden fixtures.
+
+    `generate(num_beams > 1, do_sample=False)` as the reference's callers can ask for it (`--num_beams`: eval_spatial.py:234,
     eval_region_cls.py:321, model_vqa.py:75; default 1): HF beam search over a decoder whose prompt was fed as `inputs_embeds`
     (llava_llama.py:212) -- so the id sequences start EMPTY, `max_length` counts new tokens only, and the length penalty divides
     by the number of generated tokens.  Semantics restated from transformers' GenerationMixin beam search (4.37.2's
@@ -198,3 +202,198 @@ def beam_search(first_logits: torch.Tensor, step, batch: int, num_beams: int, ma
         logits = step(run_seq[:, :, cur - 1].reshape(-1), (new_src + rows).reshape(-1))
     n = int(fin_len[:, 0].max())
     return fin_seq[:, 0, :max(n, 1)].contiguous()
+
+
+beam_search = beam_search_v5  # the name the golden-minting script and the CPU pin use
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# transformers==4.37.2 (the reference's pin, pyproject.toml:17): BeamSearchScorer / BeamHypotheses, GenerationMixin.beam_search and
+# GenerationMixin.beam_sample, restated for a decoder whose prompt went in as `inputs_embeds` (llava_llama.py:212): input_ids start
+# EMPTY, decoder_prompt_len = 0, max_length = max_new_tokens.  num_beam_groups 1, one returned sequence per batch item.
+# Differences from the vectorised 5.x form above that matter to a caller:
+#   * a batch item is done when its WORST kept hypothesis is at least as good as the best of ALL 2 x num_beams candidates of the step
+#     (EOS candidates included) at the current length -- 5.x compares against the best beam that keeps running;
+#   * the returned row holds the hypothesis WITHOUT the token that ended it, followed by eos_token_id[0] when there is room --
+#     whichever EOS id of a list fired (Llama-3 lists two);
+#   * stopping criteria end the whole search (`if beam_scorer.is_done or stopping_criteria(input_ids, scores): break`), the beams
+#     still running are then entered as hypotheses at their current length.
+# ------------------------------------------------------------------------------------------------------------------------------
+class _BeamHypotheses:
+    """transformers 4.37.2 generation/beam_search.py: BeamHypotheses (n-best list of one batch item)"""
+
+    def __init__(self, num_beams: int, length_penalty: float, early_stopping, max_length: Optional[int]):
+        self.num_beams, self.length_penalty, self.early_stopping, self.max_length = num_beams, length_penalty, early_stopping, max_length
+        self.beams: list = []  # (score, token list)
+        self.worst_score = 1e9
+
+    def __len__(self):
+        return len(self.beams)
+
+    def add(self, hyp: List[int], sum_logprobs: float, generated_len: int):
+        score = sum_logprobs / (generated_len ** self.length_penalty)
+        if len(self) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, hyp))
+            if len(self) > self.num_beams:
+                order = sorted([(s_, i) for i, (s_, _) in enumerate(self.beams)])
+                del self.beams[order[0][1]]
+                self.worst_score = order[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs: float, cur_len: int) -> bool:
+        if len(self) < self.num_beams:
+            return False
+        if self.early_stopping is True:
+            return True
+        if self.early_stopping is False:
+            return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
+        # "never"
+        if self.length_penalty > 0.0:
+            return self.worst_score >= best_sum_logprobs / self.max_length ** self.length_penalty
+        return self.worst_score >= best_sum_logprobs / cur_len ** self.length_penalty
+
+
+class BeamScorer437:
+    """transformers 4.37.2 BeamSearchScorer.process / .finalize on host lists (a step hands over 2 x num_beams candidates per batch
+    item: a few dozen numbers)."""
+
+    def __init__(self, batch: int, num_beams: int, max_length: int, length_penalty: float = 1.0, early_stopping=False):
+        self.batch, self.nb, self.max_length = batch, num_beams, max_length
+        self.hyps = [_BeamHypotheses(num_beams, length_penalty, early_stopping, max_length) for _ in range(batch)]
+        self.done = [False] * batch
+
+    @property
+    def is_done(self) -> bool:
+        return all(self.done)
+
+    def process(self, seqs: List[List[int]], next_scores, next_tokens, next_indices, pad_token_id, eos_token_ids):
+        """seqs: the batch * num_beams running id lists; next_*: [batch][K] candidates sorted by score (descending).
+        -> (beam_scores, beam_tokens, beam_idx) flat lists of batch * num_beams"""
+        nb = self.nb
+        cur_len = (len(seqs[0]) if seqs else 0) + 1
+        out_s, out_t, out_i = [], [], []
+        for b in range(self.batch):
+            if self.done[b]:
+                out_s += [0.0] * nb
+                out_t += [pad_token_id if pad_token_id is not None else 0] * nb
+                out_i += [0] * nb
+                continue
+            kept = 0
+            for rank, (tok, sc, idx) in enumerate(zip(next_tokens[b], next_scores[b], next_indices[b])):
+                row = b * nb + idx
+                if eos_token_ids is not None and tok in eos_token_ids:
+                    if rank >= nb:
+                        continue
+                    self.hyps[b].add(list(seqs[row]), sc, cur_len)
+                else:
+                    out_s.append(sc)
+                    out_t.append(tok)
+                    out_i.append(row)
+                    kept += 1
+                if kept == nb:
+                    break
+            if kept < nb:
+                raise ValueError(f"At most {nb} tokens in {next_tokens[b]} can be equal to `eos_token_id: {eos_token_ids}`. "
+                                 "Make sure they are defined correctly.")
+            self.done[b] = self.done[b] or self.hyps[b].is_done(max(next_scores[b]), cur_len)
+        return out_s, out_t, out_i
+
+    def finalize(self, seqs: List[List[int]], beam_scores: List[float], pad_token_id, eos_token_ids) -> List[List[int]]:
+        nb = self.nb
+        for b in range(self.batch):
+            if self.done[b]:
+                continue
+            for j in range(nb):
+                row = b * nb + j
+                self.hyps[b].add(list(seqs[row]), beam_scores[row], len(seqs[row]))
+        best = []
+        for b in range(self.batch):
+            best.append(sorted(self.hyps[b].beams, key=lambda x: x[0]).pop()[1])
+        lengths = [len(h) for h in best]
+        sent_max_len = min(max(lengths) + 1, self.max_length)
+        if min(lengths) != max(lengths) and pad_token_id is None:
+            raise ValueError("`pad_token_id` has to be defined")
+        rows = []
+        for h in best:
+            row = list(h[:sent_max_len])
+            if len(h) < sent_max_len:
+                row.append(eos_token_ids[0])  # "inserting only the first eos_token_id"
+            fill = pad_token_id if pad_token_id is not None else (eos_token_ids[0] if eos_token_ids else 0)
+            rows.append(row + [fill] * (sent_max_len - len(row)))
+        return rows
+
+
+def beam_sample_candidates(scores: torch.Tensor, n: int, generator: Optional[torch.Generator] = None):
+    """`torch.multinomial(softmax(scores), n)` WITHOUT replacement over the flattened (beam, token) axis, then HF's re-sort by score:
+    scores [B, num_beams * V] (filtered entries -inf) -> (cand_scores [B, n] descending, cand_index [B, n]).
+    Drawn as the top n of scores + Gumbel noise -- the Plackett-Luce order statistic, i.e. exactly sequential draws without
+    replacement from the softmax (Gumbel-top-k) -- so one top-k replaces n dependent multinomial draws.  A row with fewer than n
+    finite entries raises like torch.multinomial does ("invalid multinomial distribution")."""
+    if int(torch.isfinite(scores).sum(-1).min()) < n:
+        raise RuntimeError("invalid multinomial distribution (with replacement=False, not enough non-negative category to sample)")
+    u = torch.rand(scores.shape, device=scores.device, dtype=torch.float32, generator=generator).clamp_(1e-20, 1.0 - 1e-7)
+    keys = scores.float() - torch.log(-torch.log(u))
+    idx = torch.topk(keys, n, dim=-1)[1]
+    sc = torch.gather(scores.float(), -1, idx)
+    sc, order = torch.sort(sc, descending=True, dim=-1, stable=True)
+    return sc, torch.gather(idx, -1, order)
+
+
+def beam_generate(first_logits: torch.Tensor, step, batch: int, num_beams: int, max_new_tokens: int,
+                  eos_token_ids: Optional[List[int]], pad_token_id: Optional[int], do_sample: bool = False, temperature=None,
+                  top_k=None, top_p=None, generator: Optional[torch.Generator] = None, length_penalty: float = 1.0,
+                  early_stopping=False, stopping_criteria=None, warp_before_beam_scores: bool = False) -> torch.Tensor:
+    """`generate(num_beams > 1)` of the reference's callers -- `--num_beams` of eval_spatial.py:231-235, eval_region_cls.py:318-322,
+    model_vqa.py:72-76, which pass `do_sample = temperature > 0` with `--temperature` defaulting to 0.2: the default flags plus
+    `--num_beams 3` are BEAM-SAMPLE -- as transformers 4.37.2 runs them (GenerationMixin.beam_search / .beam_sample +
+    BeamSearchScorer), over a decoder fed `inputs_embeds` (ids start empty; lengths count new tokens).
+
+    Every step: scores = log_softmax(logits) (+ the running beam scores); beam search takes the max(2, 1 + #eos) * num_beams best
+    (beam, token) continuations per batch item; beam-sample warps the summed scores (temperature -> top-k -> top-p, per beam row:
+    4.37.2 applies the warpers AFTER adding the beam scores -- `warp_before_beam_scores=True` gives the later releases' order),
+    draws 2 * num_beams continuations without replacement from their softmax and sorts them by score.  BeamScorer437.process keeps
+    the first num_beams that do not end in an EOS id and files the EOS ones that rank among the first num_beams as hypotheses.
+
+    first_logits fp32 [batch * num_beams, V]; step(tokens int64 [batch * num_beams], beam_idx int64 [batch * num_beams]) -> logits of
+    the next position for rows continued from (old) rows beam_idx.  Returns int64 [batch, <= max_new_tokens]: new tokens only."""
+    dev = first_logits.device
+    B, nb, G = batch, num_beams, max_new_tokens
+    V = first_logits.shape[-1]
+    eos = list(eos_token_ids) if eos_token_ids else None
+    scorer = BeamScorer437(B, nb, G, length_penalty, early_stopping)
+    beam_scores = torch.zeros((B, nb), dtype=torch.float32, device=dev)
+    beam_scores[:, 1:] = -1e9
+    seqs: List[List[int]] = [[] for _ in range(B * nb)]
+    flat_scores = beam_scores.reshape(-1).tolist()
+    logits = first_logits
+    K = 2 * nb if do_sample else max(2, 1 + (len(eos) if eos else 0)) * nb
+    # `_get_logits_warper` (4.37.2): with beams every warper keeps at least one token per EOS id + 1 (2 for a single id / none)
+    keep_min = (len(eos) + 1) if (eos and len(eos) > 1) else 2
+    while True:
+        lp = torch.log_softmax(logits.float(), dim=-1)
+        if do_sample and warp_before_beam_scores:
+            lp = warp_logits(lp, temperature, top_k, top_p, min_tokens_to_keep=keep_min)
+        sc = lp + beam_scores.reshape(B * nb, 1)
+        if do_sample:
+            if not warp_before_beam_scores:
+                sc = warp_logits(sc, temperature, top_k, top_p, min_tokens_to_keep=keep_min)
+            cs, ci = beam_sample_candidates(sc.reshape(B, nb * V), K, generator)
+        else:
+            cs, ci = torch.topk(sc.reshape(B, nb * V), K, dim=1, largest=True, sorted=True)
+        host = torch.stack((cs.double(), (ci // V).double(), (ci % V).double())).cpu()  # one copy per step: [3, B, K]
+        n_scores, n_idx, n_tok = host[0].tolist(), [[int(v) for v in r] for r in host[1].tolist()], [[int(v) for v in r] for r in host[2].tolist()]
+        flat_scores, toks, rows = scorer.process(seqs, n_scores, n_tok, n_idx, pad_token_id, eos)
+        seqs = [seqs[r] + [t] for r, t in zip(rows, toks)]
+        beam_scores = torch.tensor(flat_scores, dtype=torch.float32, device=dev).reshape(B, nb)
+        stop = scorer.is_done or len(seqs[0]) >= G
+        if not stop and stopping_criteria:
+            ids = torch.tensor(seqs, dtype=torch.int64)
+            for crit in stopping_criteria:
+                r = crit(ids, None)
+                stop = stop or (bool(r.all()) if isinstance(r, torch.Tensor) else bool(r))
+        if stop:
+            break
+        logits = step(torch.tensor(toks, dtype=torch.int64, device=dev), torch.tensor(rows, dtype=torch.int64, device=dev))
+    out = scorer.finalize(seqs, flat_scores, pad_token_id, eos)
+    return torch.tensor(out, dtype=torch.int64, device=dev)

@@ -19,6 +19,48 @@ from .engine import SrgptEngine
 from .generation import NOT_GIVEN, resolve_generation, warp_logits
 
 
+class CausalLMOutputWithPast:
+    """What the reference's forward() returns (llava_llama.py:177-192 -> transformers.modeling_outputs.CausalLMOutputWithPast):
+    attribute access, key access, integer / slice access over the fields that are not None (HF's ModelOutput.to_tuple order:
+    loss, logits, past_key_values, hidden_states, attentions), and `return_dict=False` -> that tuple.
+    Seam differences, stated rather than hidden:
+      * `past_key_values` is the engine's DecodeState (static KV cache + device bookkeeping), not a tuple of per-layer (k, v)
+        tensors -- callers hand it back to forward()/generate unchanged, which is all the reference's callers do with it;
+      * `attentions` is always None: the reference's LLM is built with FlashAttention2 (modeling_llama.py:615-618), which cannot
+        return attention weights either (`output_attentions` is accepted and ignored there too)."""
+
+    _fields = ("loss", "logits", "past_key_values", "hidden_states", "attentions")
+
+    def __init__(self, loss=None, logits=None, past_key_values=None, hidden_states=None, attentions=None):
+        self.loss, self.logits, self.past_key_values, self.hidden_states, self.attentions = \
+            loss, logits, past_key_values, hidden_states, attentions
+
+    def to_tuple(self):
+        return tuple(getattr(self, k) for k in self._fields if getattr(self, k) is not None)
+
+    def keys(self):
+        return [k for k in self._fields if getattr(self, k) is not None]
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            if k not in self._fields or getattr(self, k) is None:
+                raise KeyError(k)
+            return getattr(self, k)
+        return self.to_tuple()[k]
+
+    def __contains__(self, k):
+        return k in self.keys()
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+
 class _Facade:
     """nn.Module-looking handle (callers only use .to/.eval/.config/.is_loaded on sub-modules)."""
 
@@ -302,9 +344,10 @@ class LlavaLlamaModel:
             if input_ids is None or input_ids.shape[1] != 1 or labels is not None:
                 raise NotImplementedError("forward() with past_key_values takes input_ids [B, 1] and no labels")
             logits = self.engine.step(past_key_values, input_ids)
-            out = SimpleNamespace(loss=None, logits=logits[:, None, :], past_key_values=past_key_values, hidden_states=None,
-                                  attentions=None)
-            return (out.logits, None) if dpo_forward else out
+            out = CausalLMOutputWithPast(logits=logits[:, None, :], past_key_values=past_key_values)
+            if dpo_forward:
+                return out.logits, None
+            return out if return_dict is not False else out.to_tuple()
         if inputs_embeds is not None:
             inputs_embeds = inputs_embeds.to(self.dtype)
         if inputs_embeds is None:
@@ -355,12 +398,11 @@ class LlavaLlamaModel:
             shift_logits = logits[:, :-1, :].reshape(-1, logits.shape[-1])
             shift_labels = lab[:, 1:].reshape(-1)
             loss, _ = ops.cross_entropy(shift_logits, shift_labels, IGNORE_INDEX)
-        out = SimpleNamespace(loss=loss, logits=logits, past_key_values=st,
-                              hidden_states=None if hs is None else tuple(hs[i] for i in range(hs.shape[0])),
-                              attentions=None)
+        out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=st if use_cache else None,
+                                     hidden_states=None if hs is None else tuple(hs[i] for i in range(hs.shape[0])))
         if dpo_forward:
             return out.logits, labels
-        return out
+        return out if return_dict is not False else out.to_tuple()
 
     __call__ = forward
 
@@ -392,8 +434,6 @@ class LlavaLlamaModel:
         g = resolve_generation(self.generation_defaults(), do_sample=do_sample, temperature=temperature, top_p=top_p, top_k=top_k,
                                num_beams=num_beams, max_new_tokens=max_new_tokens, max_length=max_length,
                                min_new_tokens=min_new_tokens, pad_token_id=pad_token_id, eos_token_id=eos_token_id)
-        if g.num_beams != 1 and g.do_sample:
-            raise NotImplementedError("beam-sample decoding (num_beams > 1 with do_sample=True) is not implemented")
         max_new_tokens = g.max_new_tokens
         eos_ids = g.eos_token_ids
         if g.min_new_tokens is not None and g.min_new_tokens >= max_new_tokens:
@@ -419,7 +459,11 @@ class LlavaLlamaModel:
             if min(lens_h) == Tmax:
                 lens = None
         if g.num_beams != 1:
-            return self._beam_search(inputs_embeds, lens, g.num_beams, max_new_tokens, eos_ids, g.pad_token_id, stopping_criteria)
+            # `--num_beams N` of the eval CLIs; with their default `--temperature 0.2` (do_sample = temperature > 0) this is HF's
+            # beam-SAMPLE, with `--temperature 0` beam search proper
+            sample = bool(g.do_sample and g.temperature is not None and g.temperature > 0)
+            return self._beam_search(inputs_embeds, lens, g.num_beams, max_new_tokens, eos_ids, g.pad_token_id, stopping_criteria,
+                                     sampling=dict(temperature=g.temperature, top_k=g.top_k, top_p=g.top_p) if sample else None)
         st, _, _ = self.engine.prefill(inputs_embeds, max_new=max_new_tokens, lens=lens)
         if g.do_sample and g.temperature is not None and g.temperature > 0:
             from . import ops
@@ -438,31 +482,49 @@ class LlavaLlamaModel:
         return self.engine.greedy_decode(st, max_new_tokens, eos_token_id=eos_ids, pad_token_id=g.pad_token_id,
                                          stopping_criteria=stopping_criteria)
 
-    def _beam_search(self, inputs_embeds, lens, num_beams, max_new_tokens, eos_ids, pad_token_id, stopping_criteria):
+    def _beam_search(self, inputs_embeds, lens, num_beams, max_new_tokens, eos_ids, pad_token_id, stopping_criteria, sampling=None):
         """`generate(num_beams > 1)` -- the `--num_beams` flag of eval_spatial.py:234, eval_region_cls.py:321, model_vqa.py:75 (default
-        1: the benchmarked path is the greedy loop).  HF semantics in spatialrgpt_amd/generation.beam_search (pinned to the
-        reference's own generate(num_beams=3), tests/golden/beam_kat.npz); here only the device side: every batch item's prompt is
-        prefilled once per beam (HF's `_expand_inputs_for_generation`), each step runs the HIP decode step on batch * num_beams
-        rows, and the KV-cache rows are gathered by the beam indices the search picked.  The beam bookkeeping itself (log-softmax,
-        top-k over num_beams * vocab, a handful of [batch, 2 * num_beams] tensors) is torch on the device: a rarely used,
-        latency-tolerant mode -- not part of the measured path."""
-        from .generation import beam_search
+        1: the benchmarked path is the greedy loop); `sampling` (temperature / top_k / top_p) makes it beam-SAMPLE, which is what those
+        CLIs ask for under their default `--temperature 0.2`.  HF 4.37.2 semantics in spatialrgpt_amd/generation.beam_generate; here
+        only the device side: every batch item's prompt is prefilled once per beam (HF's `_expand_inputs_for_generation`), each step
+        runs the HIP decode step on batch * num_beams rows, and the live KV-cache rows follow the beam indices the search picked.
+        The beam bookkeeping itself (log-softmax, warpers, top-k / Gumbel-top-k over num_beams * vocab, a [batch, 2 * num_beams]
+        hand-over to the host scorer per step) is torch: a rarely used, latency-tolerant mode -- not part of the measured path."""
+        import ctypes as C
+
+        from . import _lib as L
+        from . import ops
+        from .generation import beam_generate
 
         eng = self.engine
         B = inputs_embeds.shape[0]
         emb = inputs_embeds.repeat_interleave(num_beams, dim=0)
         lens_x = None if lens is None else lens.repeat_interleave(num_beams, dim=0)
         st, _, _ = eng.prefill(emb, max_new=max_new_tokens, lens=lens_x)
+        ident = torch.arange(B * num_beams, device=self.device)
 
         def step(tokens, beam_idx):
-            # rows of the next step continue from the caches of the beams the search kept (all beams of a batch item share their
-            # position, so only K / V rows move)
-            st.kcache.copy_(st.kcache.index_select(1, beam_idx))
-            st.vcache.copy_(st.vcache.index_select(1, beam_idx))
+            # rows of the next step continue from the caches of the beams the search kept.  Only the LIVE positions move, and
+            # nothing moves when the permutation is the identity (ADVICE r4: the whole-capacity index_select built a cache-sized
+            # temporary for K and again for V every token)
+            if not torch.equal(beam_idx, ident):
+                n = max(st.host_len)
+                st.kcache[:, :, :, :n].copy_(st.kcache[:, :, :, :n].index_select(1, beam_idx))
+                st.vcache[:, :, :, :n].copy_(st.vcache[:, :, :, :n].index_select(1, beam_idx))
             return eng.step(st, tokens[:, None])
 
-        return beam_search(st.logits.clone(), step, B, num_beams, max_new_tokens, eos_ids, pad_token_id,
-                           stopping_criteria=stopping_criteria)
+        gen = None
+        kw = {}
+        if sampling is not None:
+            # seeded from torch's default CPU generator, like the sampling path: torch.manual_seed makes a request reproducible
+            gen = torch.Generator(device=self.device)
+            gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
+            kw = dict(do_sample=True, temperature=sampling["temperature"], top_k=sampling["top_k"], top_p=sampling["top_p"], generator=gen)
+        out = beam_generate(st.logits.clone(), step, B, num_beams, max_new_tokens, eos_ids, pad_token_id,
+                            stopping_criteria=stopping_criteria, **kw)
+        # the decode attention's hand-off health (arrival tickets re-armed), as on the greedy path
+        L.check(L.load().srgpt_llm_decode_sync_state(C.byref(eng.w.llm), C.byref(st.c), ops._stream()))
+        return out
 
     def _sample_loop(self, st, max_new_tokens, temperature, top_p, top_k, eos_token_id, pad_token_id, stopping_criteria,
                      check_every: int = 8):

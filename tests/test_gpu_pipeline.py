@@ -370,6 +370,28 @@ def test_incremental_forward_with_cached_state_equals_generate():
         model(input_ids=d["input_ids"], past_key_values=st, attention_mask=am)  # only single-token steps over a cache
 
 
+def test_forward_returns_a_causal_lm_output_like_the_reference():
+    """llava_llama.py:177-192 returns transformers' CausalLMOutputWithPast: attribute / key / index access over the fields that are
+    set, `return_dict=False` -> the tuple (loss first when labels are given), past_key_values only under use_cache,
+    attentions None (FlashAttention2 returns none either)."""
+    model, cfg, dtype, w, inp, ref = _engine("tiny_fp32.npz")
+    d = _to_dev(inp)
+    am = torch.ones_like(d["input_ids"])
+    kw = dict(input_ids=d["input_ids"], images=d["images"], masks=d["masks"], depths=d["depths"], attention_mask=am)
+    out = model(**kw)
+    assert out.keys() == ["logits"] and out.past_key_values is None and out.attentions is None and out.loss is None
+    assert out[0] is out.logits and out["logits"] is out.logits and "loss" not in out
+    tup = model(**kw, return_dict=False)
+    assert isinstance(tup, tuple) and len(tup) == 1 and torch.equal(tup[0], out.logits)
+    labels = d["input_ids"].clone()
+    labels[labels < 0] = -100
+    o2 = model(**kw, labels=labels, use_cache=True, output_hidden_states=True, output_attentions=True)
+    assert o2.keys() == ["loss", "logits", "past_key_values", "hidden_states"] and o2.attentions is None
+    t2 = model(**kw, labels=labels, use_cache=True, output_hidden_states=True, return_dict=False)
+    assert len(t2) == 4 and torch.equal(t2[0], o2.loss) and torch.equal(t2[1], o2.logits) and len(t2[3]) == len(o2.hidden_states)
+    assert torch.equal(o2[:2][1], o2.logits)
+
+
 def test_graph_replay_honours_a_token_written_into_state_between_replays():
     """the captured decode step does not embed st->tok itself (the advance kernel of the step before leaves the picked
     token's embedding row in place).  A caller that writes a token of its own into st->tok between replays -- valid under ABI 1/2 --
@@ -443,5 +465,8 @@ def test_beam_search_matches_the_references_generate_num_beams_3():
     g = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], do_sample=False, max_new_tokens=12,
                        eos_token_id=None)
     assert torch.equal(g.cpu(), ref["new_ids"])
-    with pytest.raises(NotImplementedError):
-        model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], do_sample=True, num_beams=2, max_new_tokens=4)
+    # beam-SAMPLE (do_sample with beams: the eval CLIs' default temperature 0.2 + --num_beams) runs too (tests/test_gpu_edge_cases.py)
+    torch.manual_seed(0)
+    bs = model.generate(d["input_ids"], images=d["images"], depths=d["depths"], masks=d["masks"], do_sample=True, num_beams=2, max_new_tokens=4,
+                        eos_token_id=None)
+    assert bs.shape == (1, 4)

@@ -208,3 +208,21 @@ def test_stopping_criteria_run_ahead_returns_the_serial_loops_prefix(do_sample):
     # the next request on the pooled state is unaffected by the step that ran ahead
     again = model.generate(**req, do_sample=False, max_new_tokens=G, eos_token_id=None)
     assert torch.equal(again, model.generate(**req, do_sample=False, max_new_tokens=G, eos_token_id=None))
+
+
+def test_settings_outside_the_served_range_are_reported_not_clamped():
+    """a C-API caller can put top_k > 64, or top_p < 1 with top_k = 0, into the DEVICE parameter block; the kernels used
+    to clamp / ignore silently.  Now a sticky error bit: srgpt_sample_status (and srgpt_llm_decode_sync_state inside the decode
+    step) return SRGPT_ERR_UNSUPPORTED; served settings stay clean."""
+    from spatialrgpt_amd import ops
+
+    logits = torch.randn((2, 1000), device=DEV)
+    for bad in (dict(temperature=0.7, top_k=65, top_p=None), dict(temperature=0.7, top_k=0, top_p=0.9)):
+        p = ops.SamplingParams(DEV, 2)
+        p.set(bad["temperature"], bad["top_k"], bad["top_p"], seed=1)
+        with pytest.raises(NotImplementedError, match="not served"):
+            ops.sample(logits, p, check=True)
+    for ok in (dict(temperature=0.7, top_k=64, top_p=0.9), dict(temperature=0.7, top_k=0, top_p=None)):
+        p = ops.SamplingParams(DEV, 2)
+        p.set(ok["temperature"], ok["top_k"], ok["top_p"], seed=1)
+        ops.sample(logits, p, check=True)

@@ -135,3 +135,60 @@ def make_peaked(sd, cfg, seed=7, embed_std=0.5, resid_gain=1.0):
     head[perm[3:hi].to(dev)] = unit
     sd["llm.lm_head.weight"] = head.to(dt)
     return perm
+
+
+def make_heavy_tailed(w, cfg, seed=13, gains=(0.1, 50.0), n_massive=6, massive=300.0, hot_rows=3, hot_row_gain=30.0, attn_gain=4.0):
+    """OUTLIER-STATISTICS variant of a synthetic weight dict (oracle key names), in place -- VERDICT r4 missing #3.  Trained SigLIP /
+    Llama checkpoints (llava/model/builder.py:141-159; a8cheng/SpatialRGPT-VILA1.5-8B) are not N(0, 0.02): norm gains spread over
+    orders of magnitude, a handful of "massive activation" channels of the residual stream carry values hundreds of times the rest,
+    some weight rows are far larger than their neighbours, attention logits reach tens.  None can be downloaded here; this plants the
+    same statistics into the seeded random weights:
+      * every LayerNorm / RMSNorm / LayerNorm2d gain: log-uniform in [gains] per channel;
+      * n_massive channels of embed_tokens and of the ViT position embedding multiplied by `massive`;
+      * hot_rows random rows of every projection matrix (LLM q/k/v/o/gate/up/down, ViT q/k/v/out/fc1/fc2) multiplied by hot_row_gain;
+      * the q and k rows of the first head (LLM and ViT) multiplied by attn_gain (logits x attn_gain^2).
+    Returns a dict describing what was planted (for the report)."""
+    g = torch.Generator().manual_seed(seed)
+    lo, hi = math.log(gains[0]), math.log(gains[1])
+    planted = {"gains": [], "massive_llm": None, "massive_vit": None, "hot_rows": 0}
+    norm_tails = ("layernorm.weight", "layer_norm1.weight", "layer_norm2.weight", "model.norm.weight", "post_layernorm.weight",
+                  "feature_refinement_module.1.weight", "mm_projector.layers.1.weight")
+    proj_tails = ("q_proj.weight", "k_proj.weight", "v_proj.weight", "o_proj.weight", "out_proj.weight", "gate_proj.weight",
+                  "up_proj.weight", "down_proj.weight", "fc1.weight", "fc2.weight")
+    for k in list(w):
+        t = w[k]
+        if k.endswith(norm_tails):
+            w[k] = torch.exp(torch.rand(t.shape, generator=g) * (hi - lo) + lo).to(t.dtype)
+            planted["gains"].append(k)
+        elif k.endswith(proj_tails):
+            rows = torch.randperm(t.shape[0], generator=g)[:hot_rows]
+            tt = t.clone()
+            tt[rows] = (tt[rows].float() * hot_row_gain).to(t.dtype)
+            w[k] = tt
+            planted["hot_rows"] += hot_rows
+    e = w["llm.model.embed_tokens.weight"]
+    dims = torch.randperm(e.shape[1], generator=g)[:n_massive]
+    e = e.clone()
+    e[:, dims] = (e[:, dims].float() * massive).to(e.dtype)
+    w["llm.model.embed_tokens.weight"] = e
+    planted["massive_llm"] = dims.tolist()
+    pk = "vision_tower.vision_tower.vision_model.embeddings.position_embedding.weight"
+    pe = w[pk].clone()
+    vd = torch.randperm(pe.shape[1], generator=g)[:max(4, n_massive - 2)]
+    pe[:, vd] = (pe[:, vd].float() * massive).to(pe.dtype)
+    w[pk] = pe
+    planted["massive_vit"] = vd.tolist()
+    hd = cfg.hidden // cfg.heads
+    for i in range(cfg.layers):
+        for n in ("q_proj", "k_proj"):
+            k = f"llm.model.layers.{i}.self_attn.{n}.weight"
+            t = w[k].clone()
+            t[:hd] = (t[:hd].float() * attn_gain).to(t.dtype)
+            w[k] = t
+    vhd = cfg.vit_hidden // cfg.vit_heads
+    for k in list(w):
+        if "vision_model.encoder.layers" in k and (k.endswith("self_attn.q_proj.weight") or k.endswith("self_attn.k_proj.weight")):
+            t = w[k].clone()
+            t[:vhd] = (t[:vhd].float() * attn_gain).to(t.dtype)
+            w[k] = t
+    return planted
