@@ -3,12 +3,12 @@ import json
 import re
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05_final"
 g, p = "gpurun_out/" + tag, "profiles/" + tag
 d = json.loads(open(g + "_bench_default.json").read().strip().splitlines()[-1])
 open(p + "_bench.json", "w").write(json.dumps(d, indent=1) + "\n")
 ks = open(g + "_kernel_stats.txt").read()
-m = re.search(r"^\s*\d+\s+[\d.]+\s+([\d.]+)\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+gemv_kernel<.*?, true, 2>", ks, re.M)
+m = re.search(r"^\s*\d+\s+[\d.]+\s+([\d.]+)\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+gemv_kernel<.*?, true, 2(?:, \d+)?>", ks, re.M)
 trace_us = float(m.group(1)) if m else float("nan")
 r = d["roofline"]
 hdr = f"""# {tag}: rocprofv3 --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline   (scripts/profile_round.sh)
@@ -44,7 +44,7 @@ for l in open(g + "_pmc_fetch.txt").read().splitlines():
         continue
     nd, fs, name = int(mm.group(1)), float(mm.group(2)), mm.group(3)
     out.append(f"{nd:10d} {fs:22.1f} {2 * fs / 1024 / nd:24.2f}  {name[:100]}")
-    if "gemv_kernel" in name and ", true, 2>" in name:
+    if "gemv_kernel" in name and re.search(r", true, 2(, \d+)?>", name):
         gu = fs / nd
 if gu:
     out.append(f"# gate/up GEMV (gemv_kernel<..., true, 2>): {2 * gu / 1024:.1f} MiB per dispatch vs 224.0 MiB of weights (2*14336*4096*2 B): ratio {2 * gu * 1024 / (2 * 14336 * 4096 * 2):.4f} -> every weight byte read once.")

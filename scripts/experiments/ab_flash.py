@@ -1,5 +1,5 @@
 """Timing shapes of the MFMA flash attention kernel (flash.hip): prints a checksum of every output and runs each shape 30 times
-for `rocprofv3 --kernel-trace` (scripts/ab_flash.sh).  The round-3 / round-4 A/B in profiles/r04_flash_attention.txt was taken with
+for `rocprofv3 --kernel-trace` (scripts/experiments/ab_flash.sh).  The round-3 / round-4 A/B in profiles/r04_flash_attention.txt was taken with
 this script while both kernels were in the tuning build (knob SRGPT_FLASH_V2, gone with the round-3 kernel)."""
 import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

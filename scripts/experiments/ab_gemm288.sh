@@ -6,5 +6,5 @@ export SRGPT_LIB=$PWD/spatialrgpt_amd/libsrgpt_hip_tuning.so
 SH=${AB_SHAPES:-"qkv:259:6144:4096 o:259:4096:4096 gate/up:259:28672:4096 down:259:4096:14336"}
 for mode in ${AB_MODES:-0 2}; do
   echo "## SRGPT_GEMM_288=$mode"
-  SRGPT_GEMM_288=$mode python scripts/ubench_gemm.py $SH 2>&1 | grep -v -i "transformers\|amdgpu.ids"
+  SRGPT_GEMM_288=$mode python scripts/experiments/ubench_gemm.py $SH 2>&1 | grep -v -i "transformers\|amdgpu.ids"
 done

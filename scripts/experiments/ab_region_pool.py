@@ -1,6 +1,6 @@
 """A/B of the pooling launch: SRGPT_REGION_MFMA = 0 (VALU kernel) / 1, 2, 4 (MFMA kernel, that many chunks per wave) / 3 (by map size) -- tuning build.
 Run under `rocprofv3 --kernel-trace` for the per-kernel durations; prints max |diff| against a torch fp32 restatement.
-    SRGPT_REGION_MFMA=3 python scripts/ab_region_pool.py"""
+    SRGPT_REGION_MFMA=3 python scripts/experiments/ab_region_pool.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

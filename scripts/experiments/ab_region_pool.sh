@@ -8,7 +8,7 @@ cd /tmp
 for shape in ${AB_SHAPES:-0 1 2 3 4}; do
 for mode in ${AB_MODES:-0 1 2 4}; do
   rm -rf /tmp/prof_ab
-  AB_SHAPE=$shape SRGPT_REGION_MFMA=$mode rocprofv3 --kernel-trace -d /tmp/prof_ab -o run -- python $GRAFT_REPO_ROOT/scripts/ab_region_pool.py > /tmp/ab_$mode.log 2>&1
+  AB_SHAPE=$shape SRGPT_REGION_MFMA=$mode rocprofv3 --kernel-trace -d /tmp/prof_ab -o run -- python $GRAFT_REPO_ROOT/scripts/experiments/ab_region_pool.py > /tmp/ab_$mode.log 2>&1
   echo "=== SRGPT_REGION_MFMA=$mode" >> $OUT/r04d_region_ab.txt
   grep "^mode" /tmp/ab_$mode.log >> $OUT/r04d_region_ab.txt
   python $GRAFT_REPO_ROOT/scripts/prof_summary.py $(find /tmp/prof_ab -name "*.db" | head -1) 12 | grep -i -E "region_pool" >> $OUT/r04d_region_ab.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Where the waves of the batched decode product (skinny.hip) spend their cycles: SQ wave-cycle shares per kernel, own PMC passes
-# (counters never share a run with trace domains).   gpurun -- 'bash scripts/pmc_skinny_stalls.sh'  -> gpurun_out/r03_pmc_skinny_stalls.txt
+# (counters never share a run with trace domains).   gpurun -- 'bash scripts/experiments/pmc_skinny_stalls.sh'  -> gpurun_out/r03_pmc_skinny_stalls.txt
 OUT=$PWD/gpurun_out/r03_pmc_skinny_stalls.txt; : > $OUT
 export TMPDIR=/tmp; cd /tmp
 for cfgname in "fp8_b8:--weights fp8 --batch 8" "bf16_b4:--batch 4"; do

@@ -2,7 +2,7 @@
 greedy (the benchmarked loop), the demo's sampling settings (demo/gradio_web_server_multi.py:202-213: temperature 0.2, top_k 50 by the
 transformers 4.37.2 default), sampling + top-p, Gumbel-max (no top-k), each with and without a stopping criterion (host Python after
 every token, judged one step behind the device: engine._decode_loop_run_ahead), and the torch-op path a setting outside the device
-sampler takes.   python scripts/time_sampling.py > gpurun_out/sampling.txt   -> profiles/r04_sampling.txt"""
+sampler takes.   python scripts/experiments/time_sampling.py > gpurun_out/sampling.txt   -> profiles/r04_sampling.txt"""
 import os
 import sys
 import time

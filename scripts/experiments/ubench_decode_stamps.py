@@ -1,5 +1,5 @@
 """phase stamps (s_memtime, shader cycles) inside the decode attention kernel after a short decode run -- tuning build only.
-   python scripts/ubench_decode_stamps.py [batch]"""
+   python scripts/experiments/ubench_decode_stamps.py [batch]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

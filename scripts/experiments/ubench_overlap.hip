@@ -2,7 +2,7 @@
 // ramp / drain when they are launched on two alternating streams and ordered by an in-kernel arrival counter instead of a
 // kernel boundary?  Consumer blocks request their first weight batch, THEN wait for the producer's counter, then read the
 // activation vector with agent-scope loads.  Spins are bounded (an error word is set, nothing hangs).
-//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/ubench_overlap.hip -o scripts/ubench_overlap
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/experiments/ubench_overlap.hip -o scripts/ubench_overlap
 //   run:   scripts/ubench_overlap            -> us per "layer" (qkv 6144x4096, o 4096x4096, gate/up 28672x4096, down 4096x14336)
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -1,5 +1,5 @@
 """phase stamps (s_memtime) inside region_pool_kernel at the headline shape (108 x 108 x 1152 bf16, 8 masks) and at the depth shape
-(27 x 27) -- tuning build only.   python scripts/ubench_region_stamps.py"""
+(27 x 27) -- tuning build only.   python scripts/experiments/ubench_region_stamps.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

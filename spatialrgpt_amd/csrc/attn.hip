@@ -78,7 +78,7 @@ constexpr int DEC_CHUNK_MAX = 256;
 constexpr int DEC_SPLIT_MAX = 64;
 
 #ifdef SRGPT_TUNING_KNOBS
-// phase stamps of the decode attention kernel (tuning build only; scripts/ubench_decode_stamps.py): block 0 -> slots 0..15, the
+// phase stamps of the decode attention kernel (tuning build only; scripts/experiments/ubench_decode_stamps.py): block 0 -> slots 0..15, the
 // block that merges (kv head 0, sequence 0) -> slots 16..31
 __device__ unsigned long long srgpt_dbg_stamps[32];
 #define DEC_STAMP(i) do { if (stamp_base >= 0 && threadIdx.x == 0) srgpt_dbg_stamps[stamp_base + (i)] = __builtin_amdgcn_s_memtime(); } while (0)

@@ -31,7 +31,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 #ifdef SRGPT_TUNING_KNOBS
-// phase stamps of block (0, 0, 0), wave 0, key tile 5 (scripts/ubench_flash_stamps.py)
+// phase stamps of block (0, 0, 0), wave 0, key tile 5 (scripts/experiments/ubench_flash_stamps.py)
 __device__ unsigned long long srgpt_flash_stamps[16];
 #define FL_STAMP(i) do { if (stamp_on && t == 5 && threadIdx.x == 0) srgpt_flash_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else

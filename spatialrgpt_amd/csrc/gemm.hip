@@ -813,7 +813,7 @@ static int gemm_impl(const void* A, const void* W, const void* bias, const void*
       if (splits < 1) splits = 1;
     }
   }
-  {  // tuning knobs (scripts/ubench_gemm.py sweeps them); unset in production
+  {  // tuning knobs (scripts/experiments/ubench_gemm.py sweeps them); unset in production
     const int f_bm = SRGPT_KNOB("SRGPT_GEMM_FORCE_BM", 0);
     const int f_sp = SRGPT_KNOB("SRGPT_GEMM_FORCE_SPLITS", 0);
     if (f_bm == 64 || f_bm == 128 || f_bm == 96) bm = f_bm;

@@ -7,7 +7,7 @@
 // Work decomposition: a unit = one output row (plain) or one (gate row, up row) pair (SwiGLU); each wave owns
 // units grid-strided; per unit the K range is walked in batches of 8 row chunks: 8 independent 1-KiB loads are
 // issued back to back, then consumed in order with counted waits.  No cross-batch software pipeline: measured
-// (scripts/ubench_stream.hip, ubench_gemv_ts.hip) a 3-deep register pipeline with 16+ loads in flight per wave
+// (scripts/experiments/ubench_stream.hip, ubench_gemv_ts.hip) a 3-deep register pipeline with 16+ loads in flight per wave
 // was 2-3 us SLOWER per launch -- 8 waves/CU x 8 KiB already saturate HBM, and the independent waves of a CU
 // drift apart so that some stream while others multiply.  Grid = 2 blocks per CU.
 //
@@ -19,7 +19,7 @@
 
 #include "common.h"
 
-// Optional per-wave timestamping (scripts/ubench_gemv_ts.hip builds this file with -DSRGPT_GEMV_TS)
+// Optional per-wave timestamping (scripts/experiments/ubench_gemv_ts.hip builds this file with -DSRGPT_GEMV_TS)
 #ifdef SRGPT_GEMV_TS
 __device__ long long srgpt_gemv_ts[8 * 8192];
 extern "C" void* srgpt_gemv_ts_ptr() {
@@ -456,6 +456,9 @@ int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, con
   SRGPT_CHECK(lds <= 150 * 1024, SRGPT_ERR_UNSUPPORTED, "srgpt_gemv: batch*K too large for LDS (%zu bytes)", lds);
   const int cus = srgpt_device_cus();
   const int env_per_cu = SRGPT_KNOB("SRGPT_GEMV_BLOCKS_PER_CU", 0);  // tuning knob
+  // (round 5, measured and not kept: 3 / 4 / 5 blocks per CU for the short launches -- q/k/v, o_proj, where a wave owns only 2 - 3 rows,
+  // i.e. 2 - 3 dependent memory round trips: 2.970 -> 2.998 / 3.009 / 3.017 ms per token; for all launches 3.037 / 3.049:
+  // profiles/r05_decode_step_ab.txt)
   const int per_cu = lds > 70 * 1024 ? 1 : (env_per_cu > 0 ? env_per_cu : 2);
   int grid = (N + 3) / 4;
   if (grid > cus * per_cu) grid = cus * per_cu;
@@ -464,7 +467,7 @@ int launch_gemv(const void* x, const void* W, const void* norm_w, float eps, con
   const int use_reg = SRGPT_KNOB("SRGPT_GEMV_REG", 1);  // A/B knob
   if (B == 1 && sizeof(T) == 2 && use_reg) {
     const int nit = (K / 8 + 63) / 64;
-    // measured (scripts/ubench_gemv_c.hip): without the fused RMSNorm the register variant saves 0.6-0.8 us per launch
+    // measured (scripts/experiments/ubench_gemv_c.hip): without the fused RMSNorm the register variant saves 0.6-0.8 us per launch
     // (o_proj 8.5 -> 7.9 us); with it every wave normalises the whole row redundantly and loses ~1 us -> LDS kernel
     bool ok = false;
     if (!norm_w)

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(RP_POS) void region_resample_kernel(const MT* __res
 }
 
 #ifdef SRGPT_TUNING_KNOBS
-// phase stamps (tuning build; scripts/ubench_region_stamps.py): block (0, 0) -> slots 0..15, the last arriver of channel slab 0 -> 16..
+// phase stamps (tuning build; scripts/experiments/ubench_region_stamps.py): block (0, 0) -> slots 0..15, the last arriver of channel slab 0 -> 16..
 __device__ unsigned long long srgpt_region_stamps[32];
 #define RP_STAMP(i) do { if (stamp_base >= 0 && threadIdx.x == 0) srgpt_region_stamps[stamp_base + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -591,7 +591,7 @@ static int region_pool_impl(const void* feat, const void* masks, void* out, floa
     else if (mask_dtype == SRGPT_BF16) RW(bf16_t, bf16_t, false);
     else RW(bf16_t, float, false);
     int ch = region_mfma_chunks((size_t)L);
-#ifdef SRGPT_TUNING_KNOBS  // A/B (scripts/ab_region_pool.sh): 0 = the VALU kernel on bf16 features, 1 / 2 / 4 = that many chunks per wave
+#ifdef SRGPT_TUNING_KNOBS  // A/B (scripts/experiments/ab_region_pool.sh): 0 = the VALU kernel on bf16 features, 1 / 2 / 4 = that many chunks per wave
     const int mode = SRGPT_KNOB("SRGPT_REGION_MFMA", 3);
     if ((mode == 1 || mode == 2 || mode == 4) && cdiv(L, 128 * mode) <= lay.nslab_cap) ch = mode;  // if the partials fit
     if (mode == 0) {

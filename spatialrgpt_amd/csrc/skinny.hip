@@ -6,7 +6,7 @@
 //
 // Roofline: weight bytes read exactly once (non-temporal, each wave-instruction = 2 rows x 512 contiguous bytes).
 // MFMA operand fragments need lane (r = l & 15, g = l >> 4) to hold 16 bytes of ROW r -- loading them straight from
-// HBM puts 16 different rows in one instruction (64-byte pieces; measured slow, scripts/ubench_stream.hip), so each
+// HBM puts 16 different rows in one instruction (64-byte pieces; measured slow, scripts/experiments/ubench_stream.hip), so each
 // wave stages its 16 x 256 weight tile through a PRIVATE 8 KiB LDS region: 8 coalesced global loads -> 8 ds_write_b128
 // -> 8 conflict-free ds_read_b128 fragments (row stride padded to 544 B).  The matching [rows][256] slice of the
 // (normalised) activations goes through a second private region the same way (it comes from L2).  Nothing in the K loop

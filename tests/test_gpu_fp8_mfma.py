@@ -92,7 +92,7 @@ def test_quant_rows_fused_rejects_rows_wider_than_its_register_tile():
 def test_gemm_w8a8_equals_gemm_of_dequantised_operands(M, N, K):
     """Against the fp64 GEMM of the dequantised operands.  Every product is exact and the sum is kept in fp32, so the result
     before the epilogue differs from the reference only by the order of the fp32 additions and the adder's alignment window (bounded here by 2e-4 of
-    sum_k |a_k w_k|; scripts/probe_f8_mfma_accumulation.py looks at the adder itself); the epilogue then rounds to bf16 at
+    sum_k |a_k w_k|; scripts/experiments/probe_f8_mfma_accumulation.py looks at the adder itself); the epilogue then rounds to bf16 at
     srgpt_gemm's points (the Linear's output; the residual sum), also when the store is fp32.  Checked: every element within
     half a bf16 ulp + the accumulation bound of the reference, and (printed, bounded) the share of elements that ARE the
     correctly rounded reference -- a swapped fragment, a wrong row or a wrong scale is O(1) on both.  Ragged M / N tiles, the
