@@ -1,7 +1,7 @@
 #!/bin/bash
 # Last GPU call of a round: whole suite + smoke + default bench (gpu_suite.sh), then the kernel trace of the same build
 # (kernel table + request prefix) -- the PMC passes of profile_round.sh are not repeated.   gpurun -- 'bash scripts/final_check.sh r04'
-R=${1:-r04}; OUT=$PWD/gpurun_out; mkdir -p $OUT
+R=${1:-r05}; OUT=$PWD/gpurun_out; mkdir -p $OUT
 bash scripts/gpu_suite.sh ${R}_suite
 export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/prof_kt
 CMD="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline"

@@ -2,7 +2,7 @@
 # Round profile: kernel trace of the bench command + two separate PMC passes (counters never share a run with trace domains).
 # Usage (on the GPU box, from the repo root): bash scripts/profile_round.sh <tag>   -> gpurun_out/<tag>_*.txt
 set -u
-TAG=${1:-r04_final}
+TAG=${1:-r05_final}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp

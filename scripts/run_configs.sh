@@ -1,7 +1,7 @@
 #!/bin/bash
 # One bench line per BASELINE.json config that fits one GPU (the 8-GPU configs are run at their per-GPU share).
 # Usage: bash scripts/run_configs.sh [tag]  -> gpurun_out/<tag>_configs.jsonl (+ a table on stdout -> profiles/<tag>_configs.txt)
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$PWD/gpurun_out/${TAG}_configs.jsonl
 : > $OUT
 run() { echo "# $1" >> $OUT; shift; timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" 2>/dev/null | tail -1 >> $OUT; }
