@@ -2,10 +2,10 @@
 for `rocprofv3 --kernel-trace` (scripts/experiments/ab_flash.sh).  The round-3 / round-4 A/B in profiles/r04_flash_attention.txt was taken with
 this script while both kernels were in the tuning build (knob SRGPT_FLASH_V2, gone with the round-3 kernel)."""
 import hashlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from spatialrgpt_amd import _lib
-_lib.LIB_PATH = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "spatialrgpt_amd", "libsrgpt_hip_tuning.so"))
+_lib.LIB_PATH = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", "spatialrgpt_amd", "libsrgpt_hip_tuning.so"))
 from spatialrgpt_amd import ops
 torch.manual_seed(0)
 # (B, Tq, Tk, Hq, Hkv, D, causal): SigLIP so400m (2 passes as one batch), 8 requests' worth, CLIP-L/336, Llama-3 prefill, long prefill

@@ -2,10 +2,10 @@
 Run under `rocprofv3 --kernel-trace` for the per-kernel durations; prints max |diff| against a torch fp32 restatement.
     SRGPT_REGION_MFMA=3 python scripts/experiments/ab_region_pool.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from spatialrgpt_amd import _lib
-_lib.LIB_PATH = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "spatialrgpt_amd", "libsrgpt_hip_tuning.so"))
+_lib.LIB_PATH = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", "spatialrgpt_amd", "libsrgpt_hip_tuning.so"))
 from spatialrgpt_amd import ops
 torch.manual_seed(0)
 SHAPES = ((108, 8), (108, 16), (27, 8), (54, 3), (64, 5))

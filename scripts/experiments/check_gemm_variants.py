@@ -2,7 +2,7 @@
 the product library on the same inputs: the variants only change tiling / pipelining, so un-split results must be BIT-identical
 and split-K results equal up to the fp32 slab order (reported as max |diff| in bf16 ulps of the largest output)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ctypes as C
 import torch
 from spatialrgpt_amd import _lib, ops

@@ -5,7 +5,7 @@ both probes are built to have bf16-exact answers).
     The exact answer is 126 s (6 significant bits).  If the adder aligned the products to the largest one and dropped what falls
     below its window, the small terms would vanish for large d; an fp32 accumulation of exact products keeps them for d <= 23 - 7."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from spatialrgpt_amd import ops
 

@@ -1,7 +1,7 @@
 """flash attention (srgpt_attention) at the ViT and prefill shapes, us per call (graph-free, events around 20 back-to-back calls).
   SRGPT_LIB=<libsrgpt_hip*.so> python scripts/experiments/ubench_attention.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from spatialrgpt_amd import _lib
 if os.environ.get("SRGPT_LIB"):

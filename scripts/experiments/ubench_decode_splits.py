@@ -1,6 +1,6 @@
 """decode step time vs the decode-attention split count (tuning build: SRGPT_DECODE_MIN_SPLITS)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from spatialrgpt_amd import _lib
 _lib.LIB_PATH = _lib.LIB_PATH.replace("libsrgpt_hip.so", "libsrgpt_hip_tuning.so")

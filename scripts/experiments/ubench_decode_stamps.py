@@ -1,7 +1,7 @@
 """phase stamps (s_memtime, shader cycles) inside the decode attention kernel after a short decode run -- tuning build only.
    python scripts/experiments/ubench_decode_stamps.py [batch]"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from spatialrgpt_amd import _lib
 _lib.LIB_PATH = os.path.abspath("spatialrgpt_amd/libsrgpt_hip_tuning.so")

@@ -1,6 +1,6 @@
 """GEMM microbenchmark at the prefill / ViT / extractor shapes (graph-captured, distinct weights per launch)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from spatialrgpt_amd import _lib
 if os.environ.get("SRGPT_LIB"):
@@ -26,6 +26,9 @@ for name, M, N, K in shapes:
             ops.gemm(a, W, out=out)
 
     run(); torch.cuda.synchronize()
+    if os.environ.get("UBENCH_CHECK"):  # output of the last launch against fp32 torch (relative to the output's max)
+        ref = a.float() @ Ws[-1].float().T
+        print(f"   check: max err / max = {float((out.float() - ref).abs().max() / ref.abs().max()):.2e}", flush=True)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=side):
         run()

@@ -1,7 +1,7 @@
 """GEMM at the shapes that fill the chip (batched ViT / batched prefill / large squares).  `--tuning` loads the A/B build
 (libsrgpt_hip_tuning.so, `make -C spatialrgpt_amd/csrc TUNING=1`) so that SRGPT_GEMM_FORCE_256=-1 / 1 selects the kernel."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from spatialrgpt_amd import _lib
 if "--tuning" in sys.argv:

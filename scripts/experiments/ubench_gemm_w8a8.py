@@ -2,7 +2,7 @@
 quantisation pass at the LLM prefill shapes of BASELINE configs[4] (8 requests: M = 2072) and of one request (M = 259), plus a
 square shape.  Graph-captured, distinct weights per launch."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from spatialrgpt_amd import _lib
 if os.environ.get("SRGPT_LIB"):  # a variant build

@@ -1,7 +1,7 @@
 """Microbenchmark of the decode GEMV at the VILA1.5-8B shapes inside a captured graph (per-kernel us, TB/s).
 Each measurement replays a graph of 32 launches over 32 distinct weight matrices (cold in the 256 MB L3)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from spatialrgpt_amd import ops
 

@@ -1,7 +1,7 @@
 """phase stamps (s_memtime) inside region_pool_kernel at the headline shape (108 x 108 x 1152 bf16, 8 masks) and at the depth shape
 (27 x 27) -- tuning build only.   python scripts/experiments/ubench_region_stamps.py"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from spatialrgpt_amd import _lib
 _lib.LIB_PATH = os.path.abspath("spatialrgpt_amd/libsrgpt_hip_tuning.so")

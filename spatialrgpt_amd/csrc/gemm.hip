@@ -707,12 +707,14 @@ static int gemm_impl(const void* A, const void* W, const void* bias, const void*
     const int mode = SRGPT_KNOB("SRGPT_GEMM_288", 1);  // tuning build: 0 = never, 2 = for any M <= 272, > 2 = forced split count
     // measured at M = 259 (profiles/r04_gemm288.txt): gate/up 106.5 -> 84.2 us, down 64.8 -> 50.6, q/k/v 33.8 -> 32.0; o (27.5 vs
     // 27.9: 8 K tiles per block once K is split for 256 CUs, three of them pipeline fill) stays on the small tiles
+    const int anym = SRGPT_KNOB("SRGPT_GEMM_288_ANYM", 0);  // tuning build (round 5 probe): several 272-row tiles (grid.z) for M > 272
     bool use288 = mode != 0 && K % 64 == 0 && nk >= 4 &&
-                  ((M > 224 && M <= 272 && (int64_t)N * K >= (int64_t)24 << 20) || (mode >= 2 && M <= 272));
+                  ((M > 224 && M <= 272 && (int64_t)N * K >= (int64_t)24 << 20) || (mode >= 2 && (M <= 272 || anym)));
     int sp = 1;
     if (use288) {
-      if (gx < cus * 3 / 4 && ws) {
-        sp = (cus + gx / 2) / gx;
+      const int gz = cdiv(M, 272);
+      if (gx * gz < cus * 3 / 4 && ws) {
+        sp = (cus + gx * gz / 2) / (gx * gz);
         if (sp > nk / 8) sp = nk / 8;  // keep >= 8 K tiles per split: three of them are pipeline fill
         if (sp > 8) sp = 8;
         while (sp > 1 && (int64_t)sp * M * N * 4 > ws_bytes) --sp;
@@ -723,7 +725,7 @@ static int gemm_impl(const void* A, const void* W, const void* bias, const void*
         if (sp > nk) sp = nk;
         while (sp > 1 && (int64_t)sp * M * N * 4 > ws_bytes) --sp;
       }
-      if ((long)gx * sp < cus / 2) use288 = mode >= 2;  // too few blocks to fill the chip: the small tiles overlap better
+      if ((long)gx * gz * sp < cus / 2) use288 = mode >= 2;  // too few blocks to fill the chip: the small tiles overlap better
     }
     if (use288) {
       if (sp > 1) {
