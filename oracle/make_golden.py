@@ -21,6 +21,7 @@ import json
 import os
 import sys
 import tempfile
+import warnings
 
 import numpy as np
 import torch
@@ -370,6 +371,188 @@ def mint_labels_kat():
     print("  wrote labels_kat.npz")
 
 
+def mint_splice_kat():
+    """The token-stream splice's edge cases, pinned to the reference's OWN `prepare_inputs_labels_for_multimodal`
+    (llava_arch.py:333-650) as an exact ROW-SOURCE MAP: forward hooks replace what the projector / region extractor return and
+    the embedding table by index-coded rows (value = 1 + row number, per source kind), so every row of the reference's
+    `inputs_embeds` names the row it was copied from -- integer work, compared exactly.  Cases: several `-200` per prompt
+    (:503-539), `num_images == 0` rows (:456-463), `masks[i] is None` with `<mask>` ids present (:476-477), more embeddings than
+    `<mask>` ids (:480-485), fewer (the boolean-index shape error), `depths=None` (:406-407), left padding (:575-600), truncation
+    (:541-547), an attention mask with interior holes (:439-446), list / 5-D `images` (:387-396), labels (:430-431, :513-533)."""
+    print("== splice_kat.npz")
+    with tempfile.TemporaryDirectory() as td:
+        model, tok = rh.build_tiny_reference_model(td, llm=TINY_LLM, vit=TINY_VIT, dtype="torch.float32", seed=0)
+    cfg = cfg_from(model, tok)
+    MASK, DEPTH, IMG = cfg.mask_token_id, cfg.depth_token_id, so.IMAGE_TOKEN_INDEX
+    V = model.llm.model.embed_tokens.weight.shape[0]
+    H = cfg.hidden
+    NF = 196
+    S = cfg.image_size
+    KIND_TEXT, KIND_IMAGE, KIND_MASK, KIND_DEPTH = 0, 1, 2, 3
+
+    def coded(n):  # [n, H] rows whose every element is 1 + row number (exact in fp32)
+        return (torch.arange(n, dtype=torch.float32) + 1.0)[:, None].expand(n, H).contiguous()
+
+    with torch.no_grad():
+        model.llm.model.embed_tokens.weight.copy_(coded(V))
+    state = {}
+    hooks = [
+        model.get_mm_projector().register_forward_hook(
+            lambda m, i, o: (coded(o.shape[0] * o.shape[1]) + 1e5 * KIND_IMAGE).reshape(o.shape)),
+    ]
+
+    def rex_hook(m, i, o):
+        me, de = o
+        off, me2, de2 = 0, [], (None if de is None else [])
+        for k, e in enumerate(me):
+            n = 0 if e is None else e.shape[0]
+            me2.append(None if e is None else coded(off + n)[off:] + 1e5 * KIND_MASK)
+            if de is not None:
+                de2.append(None if de[k] is None else coded(off + n)[off:] + 1e5 * KIND_DEPTH)
+            off += n
+        return me2, de2
+
+    hooks.append(model.get_region_extractor().register_forward_hook(rex_hook))
+    g = torch.Generator().manual_seed(7)
+
+    def text(n):
+        return torch.randint(3, min(MASK, DEPTH, V - 8), (n,), generator=g).tolist()
+
+    def img(n):
+        return (torch.randn((n, 3, S, S), generator=g).clamp_(-1, 1) * 32).round().div(32)
+
+    def boxes(k):
+        m = torch.zeros((k, S, S))
+        for r in range(k):
+            m[r, 10 * r:10 * r + 60, 20:120] = 1.0
+        return m
+
+    def pad(rows, fill=0):
+        P = max(len(r) for r in rows)
+        ids = torch.full((len(rows), P), fill, dtype=torch.long)
+        am = torch.zeros((len(rows), P), dtype=torch.long)
+        for b, r in enumerate(rows):
+            ids[b, :len(r)] = torch.tensor(r)
+            am[b, :len(r)] = 1
+        return ids, am
+
+    R = lambda k: sum(([MASK, DEPTH] + text(1) for _ in range(k)), [])  # noqa: E731
+    cases = []
+
+    def add(name, rows, n_masks, *, am="pad", labels=False, depths=True, side="right", mx=None, images_as="tensor", holes=None):
+        ids, amask = pad(rows)
+        n_img = int((ids == IMG).sum())
+        if holes:
+            for (b, j) in holes:
+                amask[b, j] = 0
+        cases.append(dict(name=name, ids=ids, am=None if am is None else amask, labels=labels, depths=depths, side=side, mx=mx,
+                          n_masks=n_masks, n_img=n_img, images_as=images_as))
+
+    add("one_image", [[1] + text(3) + [IMG] + text(2) + R(2) + text(2)], [2], am=None)
+    add("two_images_in_one_prompt", [[1] + text(2) + [IMG] + R(1) + [IMG] + R(2) + text(1)], [3, 1], am=None, labels=True)
+    add("text_only_between_image_prompts", [[1, IMG] + R(2) + text(2), [1] + text(6), [1] + text(1) + [IMG] + R(1)], [2, 1], labels=True)
+    add("left_padding", [[1, IMG] + R(2) + text(4), [1] + text(2) + [IMG] + R(1)], [2, 1], side="left", labels=True)
+    add("truncation", [[1] + text(2) + [IMG] + R(2) + text(3), [1, IMG] + text(2)], [2, 1], mx=150, labels=True)
+    add("truncation_left", [[1] + text(2) + [IMG] + R(2) + text(3), [1, IMG] + text(2)], [2, None], mx=150, side="left")
+    add("mask_entry_is_None", [[1, IMG] + R(2) + text(1), [1, IMG] + R(1) + text(2)], [2, None])
+    add("more_embeddings_than_mask_ids", [[1, IMG] + R(1) + text(2)], [3], am=None)
+    add("fewer_embeddings_than_mask_ids", [[1, IMG] + R(3) + text(2)], [2], am=None)
+    add("depths_None", [[1, IMG] + R(2) + text(2), [1] + text(1) + [IMG] + R(1)], [2, 1], depths=False, labels=True)
+    add("attention_mask_interior_holes", [[1] + text(2) + [IMG] + R(2) + text(3), [1, IMG] + R(1) + text(5)], [2, 1],
+        holes=[(0, 1), (0, 6), (1, 4)], labels=True)
+    add("hole_over_a_mask_id", [[1, IMG] + R(2) + text(3)], [2], holes=[(0, 2)])
+    add("images_as_list", [[1, IMG] + R(1) + text(2), [1, IMG] + R(1)], [1, 1], images_as="list")
+    add("images_5d", [[1, IMG, IMG] + R(1) + text(2), [1] + text(1) + [IMG, IMG] + R(2)], [1, None, 2, 1], images_as="5d", labels=True)
+
+    out = {"mask_token_id": np.int64(MASK), "depth_token_id": np.int64(DEPTH), "vocab": np.int64(V), "image_tokens": np.int64(NF),
+           "case_names": np.array([c["name"] for c in cases])}
+    side0 = getattr(model.llm.config, "tokenizer_padding_side", "right")
+    mx0 = getattr(model.llm.config, "tokenizer_model_max_length", None)
+    for ci, c in enumerate(cases):
+        ids, am = c["ids"], c["am"]
+        n_img = c["n_img"]
+        images = img(n_img)
+        depths = img(n_img) if c["depths"] else None
+        masks = [None if k is None else boxes(k) for k in c["n_masks"]]
+        labels = None
+        if c["labels"]:
+            labels = torch.randint(0, V, ids.shape, generator=g)
+            labels[ids == IMG] = so.IGNORE_INDEX
+        im_in, dp_in = images, depths
+        if c["images_as"] == "list":
+            im_in = [images[i:i + 1] for i in range(n_img)]
+            dp_in = None if depths is None else [depths[i:i + 1] for i in range(n_img)]
+        elif c["images_as"] == "5d":
+            im_in = images.reshape(ids.shape[0], -1, 3, S, S)
+            dp_in = None if depths is None else depths.reshape(ids.shape[0], -1, 3, S, S)
+        model.llm.config.tokenizer_padding_side = c["side"]
+        model.llm.config.tokenizer_model_max_length = c["mx"] if c["mx"] is not None else mx0
+        pre = f"c{ci}."
+        out[pre + "input_ids"] = ids.numpy()
+        out[pre + "has_attention_mask"] = np.int64(am is not None)
+        if am is not None:
+            out[pre + "attention_mask"] = am.numpy()
+        if labels is not None:
+            out[pre + "labels"] = labels.numpy()
+        out[pre + "n_masks"] = np.array([-1 if k is None else k for k in c["n_masks"]], dtype=np.int64)
+        out[pre + "have_depths"] = np.int64(c["depths"])
+        out[pre + "padding_side_left"] = np.int64(c["side"] == "left")
+        out[pre + "max_length"] = np.int64(-1 if c["mx"] is None else c["mx"])
+        # the oracle's restatement on the same coded rows
+        feats_c = (coded(n_img * NF) + 1e5 * KIND_IMAGE).reshape(n_img, NF, H)
+        off, me_c, de_c = 0, [], ([] if c["depths"] else None)
+        for k in c["n_masks"]:
+            n = 0 if k is None else k
+            me_c.append(None if k is None else coded(off + n)[off:] + 1e5 * KIND_MASK)
+            if de_c is not None:
+                de_c.append(None if k is None else coded(off + n)[off:] + 1e5 * KIND_DEPTH)
+            off += n
+        wv = {so.LM + "model.embed_tokens.weight": coded(V)}
+        cfg.padding_side = c["side"]
+        cfg.tokenizer_model_max_length = c["mx"] if c["mx"] is not None else mx0
+        err = None
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                (_, pos, am_out, _, embeds, new_labels) = model.prepare_inputs_labels_for_multimodal(
+                    ids, None, am, None, labels, im_in, masks, dp_in)
+            except (RuntimeError, IndexError) as e:
+                err = type(e).__name__
+            o_err = None
+            try:
+                o = so.splice(wv, cfg, ids, am, feats_c, me_c, de_c, have_depths=bool(c["depths"]), labels=labels)
+            except (RuntimeError, IndexError) as e:
+                o_err = type(e).__name__
+        assert (err is None) == (o_err is None), (c["name"], err, o_err)
+        out[pre + "raises"] = np.int64(err is not None)
+        if err is not None:
+            print(f"  {c['name']}: the reference raises {err} (oracle: {o_err})")
+            continue
+        code = embeds[..., 0].double()
+        assert torch.equal(embeds, embeds[..., :1].expand_as(embeds)), "coded rows must stay constant along H"
+        kind = torch.floor(code / 1e5).long()
+        index = (code - 1e5 * kind).round().long() - 1  # -1: a padding row (zeros)
+        kind[index < 0] = -1
+        out[pre + "src_kind"] = kind.numpy().astype(np.int8)
+        out[pre + "src_index"] = index.numpy().astype(np.int32)
+        out[pre + "has_attention_mask_out"] = np.int64(am_out is not None)
+        if am_out is not None:
+            out[pre + "attention_mask_out"] = am_out.numpy().astype(np.int8)
+        if labels is not None:
+            out[pre + "new_labels"] = new_labels.numpy()
+        assert torch.equal(o[0], embeds), c["name"]
+        assert (o[1] is None) == (am_out is None) and (am_out is None or torch.equal(o[1].bool(), am_out.bool())), c["name"]
+        if labels is not None:
+            assert torch.equal(o[3], new_labels), c["name"]
+        print(f"  {c['name']}: T = {embeds.shape[1]}, sources text/image/mask/depth/pad = "
+              + "/".join(str(int((kind == k).sum())) for k in (0, 1, 2, 3, -1)) + "  oracle == reference")
+    model.llm.config.tokenizer_padding_side, model.llm.config.tokenizer_model_max_length = side0, mx0
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(GOLD, "splice_kat.npz"), **out)
+    print("  wrote splice_kat.npz")
+
+
 def mint_posembed_kat():
     """vision_resolution elevation: run the reference's OWN `VisionTower._maybe_resize_pos_embeds`
     (llava/model/multimodal_encoder/vision_encoder.py:36-113, interpolate_mode "linear") on stand-in objects that carry exactly
@@ -672,6 +855,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "vendored":  # only the vendored-Llama fixture (rope scaling, flash-attn call sites)
         mint_vendored_llama_kat()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "splice":  # only the splice edge-case fixture (row-source maps from the reference)
+        mint_splice_kat()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "labels":  # only the labels / loss fixture (reuses tiny_fp32.npz's weights)
         mint_labels_kat()
         sys.exit(0)
@@ -681,6 +867,7 @@ if __name__ == "__main__":
     mint_model_case(torch.bfloat16, "tiny_bf16.npz")
     mint_model_case(torch.float32, "tiny_clip_fp32.npz", tower="clip")
     mint_labels_kat()
+    mint_splice_kat()
     mint_posembed_kat()
     mint_checkpoint()
     mint_vendored_llama_kat()

@@ -1,0 +1,105 @@
+// Round 6: what does the FETCH PATTERN of the batched decode product (skinny.hip) cost, with nothing else in the kernel?
+// A block owns `cw` consecutive weight rows (tiles of 16), its NW waves split K into contiguous ranges; a wave requests a tile's
+// [16 rows x SK k] stage as 8 (or 16) buffer loads and XORs what arrives.  Knobs: bytes per lane-load (8 = the fp8 kernel's
+// dwordx2, 16 = dwordx4), rows per wave-instruction (2 = the kernel's shape, 1 = one row per instruction), stages in flight, waves,
+// blocks per CU.  Weights are fp8-sized ([rows][K] bytes) or bf16-sized ([rows][2K] bytes): only the byte geometry matters here.
+//   hipcc --offload-arch=gfx950 -O3 ubench_skinny_stream.hip -o ubench_skinny_stream && ./ubench_skinny_stream
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+// LW: bytes per lane-load; RPI: rows per wave-instruction (2: 32 lanes per row, 1: 64 lanes per row); DEPTH: stages in flight
+template <int LW, int RPI, int DEPTH, int NW>
+__global__ __launch_bounds__(64 * NW) void kstream(const unsigned char* __restrict__ W, unsigned* __restrict__ out, int N, int KB /* bytes per row */, int cw) {
+  constexpr int LPR = 64 / RPI;            // lanes per row
+  constexpr int SKB = LPR * LW;            // bytes of a row per wave-instruction = slice width in bytes
+  constexpr int NL = 16 / RPI;             // loads per stage
+  using R = typename std::conditional<LW == 8, u2, u4>::type;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lrow = lane / LPR, lchunk = lane % LPR;
+  const int c0 = blockIdx.x * cw, cwb = min(cw, N - c0), ntile = (cwb + 15) >> 4;
+  const int nsl = KB / SKB, per_wave = (nsl + NW - 1) / NW, first = wave * per_wave, cnt = max(0, min(per_wave, nsl - first));
+  const int nst = cnt * ntile;             // stages of this wave: slice-major, tiles inside (as the kernel walks sub-units)
+  unsigned acc = 0;
+  R ring[DEPTH][NL];
+  auto issue = [&](R* r, int st) {
+    const bool ok = st < nst;
+    const int sl = first + (ok ? st / ntile : 0), t = ok ? st % ntile : 0;
+    const unsigned char* base = W + (size_t)(c0 + t * 16) * KB;
+    const int nrow = min(cwb - t * 16, 16);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, ok ? nrow * KB : 0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const unsigned off = (unsigned)(RPI * j + lrow) * (unsigned)KB + (unsigned)sl * SKB + lchunk * LW;
+      if constexpr (LW == 8) r[j] = __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 2));
+      else r[j] = __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 2));
+    }
+  };
+#pragma unroll
+  for (int f = 0; f < DEPTH - 1; ++f) issue(ring[f], f);
+  for (int st = 0; st < nst; st += DEPTH) {
+#pragma unroll
+    for (int h = 0; h < DEPTH; ++h) {
+      issue(ring[(h + DEPTH - 1) % DEPTH], st + h + DEPTH - 1);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) acc ^= ring[h][j][0] ^ ring[h][j][LW / 4 - 1];
+    }
+  }
+  if (acc == 0x12345u) out[0] = 1;
+}
+
+__global__ void fill(unsigned* p, size_t n, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = h;
+  }
+}
+
+template <int LW, int RPI, int DEPTH, int NW>
+int run(const char* name, hipStream_t s, std::vector<unsigned char*>& Ws, unsigned* out, int N, int KB, int blocks) {
+  int cw = (N + blocks - 1) / blocks; if (cw < 16) cw = 16;
+  const int grid = (N + cw - 1) / cw;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipGraph_t g; hipGraphExec_t ge;
+  CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  for (auto W : Ws) hipLaunchKernelGGL((kstream<LW, RPI, DEPTH, NW>), dim3(grid), dim3(64 * NW), 0, s, W, out, N, KB, cw);
+  CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  float ms = 0, best = 1e9f;
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
+  }
+  const double us = best * 1e3 / Ws.size(), mb = (double)N * KB / 1e6;
+  printf("  %-64s %7.2f us  %.2f TB/s\n", name, us, mb / us);
+  CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+  return 0;
+}
+
+int main() {
+  hipStream_t s; CK(hipStreamCreate(&s));
+  unsigned* out; CK(hipMalloc(&out, 64));
+  struct Shape { const char* name; int N, K; };  // N = weight rows streamed (gate + up rows for the SwiGLU product), K elements
+  Shape shapes[] = {{"qkv", 6144, 4096}, {"o", 4096, 4096}, {"gate/up", 28672, 4096}, {"down", 4096, 14336}};
+  for (int web = 1; web <= 2; ++web) {
+    for (auto& sh : shapes) {
+      const int KB = sh.K * web;
+      const size_t bytes = (size_t)sh.N * KB;
+      const int L = (int)(700e6 / bytes) + 2;  // > the 256 MiB of the Infinity Cache between reuses
+      std::vector<unsigned char*> Ws(L);
+      for (auto& W : Ws) { CK(hipMalloc(&W, bytes)); hipLaunchKernelGGL(fill, dim3(2048), dim3(256), 0, s, (unsigned*)W, bytes / 4, (unsigned)(size_t)W); }
+      CK(hipStreamSynchronize(s));
+      printf("%s  %s weights: %d rows x %d bytes = %.1f MB per launch, %d launches per graph\n", sh.name, web == 1 ? "fp8" : "bf16", sh.N, KB, bytes / 1e6, L);
+      // rows for the swiglu product are walked as plain rows here (the kernel walks gate tile, up tile: two 16-row tiles N rows apart)
+#define RUN(LW, RPI, D, NW, B) if (run<LW, RPI, D, NW>("  " #LW " B/lane, " #RPI " rows/instr, depth " #D ", " #NW " waves, " #B " blocks", s, Ws, out, sh.N, KB, B)) return 1
+      RUN(8, 2, 2, 4, 512);  RUN(8, 2, 2, 8, 256);  RUN(8, 2, 3, 4, 512);  RUN(8, 2, 4, 4, 512);  RUN(8, 2, 4, 8, 256);
+      RUN(8, 1, 2, 4, 512);  RUN(8, 1, 4, 4, 512);
+      RUN(16, 2, 2, 4, 512); RUN(16, 2, 2, 8, 256); RUN(16, 2, 3, 4, 512); RUN(16, 2, 4, 4, 512); RUN(16, 2, 4, 8, 256);
+      RUN(16, 1, 2, 4, 512); RUN(16, 1, 4, 4, 512); RUN(16, 1, 4, 8, 256);
+      for (auto W : Ws) CK(hipFree(W));
+    }
+  }
+  return 0;
+}

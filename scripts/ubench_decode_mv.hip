@@ -1,5 +1,7 @@
 // The decode-path products (srgpt_gemv / srgpt_gemv_w8) of one LLM layer + lm_head, timed in a raw hipGraph chain per shape.
-//   ubench_decode_mv <libsrgpt_hip*.so> <batch> <bf16|fp8>
+//   ubench_decode_mv <libsrgpt_hip*.so> <batch> <bf16|fp8> [pub]
+// pub: through srgpt_gemv_rowss as the batched decode step calls them (the RMSNorm products read a published row-statistics table,
+// the residual products publish one)
 // The library is dlopen'ed so that one binary times every build variant (scripts/build_skinny_variants.sh).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -10,6 +12,8 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 typedef int (*gemv_fn)(const void*, const void*, const void*, float, const void*, void*, int, int, int, int, int, int, void*);
 typedef int (*gemv_w8_fn)(const void*, const void*, const float*, const void*, float, const void*, void*, int, int, int, int, int, void*);
+typedef int (*gemv_rowss_fn)(const void*, const void*, const void*, const float*, const void*, float, const void*, void*, int, int, int, int, int,
+                             const float*, float*, void*);
 __global__ void fill_bf16(unsigned* p, size_t n, unsigned seed) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
@@ -32,9 +36,15 @@ int main(int argc, char** argv) {
   gemv_fn gemv = (gemv_fn)dlsym(lib, "srgpt_gemv");
   gemv_w8_fn gemv_w8 = (gemv_w8_fn)dlsym(lib, "srgpt_gemv_w8");
   const char* (*last_error)() = (const char* (*)())dlsym(lib, "srgpt_last_error");
+  gemv_rowss_fn gemv_rowss = (gemv_rowss_fn)dlsym(lib, "srgpt_gemv_rowss");
   if (!gemv || !gemv_w8) { printf("symbols missing\n"); return 2; }
   const int B = atoi(argv[2]);
   const bool fp8 = !strcmp(argv[3], "fp8");
+  const bool pub = argc > 4 && !strcmp(argv[4], "pub");
+  if (pub && !gemv_rowss) { printf("srgpt_gemv_rowss missing\n"); return 2; }
+  float *ss_a, *ss_b;  // row-statistics tables [B][512]
+  CK(hipMalloc(&ss_a, (size_t)B * 512 * 4)); CK(hipMalloc(&ss_b, (size_t)B * 512 * 4));
+  CK(hipMemset(ss_a, 0, (size_t)B * 512 * 4)); CK(hipMemset(ss_b, 0, (size_t)B * 512 * 4));
   const int web = fp8 ? 1 : 2;
   hipStream_t s; CK(hipStreamCreate(&s));
   struct Cfg { const char* name; int N, K, norm, res, swiglu, f32; int L; };
@@ -59,6 +69,9 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(fill_f32, dim3(64), dim3(256), 0, s, sc, rows, 0.001f);
     CK(hipStreamSynchronize(s));
     auto run = [&](void* W) -> int {
+      if (pub && c.N != 128258)
+        return gemv_rowss(x, fp8 ? nullptr : W, fp8 ? W : nullptr, fp8 ? sc : nullptr, c.norm ? g : nullptr, 1e-5f, c.res ? res : nullptr, out, B,
+                          c.N, c.K, c.swiglu, c.f32, c.norm ? ss_a : nullptr, c.res ? ss_b : nullptr, s);
       if (fp8) return gemv_w8(x, W, sc, c.norm ? g : nullptr, 1e-5f, c.res ? res : nullptr, out, B, c.N, c.K, c.swiglu, c.f32, s);
       return gemv(x, W, c.norm ? g : nullptr, 1e-5f, c.res ? res : nullptr, out, B, c.N, c.K, c.swiglu, c.f32, 1 /*SRGPT_BF16*/, s);
     };

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // per wave: [x stage | w stage]; reused for the reduction
   __shared__ float rs_s[16];
   __shared__ float ss_s[16][NW / 2];
+  __shared__ float pub_s[NW][4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned char* xst = smem + wave * (XSTAGEB + WSTAGEB);
@@ -121,30 +122,38 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
 
   // activation slice: XL loads covering 2*NI rows x SK k (rows past the batch re-read row B-1: their outputs are never
   // stored), plus the RMSNorm gains of the lane's chunk
-  u32x4 xr[XL];
-  u32x4 gr = {0u, 0u, 0u, 0u};
-  auto load_x = [&](int sl) {
+  // The slices live in a register ring of XS slots (slot of slice index j: j % XS); x of slice j + XS is requested right after slice
+  // j has been staged.  Vector loads return IN ORDER: with one slot, waiting for the next slice's activations also waits for every
+  // weight stage requested before them -- a product whose slices are ONE weight stage (o_proj / down_proj: a single 16-column tile)
+  // then never has more than one stage in flight whatever the weight ring's depth (round 6; run_pass picks XS per sub-unit count).
+  constexpr int DEPTH = W8 ? SRGPT_SKINNY_DEPTH_W8 : SRGPT_SKINNY_DEPTH;
+  constexpr int XSMAX = DEPTH;
+  u32x4 xr[XSMAX][XL];
+  u32x4 gr[XSMAX];
+  auto load_x = [&](auto slot_c, int sl) {
+    constexpr int slot = decltype(slot_c)::value;
     int kg = min(sl * SK + xchunk * 8, K - 8);
     asm volatile("" : "+v"(kg));  // keep the row products out of loop-invariant registers (see issue_w)
 #pragma unroll
     for (int j = 0; j < XL; ++j) {
       const unsigned off = (unsigned)min(xrow_of(j), B - 1) * (unsigned)K + (unsigned)kg;
-      xr[j] = *reinterpret_cast<const u32x4*>(x + off);
+      xr[slot][j] = *reinterpret_cast<const u32x4*>(x + off);
     }
-    gr = *reinterpret_cast<const u32x4*>((do_norm ? norm_w : x) + kg);  // unconditional: see the note on counted waits below
+    gr[slot] = *reinterpret_cast<const u32x4*>((do_norm ? norm_w : x) + kg);  // unconditional: see the note on counted waits below
   };
-  auto stage_x = [&](int sl, bool valid) {
+  auto stage_x = [&](auto slot_c, int sl, bool valid) {
+    constexpr int slot = decltype(slot_c)::value;
     const bool kvalid = valid && sl * SK + xchunk * 8 < K;
 #pragma unroll
     for (int j = 0; j < XL; ++j) {
-      u32x4 v = xr[j];
+      u32x4 v = xr[slot][j];
       if (do_norm) {
         const float rsj = rs_s[xrow_of(j)];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           // weight * hidden.to(dtype): two roundings, like the GEMV prologue
-          const float lo = bf16lo(gr[q]) * rnd<bf16_t>(bf16lo(v[q]) * rsj);
-          const float hi = bf16hi(gr[q]) * rnd<bf16_t>(bf16hi(v[q]) * rsj);
+          const float lo = bf16lo(gr[slot][q]) * rnd<bf16_t>(bf16lo(v[q]) * rsj);
+          const float hi = bf16hi(gr[slot][q]) * rnd<bf16_t>(bf16hi(v[q]) * rsj);
           bf16x2 p;
           p[0] = (bf16_t)lo;
           p[1] = (bf16_t)hi;
@@ -219,9 +228,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   auto sl_of = [&](int i) { return wave + NW * i; };
 #endif
   SK_STAMP(0);
-  load_x(sl_of(0));
+  load_x(std::integral_constant<int, 0>{}, sl_of(0));
+  bool x0_ready = true;  // slot 0 holds (a request for) the first slice of the pass about to start
 
-  constexpr int DEPTH = W8 ? SRGPT_SKINNY_DEPTH_W8 : SRGPT_SKINNY_DEPTH;
   // measured per decode step (profiles/r02_skinny_ab.txt, section 6): 5-8 rows bf16 -1.8 %, 3-4 rows bf16 +-0, fp8 +0.8..1 % -> bf16 only;
   // 16 staged rows: the registers are not there
   constexpr bool PRE = (W8 ? SRGPT_SKINNY_PRE_W8 != 0 : SRGPT_SKINNY_PRE != 0) && NI == 4;
@@ -311,6 +320,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     constexpr int NS = SK / 32;           // MFMA k steps per stage
     constexpr int FS = NI == 8 ? 2 : SRGPT_SKINNY_FS;  // k steps whose fragments are read together (16 staged rows: fewer, registers)
     constexpr bool TWO_ACC = NI < 8;  // even / odd k steps on separate accumulators (16 staged rows: the registers are not there)
+    // slots of the activation ring (see load_x): as many slices ahead as the weight ring reaches
+    constexpr int XS = NSU == 1 ? DEPTH : (NSU == 2 && DEPTH == 4 ? 2 : 1);
+    static_assert(DEPTH % XS == 0, "the slot of a slice must be a compile-time function of its place in the trip");
+    if (!x0_ready) load_x(std::integral_constant<int, 0>{}, sl_of(0));
+    if constexpr (XS > 1) load_x(std::integral_constant<int, 1>{}, sl_of(min(1, max(cnt - 1, 0))));
+    if constexpr (XS > 2) load_x(std::integral_constant<int, 2>{}, sl_of(min(2, max(cnt - 1, 0))));
+    if constexpr (XS > 3) load_x(std::integral_constant<int, 3>{}, sl_of(min(3, max(cnt - 1, 0))));
+    x0_ready = XS == 1;  // a one-slot pass leaves the next pass's first slice requested
     f32x4 acc[NSU], acc2[TWO_ACC ? NSU : 1];
 #pragma unroll
     for (int su = 0; su < NSU; ++su) acc[su] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -369,8 +386,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
             const int fn = h * NSU + su + DEPTH - 1;  // stage to prefetch, relative to this trip
             issue_w(wb[fn % DEPTH], pass, sl_of(i + fn / NSU), fn % NSU, i + fn / NSU < cnt);
             if (su == 0) {
-              stage_x(sl, true);
-              load_x(i + h + 1 < cnt ? sl_of(i + h + 1) : sl_of(0));  // next slice, or the first one of the next pass
+              stage_x(std::integral_constant<int, h % XS>{}, sl, true);
+              if constexpr (XS == 1) load_x(std::integral_constant<int, 0>{}, i + h + 1 < cnt ? sl_of(i + h + 1) : sl_of(0));  // next slice, or the first one of the next pass
+              else load_x(std::integral_constant<int, h % XS>{}, sl_of(min(i + h + XS, cnt - 1)));  // XS slices ahead (past the end: a valid slice, never staged)
             }
 #if !(defined(SRGPT_SKINNY_PROBE) && SRGPT_SKINNY_PROBE == 2)
 #pragma unroll
@@ -470,7 +488,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
         } else {
           float v = rnd<bf16_t>(a[0]);
           if (residual) v = rnd<bf16_t>(__uint_as_float((unsigned int)pre_res[i] << 16) + v);
-          if constexpr (NW == 4) pub_acc = fmaf(v, v, pub_acc);
+          pub_acc = fmaf(v, v, pub_acc);
           if (out_f32)
             reinterpret_cast<float*>(out)[(size_t)b * N + n] = v;
           else
@@ -495,13 +513,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
       default: run_pass(std::integral_constant<int, 4>{}, pass, nu); break;
     }
   }
-  if constexpr (!SWIGLU && NW == 4) {  // (the launcher gives a publishing product 4-wave blocks)
+  if constexpr (!SWIGLU) {
     if (ss_out != nullptr) {
-      // epilogue element e = tid + i NT sits in batch row 4 (lane >> 4) + wave whatever i and the pass are: a thread's pub_acc
-      // belongs to ONE row, and the 16 lanes of a DPP row hold that row's 16 columns of every tile
-      const float tot = lanes_sum<16>(pub_acc);
+      // epilogue element e = tid + i NT sits in batch row 4 (lane >> 4) + (wave & 3) whatever i and the pass are: a thread's pub_acc
+      // belongs to ONE row, and the 16 lanes of a DPP row hold that row's 16 columns of every tile; waves w and w + 4 (8-wave blocks)
+      // hold different tiles of the same rows: added in wave order through LDS
+      float tot = lanes_sum<16>(pub_acc);
+      if constexpr (NW > 4) {
+        if ((lane & 15) == 0) pub_s[wave][lane >> 4] = tot;
+        __syncthreads();
+        if (wave < 4) {
+          tot = 0.f;
+#pragma unroll
+          for (int wv = 0; wv < NW; wv += 4) tot += pub_s[wave + wv][lane >> 4];
+        }
+      }
       const int b = 4 * (lane >> 4) + wave;
-      if ((lane & 15) == 0 && b < B) {
+      if (wave < 4 && (lane & 15) == 0 && b < B) {
         float* row = ss_out + (size_t)b * SRGPT_ROWSS_STRIDE;
         row[blockIdx.x] = tot;
         for (int sidx = (int)blockIdx.x + (int)gridDim.x; sidx < SRGPT_ROWSS_STRIDE; sidx += (int)gridDim.x) row[sidx] = 0.f;
@@ -536,8 +564,11 @@ int launch_skinny_nw(const void* x, const void* W, const float* wscale, const vo
   // 12.3 vs 13.7 fp8) -- there the prologue is shared by twice the threads.
   const int cus = srgpt_device_cus();
   int waves = SRGPT_KNOB("SRGPT_SKINNY_WAVES", 0);
-  if (waves != 4 && waves != 8) waves = (norm_w != nullptr && (N + cus - 1) / cus <= 32) ? 8 : 4;
-  if (ss_out) waves = 4;  // the publishing epilogue is the 4-wave kernel's (one wave per batch-row residue)
+  if (waves != 4 && waves != 8) {
+    const int ncol = (N + cus - 1) / cus;  // output columns per CU
+    waves = (norm_w != nullptr && ncol <= 32) ? 8 : 4;
+    if (norm_w == nullptr && ncol <= SRGPT_KNOB("SRGPT_SKINNY_W8_RES_COLS", 0)) waves = 8;
+  }
   const int blocks = waves == 8 ? cus : 2 * cus;
   int cw = (N + blocks - 1) / blocks;
   if (cw < 16) cw = 16;

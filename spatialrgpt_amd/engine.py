@@ -318,6 +318,19 @@ class SrgptEngine:
         table, image features, region embeddings, zeros for padding) and, when asked, the spliced labels / attention mask."""
         cfg, dev = self.cfg, self.device
         B, T, H = plan.B, plan.T, cfg.hidden
+        # the plan's offsets into the concatenated region tables were computed from PREDICTED row counts (masks[i].shape[0]) before
+        # the tower ran: what is gathered must have exactly those shapes, or the kernel reads the wrong rows / past a table
+        if image_features.shape[0] != plan.n_images or image_features.shape[1] != plan.nimg_feat:
+            raise RuntimeError(f"splice: planned for {plan.n_images} x {plan.nimg_feat} image rows, got {tuple(image_features.shape[:2])}")
+        counts = plan.region_counts
+        for what, embeds, planned in (("mask", mask_embeds, cfg.enable_region and counts is not None),
+                                     ("depth", depth_embeds, cfg.enable_region and cfg.enable_depth and plan.have_depths and counts is not None)):
+            if not planned:
+                continue
+            got = [] if embeds is None else [None if e is None else int(e.shape[0]) for e in embeds]
+            got += [None] * (plan.n_images - len(got))
+            if got != [counts[i] if i < len(counts) else None for i in range(plan.n_images)]:
+                raise RuntimeError(f"splice: planned for {what} embeddings of {list(counts)} rows per image, got {got}")
         out = torch.empty((B * T, H), device=dev, dtype=self.dtype)
         feats = image_features.reshape(-1, H).to(dtype=self.dtype).contiguous()
         me = de = None

@@ -1,8 +1,9 @@
 """GPU: the device-side splice (csrc/splice.hip: srgpt_splice_plan + srgpt_splice_gather) against the host loop it replaced.
 
-`splice_reference` below IS rounds 1-4's implementation of prepare_inputs_labels_for_multimodal's index arithmetic
-(llava_arch.py:420-611) -- a per-token Python loop, itself pinned to the reference by tests/golden/labels_kat.npz and the
-pipeline goldens -- kept as the checker.  Integer / byte work: every comparison is exact."""
+The edge cases are pinned to the REFERENCE by tests/golden/splice_kat.npz (row-source maps minted from llava_arch.py:333-650,
+`test_splice_equals_the_reference_row_source_maps`).  `splice_reference` below IS rounds 1-4's implementation of the same index
+arithmetic -- a per-token Python loop, itself checked against that fixture on CPU (tests/test_host_logic.py) -- kept for the
+randomised shapes the fixture does not hold (2100-position prompts, 8 prompts).  Integer / byte work: every comparison is exact."""
 import warnings
 
 import pytest
@@ -160,6 +161,51 @@ def test_splice_matches_the_host_loop(eng, side):
     _case(eng, 7, 2, 70, [1, 2], 3, side, mx=31, with_labels=True, with_am=True)          # cut at tokenizer_model_max_length
     _case(eng, 8, 5, 2100, [1, 0, 2, 1, 1], 6, side, with_am=True, with_labels=True)      # > 1024 positions: several per thread
     _case(eng, 9, 8, 64, [1] * 8, 8, side)                                                # configs[4]'s shape
+
+
+def test_splice_equals_the_reference_row_source_maps():
+    """The device splice against tests/golden/splice_kat.npz: the REFERENCE's row-source maps (llava_arch.py:333-650 run on
+    index-coded rows by oracle/make_golden.py `splice`) for several images per prompt, text-only rows, None mask entries, surplus /
+    missing region embeddings, depths=None, left padding, truncation, attention masks with holes, labels.  Exact."""
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.engine import SrgptEngine
+    from spatialrgpt_amd.weights import synth_state_dict
+    from tests.util import splice_kat_cases, splice_kat_tables
+
+    engine, n = None, 0
+    for c in splice_kat_cases():
+        if engine is None:
+            cfg = SrgptConfig(vit_hidden=64, vit_inter=176, vit_layers=2, vit_heads=4, image_size=42, patch_size=14, hidden=64,
+                              inter=128, layers=1, heads=4, kv_heads=2, vocab=c["vocab"], mask_token_id=c["mask_token_id"],
+                              depth_token_id=c["depth_token_id"])
+            engine = SrgptEngine(cfg, synth_state_dict(cfg, seed=3, dtype=torch.float32, device=DEV), device=DEV,
+                                 dtype=torch.float32, rope_positions=64)
+        cfg = engine.cfg
+        embed, feats, me, de, expect = splice_kat_tables(c, cfg.hidden, embed=engine.w.embed.cpu(), seed=n)
+        n += 1
+        dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+        cfg.padding_side, cfg.tokenizer_model_max_length = c["padding_side"], c["max_length"]
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                args = (dev(c["input_ids"]), dev(c["attention_mask"]), dev(feats), [dev(e) for e in me],
+                        None if de is None else [dev(e) for e in de], c["have_depths"])
+                if c["raises"]:
+                    with pytest.raises(RuntimeError, match="shape mismatch"):
+                        engine.splice(*args, labels=dev(c["labels"]))
+                    continue
+                got = engine.splice(*args, labels=dev(c["labels"]))
+        finally:
+            cfg.padding_side, cfg.tokenizer_model_max_length = "right", None
+        assert torch.equal(got[0].cpu(), expect()), c["name"]
+        if c["attention_mask_out"] is None:
+            assert got[1] is None, c["name"]
+        else:
+            assert got[1].dtype == c["attention_mask"].dtype and torch.equal(got[1].cpu().bool(), c["attention_mask_out"]), c["name"]
+        assert got[2] == [int((c["src_kind"][b] >= 0).sum()) for b in range(c["src_kind"].shape[0])], c["name"]
+        if c["labels"] is not None:
+            assert torch.equal(got[3].cpu(), c["new_labels"]), c["name"]
+    assert n >= 14
 
 
 def test_splice_errors_match_the_reference(eng):

@@ -330,3 +330,33 @@ def test_pad_mode_masks_follow_pillow_and_the_hf_processor_bit_for_bit():
         mp.do_normalize, mp.do_convert_rgb, mp.rescale_factor = False, False, 1.0
         ref = mp.preprocess(p[None, ...], return_tensors="pt")["pixel_values"][0]
         assert torch.equal(out, torch.as_tensor(ref).float())
+
+
+def test_the_gpu_tests_host_splice_loop_equals_the_reference_row_source_maps():
+    """tests/test_gpu_splice.py::splice_reference (the checker of the randomised device-splice cases) against the reference's own
+    row-source maps (tests/golden/splice_kat.npz): the checker is pinned, not only what it checks."""
+    import types
+    import warnings
+
+    import pytest
+    import torch
+
+    from tests.test_gpu_splice import splice_reference
+    from tests.util import splice_kat_cases, splice_kat_tables
+    for n, c in enumerate(splice_kat_cases()):
+        cfg = types.SimpleNamespace(mask_token_id=c["mask_token_id"], depth_token_id=c["depth_token_id"], enable_region=True,
+                                    enable_depth=True, tokenizer_model_max_length=c["max_length"], padding_side=c["padding_side"])
+        embed, feats, me, de, expect = splice_kat_tables(c, 8, seed=n)
+        args = (cfg, c["vocab"], embed, c["input_ids"], c["attention_mask"], feats, me, de, c["have_depths"], c["labels"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if c["raises"]:
+                with pytest.raises(RuntimeError, match="shape mismatch"):
+                    splice_reference(*args)
+                continue
+            out, am, lens, new_labels = splice_reference(*args)
+        assert torch.equal(out, expect()), c["name"]
+        if c["attention_mask_out"] is not None:
+            assert torch.equal(am, c["attention_mask_out"]), c["name"]
+        if c["labels"] is not None:
+            assert torch.equal(new_labels, c["new_labels"]), c["name"]

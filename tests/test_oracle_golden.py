@@ -127,6 +127,39 @@ def test_oracle_labels_and_loss_match_reference():
     assert_close(last, torch.from_numpy(z["logits_valid_last"]), 1e-4, 0, "last valid logits")
 
 
+def test_oracle_splice_equals_the_reference_row_source_maps():
+    """The splice restatement against tests/golden/splice_kat.npz -- the reference's own prepare_inputs_labels_for_multimodal
+    (llava_arch.py:333-650) run on index-coded rows: several images per prompt, text-only rows, None mask entries, surplus /
+    missing region embeddings, depths=None, left padding, truncation, attention masks with holes, list / 5-D images, labels.
+    Integer work: rows, attention mask and labels compare exactly; the error case raises."""
+    import warnings
+
+    from tests.util import splice_kat_cases, splice_kat_tables
+    n = 0
+    for c in splice_kat_cases():
+        cfg = so.SrgptConfig(hidden=16, vocab=c["vocab"], mask_token_id=c["mask_token_id"], depth_token_id=c["depth_token_id"],
+                             padding_side=c["padding_side"], tokenizer_model_max_length=c["max_length"])
+        embed, feats, me, de, expect = splice_kat_tables(c, 16, seed=n)
+        w = {so.LM + "model.embed_tokens.weight": embed}
+        args = (w, cfg, c["input_ids"], c["attention_mask"], feats, me, de)
+        n += 1
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if c["raises"]:
+                with pytest.raises(RuntimeError):
+                    so.splice(*args, have_depths=c["have_depths"], labels=c["labels"])
+                continue
+            o = so.splice(*args, have_depths=c["have_depths"], labels=c["labels"])
+        assert torch.equal(o[0], expect()), c["name"]
+        if c["attention_mask_out"] is None:
+            assert o[1] is None, c["name"]
+        else:
+            assert torch.equal(o[1].bool(), c["attention_mask_out"]), c["name"]
+        if c["labels"] is not None:
+            assert torch.equal(o[3], c["new_labels"]), c["name"]
+    assert n >= 14
+
+
 def _vendored():
     import json
     import os

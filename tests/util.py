@@ -192,3 +192,60 @@ def make_heavy_tailed(w, cfg, seed=13, gains=(0.1, 50.0), n_massive=6, massive=3
             t[:vhd] = (t[:vhd].float() * attn_gain).to(t.dtype)
             w[k] = t
     return planted
+
+
+# ---- tests/golden/splice_kat.npz: the reference's own row-source maps of the token-stream splice's edge cases ----
+KIND_PAD, KIND_TEXT, KIND_IMAGE, KIND_MASK, KIND_DEPTH = -1, 0, 1, 2, 3
+
+
+def splice_kat_cases():
+    """Yield the cases of tests/golden/splice_kat.npz (oracle/make_golden.py `splice`: llava_arch.py:333-650 run on index-coded
+    rows) as dicts: inputs (ids, attention mask | None, labels | None, per-image region counts with None entries, have_depths,
+    padding side, max length) and the reference's outputs (src_kind / src_index [B, T]: which row of which table every output row
+    is -- KIND_* above, index -1 = padding zeros --, attention mask, labels) or raises=True."""
+    z = np.load(os.path.join(GOLD, "splice_kat.npz"))
+    head = dict(mask_token_id=int(z["mask_token_id"]), depth_token_id=int(z["depth_token_id"]), vocab=int(z["vocab"]),
+                image_tokens=int(z["image_tokens"]))
+    for ci, name in enumerate(z["case_names"].tolist()):
+        g = lambda k: z[f"c{ci}.{k}"]  # noqa: E731
+        has = lambda k: f"c{ci}.{k}" in z.files  # noqa: E731
+        ids = torch.from_numpy(g("input_ids"))
+        c = dict(head, name=name, input_ids=ids,
+                 attention_mask=torch.from_numpy(g("attention_mask")) if int(g("has_attention_mask")) else None,
+                 labels=torch.from_numpy(g("labels")) if has("labels") else None,
+                 n_masks=[None if k < 0 else int(k) for k in g("n_masks").tolist()], have_depths=bool(int(g("have_depths"))),
+                 padding_side="left" if int(g("padding_side_left")) else "right",
+                 max_length=None if int(g("max_length")) < 0 else int(g("max_length")), raises=bool(int(g("raises"))))
+        c["n_images"] = len(c["n_masks"])
+        if not c["raises"]:
+            c["src_kind"] = torch.from_numpy(g("src_kind").astype(np.int64))
+            c["src_index"] = torch.from_numpy(g("src_index").astype(np.int64))
+            c["attention_mask_out"] = torch.from_numpy(g("attention_mask_out")).bool() if int(g("has_attention_mask_out")) else None
+            c["new_labels"] = torch.from_numpy(g("new_labels")) if has("new_labels") else None
+        yield c
+
+
+def splice_kat_tables(c, hidden, embed=None, seed=0, dtype=torch.float32):
+    """Source tables for a splice_kat case: (embed [vocab, H], image_features [n_images, nf, H], mask_embeds list, depth_embeds list |
+    None) with random rows, and `expect(kind, index) -> [B, T, H]` assembling the rows the reference's map names."""
+    g = torch.Generator().manual_seed(seed)
+    nf = c["image_tokens"]
+    if embed is None:
+        embed = torch.randn((c["vocab"], hidden), generator=g).to(dtype)
+    feats = torch.randn((c["n_images"], nf, hidden), generator=g).to(dtype)
+    me = [None if k is None else torch.randn((k, hidden), generator=g).to(dtype) for k in c["n_masks"]]
+    de = [None if k is None else torch.randn((k, hidden), generator=g).to(dtype) for k in c["n_masks"]] if c["have_depths"] else None
+
+    def expect():
+        kind, index = c["src_kind"], c["src_index"]
+        out = torch.zeros(tuple(kind.shape) + (hidden,), dtype=dtype)
+        tabs = {KIND_TEXT: embed.cpu(), KIND_IMAGE: feats.reshape(-1, hidden)}
+        if any(e is not None for e in me):
+            tabs[KIND_MASK] = torch.cat([e for e in me if e is not None], 0)
+        if de is not None and any(e is not None for e in de):
+            tabs[KIND_DEPTH] = torch.cat([e for e in de if e is not None], 0)
+        for k, tab in tabs.items():
+            sel = kind == k
+            out[sel] = tab[index[sel]]
+        return out
+    return embed, feats, me, de, expect
