@@ -167,7 +167,20 @@ int srgpt_gemv_w8(const void* x, const void* W8, const float* wscale, const void
 int srgpt_gemv_rowss_supported(int batch, int dtype, int fp8);
 int srgpt_gemv_rowss(const void* x, const void* W, const void* W8, const float* wscale, const void* norm_w, float norm_eps,
                      const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32, const float* rowss_in,
-                     float* rowss_out, srgpt_stream_t stream);
+                     float* rowss_out, int packed_rows, srgpt_stream_t stream);
+/* ABI 9: the PACKED decode layout of a streamed matrix.  The MFMA kernel behind srgpt_gemv_rowss multiplies 16 weight rows x 32 k
+ * per instruction and wants lane (c = lane & 15, g = lane >> 4) to hold row c, k = 32 s + 8 g .. + 8 of the step.  A row-major
+ * matrix delivers that through an LDS transpose per 8-KiB stage; the packed array stores the SAME bytes in operand order, so one
+ * coalesced 16-byte load per lane is the fragment (fp8 weights, 8 rows per GPU: the four layer products 56 -> 52 us,
+ * profiles/r06_skinny_packed.txt).  Layout, `rows` = 4, 8 or 16 rows per granule, e = bytes per element (1: fp8, 2: bf16),
+ * kb = 16 / e ... a k block is 64 k (fp8) or 32 k (bf16):
+ *   out[ ((n / rows) * (K / kblock) + k / kblock) * rows * 64  +  ((k % 32) / 8 * rows + n % rows) * 16  +  byte ]
+ *   byte = (k % 8) * 2 (bf16)   |   ((k % 64) / 32) * 8 + k % 8 (fp8: the lane's 8 k of two consecutive MFMA steps)
+ * N is padded to whole granules with zeros (srgpt_packed_bytes); K %% 64 == 0 (fp8) / K %% 32 == 0 (bf16).  A SwiGLU matrix
+ * [gate rows (N); up rows (N)] is packed as ONE matrix of 2 N rows (N %% rows == 0).  srgpt_gemv_rowss takes such an array as
+ * W / W8 with packed_rows = rows (0: row-major) and returns bit for bit what it returns for the row-major matrix. */
+size_t srgpt_packed_bytes(int N, int K, int elem_bytes, int rows);
+int srgpt_pack_decode_weights(const void* W, void* out, int N, int K, int elem_bytes, int rows, srgpt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Normalisations.
@@ -424,6 +437,13 @@ typedef struct {
    * 1: prefill quantises each GEMM's input per token (srgpt_quant_rows_e4m3) and multiplies on the fp8 matrix pipe
    * (srgpt_gemm_w8a8); decode and the all-position lm_head stay W8A16.  Needs hidden, inter and heads * head_dim % 128 == 0. */
   int fp8_act;
+  /* ABI 9: optional PACKED copies (srgpt_pack_decode_weights) of the fp8 layer matrices for the batched decode step (2+ rows per GPU);
+   * NULL (array or entry): that product streams the row-major copy.  pk_rows_*: rows per granule of the matrix' packed copies. */
+  const void* const* wqkv8p;
+  const void* const* wo8p;
+  const void* const* wgu8p;
+  const void* const* wdown8p;
+  int pk_rows_qkv, pk_rows_o, pk_rows_gu, pk_rows_down;
 } srgpt_llm_weights;
 
 typedef struct {

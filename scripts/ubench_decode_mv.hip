@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
     const size_t rows = (size_t)c.N * (c.swiglu ? 2 : 1);
     std::vector<void*> Ws(L);
     for (auto& W : Ws) {
-      CK(hipMalloc(&W, rows * c.K * web));
+      CK(hipMalloc(&W, (rows + 32) * c.K * web));  // slack: the packed layout pads the rows to whole 16-row tiles
       if (fp8) hipLaunchKernelGGL(fill_fp8, dim3(2048), dim3(256), 0, s, (unsigned*)W, rows * c.K / 4, (unsigned)(size_t)W);
       else hipLaunchKernelGGL(fill_bf16, dim3(2048), dim3(256), 0, s, (unsigned*)W, rows * c.K / 2, (unsigned)(size_t)W);
     }

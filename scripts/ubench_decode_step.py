@@ -15,13 +15,13 @@ from spatialrgpt_amd.weights import synth_state_dict
 
 cfg = SrgptConfig.vila15_8b()
 G, T = 128, 259
-knobs = {k: v for k, v in os.environ.items() if k.startswith("SRGPT_")}
+knobs = {k: v for k, v in os.environ.items() if k.startswith("SRGPT_") or k.startswith("UBENCH_")}
 wanted = [(a.split(":") + [str(T)])[:3] for a in sys.argv[1:]] or [["bf16", "1", str(T)]]
 rope = max(1024, max(int(t) for _, _, t in wanted) + G + 128)
 for fmt in sorted({w for w, _, _ in wanted}):
     sd = synth_state_dict(cfg, seed=0, dtype=torch.bfloat16, device="cuda")
     eng = SrgptEngine(cfg, sd, device="cuda", dtype=torch.bfloat16, rope_positions=rope, consume_state_dict=True,
-                      llm_weight_format="fp8" if fmt == "fp8" else "native")
+                      llm_weight_format="fp8" if fmt == "fp8" else "native", decode_layout=os.environ.get("UBENCH_DECODE_LAYOUT", "packed"))
     del sd
     for w, b, t_ in wanted:
         if w != fmt:

@@ -46,6 +46,8 @@ class LlmWeights(C.Structure):
         ("wqkv8", C.POINTER(vp)), ("wqkv_scale", C.POINTER(vp)), ("wo8", C.POINTER(vp)), ("wo_scale", C.POINTER(vp)),
         ("wgu8", C.POINTER(vp)), ("wgu_scale", C.POINTER(vp)), ("wdown8", C.POINTER(vp)), ("wdown_scale", C.POINTER(vp)),
         ("fp8_act", i32),
+        ("wqkv8p", C.POINTER(vp)), ("wo8p", C.POINTER(vp)), ("wgu8p", C.POINTER(vp)), ("wdown8p", C.POINTER(vp)),
+        ("pk_rows_qkv", i32), ("pk_rows_o", i32), ("pk_rows_gu", i32), ("pk_rows_down", i32),
     ]
 
 
@@ -70,7 +72,7 @@ SAMPLING_VOCAB_MAX = 128 * 2048
 NORM_RMS, NORM_LAYER = 1, 2  # srgpt_gemm_norm
 SPLICE_STATS = 8             # SRGPT_SPLICE_STATS: ints per prompt the splice plan reports
 ROWSS_STRIDE = 512           # SRGPT_ROWSS_STRIDE: slots per row of a row-statistics table
-ABI_VERSION = 8  # include/srgpt.h; bumped with every export / layout change
+ABI_VERSION = 9  # include/srgpt.h; bumped with every export / layout change
 
 _SIGNATURES = {
     "srgpt_last_error": (C.c_char_p, []),
@@ -92,7 +94,9 @@ _SIGNATURES = {
     "srgpt_splice_plan": (i32, [vp, vp, i32, i32, i32, i32, vp, i32, i32, i64, i64, i32, i32, vp, vp, vp, vp]),
     "srgpt_splice_gather": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i64, vp, vp, vp, vp]),
     "srgpt_gemv_rowss_supported": (i32, [i32, i32, i32]),
-    "srgpt_gemv_rowss": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "srgpt_gemv_rowss": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
+    "srgpt_packed_bytes": (C.c_size_t, [i32, i32, i32, i32]),
+    "srgpt_pack_decode_weights": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "srgpt_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, i32, i32, vp]),
     "srgpt_rmsnorm": (i32, [vp, vp, vp, i32, i32, f32, i32, vp]),
     "srgpt_attention": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64, i64,

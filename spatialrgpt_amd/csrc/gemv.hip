@@ -36,10 +36,11 @@ extern "C" void* srgpt_gemv_ts_ptr() {
 #endif
 
 int srgpt_skinny_launch(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
-                        int batch, int N, int K, int swiglu, int out_f32, const float* ss_in, float* ss_out, hipStream_t s);  // skinny.hip
+                        int batch, int N, int K, int swiglu, int out_f32, const float* ss_in, float* ss_out, int packed,
+                        hipStream_t s);  // skinny.hip
 int srgpt_skinny_w8_launch(const void* x, const void* W8, const float* wscale, const void* norm_w, float norm_eps,
                            const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32,
-                           const float* ss_in, float* ss_out, hipStream_t s);  // skinny.hip
+                           const float* ss_in, float* ss_out, int packed, hipStream_t s);  // skinny.hip
 int srgpt_w8_valu_max_batch();  // skinny.hip
 
 #ifndef SRGPT_GEMV_REG_PIPE
@@ -520,7 +521,7 @@ int dispatch_b(const void* x, const void* W, const void* norm_w, float eps, cons
       const void* rb = residual ? (const char*)residual + (size_t)b0 * N * sizeof(T) : nullptr;
       void* ob = (char*)out + (size_t)b0 * N * on;
       if (mfma && (nb > 4 || nb >= skinny_min))
-        SRGPT_TRY(srgpt_skinny_launch(xb, W, norm_w, eps, rb, ob, nb, N, K, swiglu, out_f32, nullptr, nullptr, s));
+        SRGPT_TRY(srgpt_skinny_launch(xb, W, norm_w, eps, rb, ob, nb, N, K, swiglu, out_f32, nullptr, nullptr, 0, s));
       else
         SRGPT_TRY((dispatch_b<T>(xb, W, norm_w, eps, rb, ob, nb, N, K, swiglu, out_f32, s)));
     }
@@ -565,22 +566,26 @@ extern "C" int srgpt_gemv_rowss_supported(int batch, int dtype, int fp8) {
 
 extern "C" int srgpt_gemv_rowss(const void* x, const void* W, const void* W8, const float* wscale, const void* norm_w,
                                 float norm_eps, const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32,
-                                const float* rowss_in, float* rowss_out, srgpt_stream_t stream) {
+                                const float* rowss_in, float* rowss_out, int packed_rows, srgpt_stream_t stream) {
   SRGPT_CHECK(x && (W || W8) && out, SRGPT_ERR_ARG, "srgpt_gemv_rowss: null pointer");
+  SRGPT_CHECK(packed_rows == 0 || packed_rows == 4 || packed_rows == 8 || packed_rows == 16, SRGPT_ERR_ARG,
+              "srgpt_gemv_rowss: packed_rows = %d (0: row-major; 4, 8 or 16 rows per granule)", packed_rows);
+  SRGPT_CHECK(packed_rows == 0 || (N % packed_rows == 0 && K % (W8 ? 64 : 32) == 0), SRGPT_ERR_ARG,
+              "srgpt_gemv_rowss: the packed layout needs N %% %d == 0 and K %% %d == 0 (N = %d, K = %d)", packed_rows, W8 ? 64 : 32, N, K);
   SRGPT_CHECK(!W8 || wscale, SRGPT_ERR_ARG, "srgpt_gemv_rowss: fp8 weights without row scales");
   SRGPT_CHECK(N > 0 && K > 0 && batch > 0 && K % 8 == 0, SRGPT_ERR_ARG, "srgpt_gemv_rowss: bad shape");
   SRGPT_CHECK(!(swiglu && (residual || out_f32)), SRGPT_ERR_ARG, "srgpt_gemv_rowss: swiglu excludes residual/out_f32");
   SRGPT_CHECK(srgpt_gemv_rowss_supported(batch, SRGPT_BF16, W8 != nullptr), SRGPT_ERR_UNSUPPORTED,
               "srgpt_gemv_rowss: %d row(s) of %s weights take a kernel without the statistics hand-off", batch, W8 ? "fp8" : "bf16");
   hipStream_t s = as_stream(stream);
-  if (W8) return srgpt_skinny_w8_launch(x, W8, wscale, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, rowss_in, rowss_out, s);
+  if (W8) return srgpt_skinny_w8_launch(x, W8, wscale, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, rowss_in, rowss_out, packed_rows, s);
   const size_t on = out_f32 ? sizeof(float) : 2;
   for (int b0 = 0; b0 < batch; b0 += 16) {
     const int nb = batch - b0 < 16 ? batch - b0 : 16;
     SRGPT_TRY(srgpt_skinny_launch((const char*)x + (size_t)b0 * K * 2, W, norm_w, norm_eps,
                                   residual ? (const char*)residual + (size_t)b0 * N * 2 : nullptr, (char*)out + (size_t)b0 * N * on, nb,
                                   N, K, swiglu, out_f32, rowss_in ? rowss_in + (size_t)b0 * SRGPT_ROWSS_STRIDE : nullptr,
-                                  rowss_out ? rowss_out + (size_t)b0 * SRGPT_ROWSS_STRIDE : nullptr, s));
+                                  rowss_out ? rowss_out + (size_t)b0 * SRGPT_ROWSS_STRIDE : nullptr, packed_rows, s));
   }
   return SRGPT_OK;
 }

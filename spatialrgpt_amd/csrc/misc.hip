@@ -15,7 +15,7 @@ void srgpt_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* srgpt_last_error(void) { return g_err; }
-extern "C" int srgpt_abi_version(void) { return 8; }
+extern "C" int srgpt_abi_version(void) { return 9; }
 extern "C" int srgpt_device_cus(void) {
   // per device ordinal, filled once each (benign race: every writer stores the same value)
   static std::atomic<int> cus[64];

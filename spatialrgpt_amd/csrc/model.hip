@@ -11,7 +11,7 @@ int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const
 void* srgpt_decode_attn_sync_words(float* ws, int B, int Hq, int D, size_t* bytes);  // attn.hip
 int srgpt_sample_launch(const float* logits, const srgpt_sampling* sp, int64_t* tok, void* ws, float* pv, int* pi, int* err, int B, int V,
                         hipStream_t s);  // sample.hip
-extern "C" int srgpt_sample_slices(void);
+extern "C" __attribute__((visibility("hidden"))) int srgpt_sample_slices(void);  // sample.hip (internal: not part of the C ABI)
 namespace {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -572,9 +572,13 @@ static int decode_step_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, srg
   const bool pub = srgpt_gemv_rowss_supported(B, dt, w8 ? 1 : 0) != 0 && SRGPT_KNOB("SRGPT_DECODE_ROWSS", 1) != 0;
   float* const ss_attn = d.rowss;                                       // rows after the attention block's residual add
   float* const ss_mlp = d.rowss + (size_t)B * SRGPT_ROWSS_STRIDE;       // rows after the MLP block's
+  // packed copy of layer i's matrix `which` (0 wqkv, 1 wo, 2 wgu, 3 wdown) for the MFMA kernel, or NULL: stream the row-major one
+  auto pk = [&](const void* const* arr, int i) -> const void* { return pub && w8 && arr != nullptr ? arr[i] : nullptr; };
   auto mv = [&](const void* x, const void* Wd, const void* W8p, const float* sc, const void* norm, const void* res, void* out,
-                int N, int K, int swiglu, int f32, const float* ss_in, float* ss_out) -> int {
-    if (pub) return srgpt_gemv_rowss(x, Wd, W8p, sc, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, ss_in, ss_out, stream);
+                int N, int K, int swiglu, int f32, const float* ss_in, float* ss_out, const void* W8pk = nullptr, int pk_rows = 0) -> int {
+    if (pub && W8pk != nullptr)
+      return srgpt_gemv_rowss(x, nullptr, W8pk, sc, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, ss_in, ss_out, pk_rows, stream);
+    if (pub) return srgpt_gemv_rowss(x, Wd, W8p, sc, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, ss_in, ss_out, 0, stream);
     if (w8) return srgpt_gemv_w8(x, W8p, sc, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, stream);
     return srgpt_gemv(x, Wd, norm, w->rms_eps, res, out, B, N, K, swiglu, f32, dt, stream);
   };
@@ -582,18 +586,19 @@ static int decode_step_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, srg
     char* kc = reinterpret_cast<char*>(st->kcache) + (size_t)i * layer_kv;
     char* vc = reinterpret_cast<char*>(st->vcache) + (size_t)i * layer_kv;
     SRGPT_TRY(mv(d.xd, w->wqkv[i], w8 ? w->wqkv8[i] : nullptr, w8 ? w->wqkv_scale[i] : nullptr, w->attn_norm[i], nullptr,
-                 d.qkvd, QW, Hd, 0, 0, i > 0 ? ss_mlp : nullptr, nullptr));
+                 d.qkvd, QW, Hd, 0, 0, i > 0 ? ss_mlp : nullptr, nullptr, pk(w->wqkv8p, i), w->pk_rows_qkv));
     // the attention launch also pulls o_proj's weights into L2 (HBM is idle while it runs).  Round 3 built the next step -- o_proj
     // itself inside this launch, weights in registers, agent-scope hand-off -- bit-exact and 3 us per layer SLOWER
     // (profiles/r03_fused_attention_oproj.txt)
     SRGPT_TRY(srgpt_decode_attention_pf(d.qkvd, kc, vc, st->pos, w->rope_cos, w->rope_sin, d.attnd, d.dws, B, Hq, Hkv, D,
-                                        st->max_pos, dt, w8 ? w->wo8[i] : w->wo[i], Hd, Hq * D, w8 ? 1 : 0, stream));
+                                        st->max_pos, dt, pk(w->wo8p, i) ? pk(w->wo8p, i) : (w8 ? w->wo8[i] : w->wo[i]), Hd, Hq * D,
+                                        w8 ? 1 : 0, stream));
     SRGPT_TRY(mv(d.attnd, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, nullptr, d.xd, d.xd, Hd,
-                 Hq * D, 0, 0, nullptr, ss_attn));
+                 Hq * D, 0, 0, nullptr, ss_attn, pk(w->wo8p, i), w->pk_rows_o));
     SRGPT_TRY(mv(d.xd, w->wgu[i], w8 ? w->wgu8[i] : nullptr, w8 ? w->wgu_scale[i] : nullptr, w->mlp_norm[i], nullptr,
-                 d.actd, I, Hd, 1, 0, ss_attn, nullptr));
+                 d.actd, I, Hd, 1, 0, ss_attn, nullptr, pk(w->wgu8p, i), w->pk_rows_gu));
     SRGPT_TRY(mv(d.actd, w->wdown[i], w8 ? w->wdown8[i] : nullptr, w8 ? w->wdown_scale[i] : nullptr, nullptr, d.xd, d.xd,
-                 Hd, I, 0, 0, nullptr, ss_mlp));
+                 Hd, I, 0, 0, nullptr, ss_mlp, pk(w->wdown8p, i), w->pk_rows_down));
   }
   SRGPT_TRY(mv(d.xd, w->lm_head, w->lm_head8, w->lm_head_scale, w->final_norm, nullptr, st->logits, w->vocab, Hd, 0, 1,
                w->layers > 0 ? ss_mlp : nullptr, nullptr));

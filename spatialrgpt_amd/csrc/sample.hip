@@ -368,4 +368,4 @@ extern "C" int srgpt_sample_status(const void* ws, int B, srgpt_stream_t stream)
   return SRGPT_OK;
 }
 
-extern "C" int srgpt_sample_slices(void) { return SMP_NB; }
+extern "C" __attribute__((visibility("hidden"))) int srgpt_sample_slices(void) { return SMP_NB; }  // cross-file helper, not exported

@@ -85,35 +85,47 @@ constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumu
 // (one wave per row, two 16-byte loads per lane), adds them in a fixed order (lane-local, then the DPP / permlane tree) -- the
 // result does not depend on which block finished first -- and goes straight to its weight stream: the statistics' loads, the first
 // activation slice and the first weight stage are all requested back to back at kernel entry, one memory latency for the three.
-template <bool SWIGLU, int NI, int NW, bool W8, bool PUB>
+// PK (round 6): the weights are read from the PACKED decode layout (srgpt_pack_decode_weights, include/srgpt.h): granules of `gr`
+// rows (4 or 16) whose bytes are stored in MFMA-operand order -- [granule][k block][g = k / 8 % 4][row in granule][16 bytes] -- so
+// that ONE coalesced 16-byte load per lane IS the B fragment of a k step (bf16: a k block = 32 k; fp8: 64 k = the fragments of two
+// k steps); a wave-instruction reads 16 / gr pieces of gr x 64 contiguous bytes and a wave walks its K range through each granule
+// sequentially.  The weights then never touch LDS: no ds_write / wave barrier / fragment ds_read per stage (the timing probe of
+// round 5 priced them at 4 - 7 % of the fp8 layer, profiles/r05_skinny_probes.txt) and a block needs LDS only for its activation
+// slices.  4-row granules keep every column split of the row-major kernel (24 q/k/v columns or 28 gate / up pairs per block);
+// 16-row granules (1 KiB contiguous per instruction) stream the single-tile products faster (profiles/r06_skinny_packed.txt).
+template <bool SWIGLU, int NI, int NW, bool W8, bool PUB, bool PK>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const bf16_t* __restrict__ x, const void* __restrict__ Wv,
                                                                           const float* __restrict__ wscale,
                                                                           const bf16_t* __restrict__ norm_w, float norm_eps,
                                                                           const bf16_t* __restrict__ residual, void* __restrict__ out,
                                                                           int B, int N, int K, int out_f32, int cw,
-                                                                          const float* __restrict__ ss_in, float* __restrict__ ss_out) {
+                                                                          const float* __restrict__ ss_in, float* __restrict__ ss_out,
+                                                                          int gr_shift) {
   constexpr int SK = 256;                   // k per wave slice
   constexpr int XROWB = WROWB;              // bytes per staged activation row
   constexpr int XL = NI;                    // activation loads per slice: 2 rows x 512 B each
-  constexpr int R = SWIGLU ? 2 : 1;
+  constexpr int R = SWIGLU ? 2 : 1;  // weight tiles (sub-units) per 16-column output tile
   constexpr int MAXU = MAXSU / R;
+  constexpr int CPT = 16;            // output columns per tile
+  constexpr int RS = R;              // weight rows (and fp8 row scales) per output
   constexpr int XSTAGEB = 2 * NI * XROWB;
   constexpr int NT = 64 * NW;
-  using WReg = typename std::conditional<W8, u32x2, u32x4>::type;  // one staged weight load per lane
+  using WReg = typename std::conditional<W8 && !PK, u32x2, u32x4>::type;  // one weight load per lane
   constexpr int WEB = W8 ? 1 : 2;                                       // bytes per weight element
-  constexpr int WEPL = 8;                                               // weight elements per lane-load
+  constexpr int WEPL = 8;                                               // weight elements per lane-load (row-major layout)
+  constexpr int NWL = PK && W8 ? 4 : 8;                                 // loads per weight stage (packed fp8: 64 k per load)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // per wave: [x stage | w stage]; reused for the reduction
   __shared__ float rs_s[16];
   __shared__ float ss_s[16][NW / 2];
   __shared__ float pub_s[NW][4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned char* xst = smem + wave * (XSTAGEB + WSTAGEB);
-  unsigned char* wst = xst + XSTAGEB;
+  unsigned char* xst = smem + wave * (XSTAGEB + (PK ? 0 : WSTAGEB));
+  unsigned char* wst = xst + XSTAGEB;  // (row-major layout only)
   const int nsl = (K + SK - 1) / SK;  // K slices; wave w takes w, w + NW, ...
   const int c0 = (int)blockIdx.x * cw;                 // first output column of this block
   const int cwb = min(cw, N - c0);                     // its column count (the last block may own fewer)
-  const int ntile = (cwb + 15) >> 4;                   // 16-column tiles, the last one possibly partial
+  const int ntile = (cwb + CPT - 1) / CPT;             // tiles, the last one possibly partial
   const int npass = (ntile + MAXU - 1) / MAXU;
   const bool do_norm = norm_w != nullptr;
   const int lrow = lane >> 5, lchunk = lane & 31;  // staging loads: lane -> (row parity, 16-byte chunk of the 512-byte row piece)
@@ -178,18 +190,40 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   for (int j = 0; j < 8; ++j) wrow_off[j] = ((unsigned)(2 * j + lrow) * (unsigned)K + (unsigned)lchunk * WEPL) * WEB;
   constexpr unsigned W_OUT_OF_RANGE = 0x10000000u;  // > any descriptor range (16 rows x K x 2 bytes), no 32-bit wrap when added
   auto issue_w = [&](WReg* w, int pass, int sl, int su, bool ok) {
-    const int cb = c0 + (pass * MAXU + su / R) * 16;  // first column of the tile
-    const unsigned char* base = reinterpret_cast<const unsigned char*>(Wv) + ((size_t)cb + (size_t)(su % R) * N) * K * WEB;
+    const int cb = c0 + (pass * MAXU + su / R) * CPT;  // first column of the tile
     const int nrow = min(c0 + cwb - cb, 16);  // valid rows of the tile (16 except in the block's last tile)
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, nrow > 0 ? nrow * K * WEB : 0, 0x00020000);
-    // slice offset; lanes whose k lies past K (last slice of a K that is no multiple of 256) leave the range too
-    const unsigned so = (ok ? (unsigned)(sl * SK) * WEB : W_OUT_OF_RANGE) + (sl * SK + lchunk * WEPL < K ? 0u : W_OUT_OF_RANGE);
+    if constexpr (PK) {
+      // granule (cb + (su % R) N) / gr of the packed array (tile starts, block widths and the stacked half's row count are multiples
+      // of gr; rows past the matrix inside its last granule are zeros in the array).  Lane (c = lane & 15, g = lane >> 4) reads row
+      // c % gr of the tile's granule c / gr: 16 bytes per k block, the k blocks of a granule gr x 64 bytes apart
+      const unsigned gstride = (unsigned)K * WEB << gr_shift;  // bytes of a granule
+      const unsigned char* base = reinterpret_cast<const unsigned char*>(Wv) + ((size_t)cb + (size_t)(su % R) * N) * K * WEB;
+      const int ngran = (nrow + (1 << gr_shift) - 1) >> gr_shift;
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, nrow > 0 ? ngran * (int)gstride : 0, 0x00020000);
+      constexpr int KBLK = W8 ? 64 : 32;  // k per load
+      const unsigned c = lane & 15, g = lane >> 4, kbs = 64u << gr_shift;  // bytes of a (granule, k block)
+      const unsigned lane_off = (c >> gr_shift) * gstride + ((g << gr_shift) + (c & ((1u << gr_shift) - 1))) * 16u;
+      const unsigned so = ok ? lane_off + (unsigned)(sl * (SK / KBLK)) * kbs : W_OUT_OF_RANGE;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if constexpr (W8) w[j] = __builtin_bit_cast(WReg, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(wrow_off[j] + so), 0, 2));
-      else w[j] = __builtin_bit_cast(WReg, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(wrow_off[j] + so), 0, 2));  // aux 2 = nt
-      __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < NWL; ++j) {
+        // k blocks past K (last slice of a K that is no multiple of 256) leave the range
+        const unsigned oj = sl * SK + j * KBLK < K ? so + j * kbs : W_OUT_OF_RANGE;
+        w[j] = __builtin_bit_cast(WReg, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)oj, 0, 2));  // aux 2 = nt
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      const unsigned char* base = reinterpret_cast<const unsigned char*>(Wv) + ((size_t)cb + (size_t)(su % R) * N) * K * WEB;
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, nrow > 0 ? nrow * K * WEB : 0, 0x00020000);
+      // slice offset; lanes whose k lies past K (last slice of a K that is no multiple of 256) leave the range too
+      const unsigned so = (ok ? (unsigned)(sl * SK) * WEB : W_OUT_OF_RANGE) + (sl * SK + lchunk * WEPL < K ? 0u : W_OUT_OF_RANGE);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (W8) w[j] = __builtin_bit_cast(WReg, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(wrow_off[j] + so), 0, 2));
+        else w[j] = __builtin_bit_cast(WReg, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(wrow_off[j] + so), 0, 2));  // aux 2 = nt
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
   // 8 fp8 -> 8 bf16 (every e4m3 value is exactly representable in bf16)
@@ -206,10 +240,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     }
     return o;
   };
-  // what a staged weight load leaves in LDS: bf16
+  // what a staged weight load leaves in LDS: bf16 (row-major layout)
   auto staged = [&](const WReg& r) -> u32x4 {
-    if constexpr (W8) return widen(r);
+    if constexpr (W8 && !PK) return widen(r);
     else return r;
+  };
+  // packed layout: the B fragment of k step s of a stage, straight from the stage's registers
+  auto pk_frag = [&](const WReg* w, int s) -> bf16x8 {
+    if constexpr (!PK) return bf16x8{};
+    else if constexpr (W8) return __builtin_bit_cast(bf16x8, widen(u32x2{w[s >> 1][2 * (s & 1)], w[s >> 1][2 * (s & 1) + 1]}));
+    else return __builtin_bit_cast(bf16x8, w[s]);
   };
 
   // A wave's K slices are ONE contiguous range of the rows (round 3): interleaved over the waves (wave, wave + NW, ...: the first
@@ -335,7 +375,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     for (int su = 0; su < (TWO_ACC ? NSU : 1); ++su) acc2[su] = f32x4{0.f, 0.f, 0.f, 0.f};
     // register ring of DEPTH weight stages with static slot indices (a trip = DEPTH slices x NSU stages, a multiple of
     // DEPTH): the loads of stage t+DEPTH-1 are issued before stage t is multiplied.  A stage is 8 KiB per wave (fp8: 4 KiB).
-    WReg wb[DEPTH][8];
+    WReg wb[DEPTH][NWL];
     // epilogue operands that do not depend on the products -- row scales (W8) and residual elements -- are requested up front
     // (fetched at their use they would each add a memory round trip after the last barrier of the pass), but BEHIND the first
     // weight stages and without touching their values: round 4's form, `residual ? (float)residual[i] : 0` in front of the first
@@ -343,7 +383,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     // through up to four serialised memory round trips (2.7k cycles, profiles/r05_skinny_stamps.txt) before asking for a weight
     constexpr int EIT0 = ((NSU / R) * 256 + NT - 1) / NT;  // epilogue iterations per thread
     constexpr int EIT = EIT0 > 0 ? EIT0 : 1;               // (odd NSU never occurs with SwiGLU; keep the type valid)
-    float pre_sc[EIT][R];
+    float pre_sc[EIT][RS];
     unsigned short pre_res[EIT];  // bf16 bits
     auto load_epilogue_operands = [&]() {
       const bool has_res = !SWIGLU && residual != nullptr;
@@ -353,9 +393,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
         const int e = tid + i * NT;
         const int u = e >> 8, l2 = e & 63, q = (e >> 6) & 3;
         const int b = min(4 * (l2 >> 4) + q, B - 1);
-        const int n = min(c0 + (pass * MAXU + u) * 16 + (l2 & 15), c0 + cwb - 1);
+        const int n = min(c0 + (pass * MAXU + u) * CPT + (l2 & (CPT - 1)), c0 + cwb - 1);
 #pragma unroll
-        for (int r = 0; r < R; ++r) pre_sc[i][r] = W8 ? wscale[n + r * N] : 1.f;
+        for (int r = 0; r < RS; ++r) pre_sc[i][r] = W8 ? wscale[n + r * N] : 1.f;
         pre_res[i] = *reinterpret_cast<const unsigned short*>(rp + (has_res ? (size_t)b * N + n : (size_t)0));
       }
     };
@@ -391,8 +431,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
               else load_x(std::integral_constant<int, h % XS>{}, sl_of(min(i + h + XS, cnt - 1)));  // XS slices ahead (past the end: a valid slice, never staged)
             }
 #if !(defined(SRGPT_SKINNY_PROBE) && SRGPT_SKINNY_PROBE == 2)
+            if constexpr (!PK) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(wst + (2 * j + lrow) * WROWB + lchunk * 16) = staged(wb[cur][j]);
+              for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(wst + (2 * j + lrow) * WROWB + lchunk * 16) = staged(wb[cur][j]);
+            }
 #endif
             __builtin_amdgcn_wave_barrier();
             // The fragment reads of FS k steps are issued together in front of their MFMAs, which alternate between two
@@ -418,7 +460,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
 #if defined(SRGPT_SKINNY_PROBE) && SRGPT_SKINNY_PROBE == 2  // timing probe (WRONG results): weights never pass through LDS
                 wfr[t] = __builtin_bit_cast(bf16x8, staged(wb[cur][s & 7]));
 #else
-                wfr[t] = *reinterpret_cast<const bf16x8*>(wst + (lane & 15) * WROWB + (4 * s + (lane >> 4)) * 16);
+                if constexpr (PK) wfr[t] = pk_frag(wb[cur], s);
+                else wfr[t] = *reinterpret_cast<const bf16x8*>(wst + (lane & 15) * WROWB + (4 * s + (lane >> 4)) * 16);
 #endif
               }
               __builtin_amdgcn_sched_barrier(0);
@@ -471,10 +514,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
       if (e >= (NSU / R) * 256) break;
       const int u = e >> 8, l2 = e & 63, q = (e >> 6) & 3;
       const int b = 4 * (l2 >> 4) + q;
-      const int n = c0 + (pass * MAXU + u) * 16 + (l2 & 15);
-      float a[R];
+      const int n = c0 + (pass * MAXU + u) * CPT + (l2 & 15);
+      float a[RS];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
+      for (int r = 0; r < RS; ++r) {
         float t = 0.f;
 #pragma unroll
         for (int wv = 0; wv < NW; ++wv) t += redf[((wv * MAXSU + u * R + r) * 64 + l2) * 4 + q];
@@ -483,7 +526,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
       }
       if (b < B && n < c0 + cwb) {
         if (SWIGLU) {
-          const float g = rnd<bf16_t>(a[0]), up = rnd<bf16_t>(a[R - 1]);
+          const float g = rnd<bf16_t>(a[0]), up = rnd<bf16_t>(a[RS - 1]);
           reinterpret_cast<bf16_t*>(out)[(size_t)b * N + n] = (bf16_t)(rnd<bf16_t>(silu(g)) * up);
         } else {
           float v = rnd<bf16_t>(a[0]);
@@ -538,26 +581,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
   }
 }
 
-template <bool SWIGLU, int NI, int NW, bool W8, bool PUB>
+template <bool SWIGLU, int NI, int NW, bool W8, bool PUB, bool PK>
 int launch_skinny(const void* x, const void* W, const float* wscale, const void* norm_w, float eps, const void* residual,
                   void* out, int batch, int N, int K, int out_f32, int grid, int cw, const float* ss_in, float* ss_out,
-                  hipStream_t s) {
-  constexpr int lds = NW * (2 * NI * WROWB + WSTAGEB);
-  static_assert(lds >= NW * MAXSU * 64 * 4 * 4, "reduction buffer must fit");
+                  int gr_shift, hipStream_t s) {
+  constexpr int lds_k = NW * (2 * NI * WROWB + (PK ? 0 : WSTAGEB)), lds_r = NW * MAXSU * 64 * 4 * 4;  // K loop stages | reduction buffer
+  constexpr int lds = lds_k > lds_r ? lds_k : lds_r;
   static_assert(lds <= 160 * 1024, "LDS");
   static_assert(NW == 8 || 2 * lds <= 160 * 1024, "two 4-wave blocks per CU");
-  auto kfn = skinny_kernel<SWIGLU, NI, NW, W8, PUB>;
+  auto kfn = skinny_kernel<SWIGLU, NI, NW, W8, PUB, PK>;
   static std::atomic<uint64_t> attr_done{0};
   SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)kfn, lds));
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * NW), lds, s, (const bf16_t*)x, W, wscale, (const bf16_t*)norm_w, eps,
-                     (const bf16_t*)residual, out, batch, N, K, out_f32, cw, ss_in, ss_out);
+                     (const bf16_t*)residual, out, batch, N, K, out_f32, cw, ss_in, ss_out, gr_shift);
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;
 }
 
 template <bool SWIGLU, int NI, bool W8>
 int launch_skinny_nw(const void* x, const void* W, const float* wscale, const void* norm_w, float eps, const void* residual,
-                     void* out, int batch, int N, int K, int out_f32, const float* ss_in, float* ss_out, hipStream_t s) {
+                     void* out, int batch, int N, int K, int out_f32, const float* ss_in, float* ss_out, int packed, hipStream_t s) {
   // Two 4-wave blocks per CU, or one 8-wave block per CU; both split the columns evenly over their blocks.  Measured per decode
   // step (profiles/r02_skinny_ab.txt): 4-wave blocks win (o_proj 8.8 vs 9.7 us, fp8 gate/up 27.4 vs 30.4) except where a block
   // would own few columns AND has the RMSNorm statistics to compute first (q/k/v: 24 columns per CU, 14.1 vs 14.3 us bf16,
@@ -572,35 +615,54 @@ int launch_skinny_nw(const void* x, const void* W, const float* wscale, const vo
   const int blocks = waves == 8 ? cus : 2 * cus;
   int cw = (N + blocks - 1) / blocks;
   if (cw < 16) cw = 16;
+  const int gr_shift = packed == 16 ? 4 : packed == 8 ? 3 : 2;
+  if (packed) cw = ((cw + packed - 1) / packed) * packed;  // whole granules
   const int grid = (N + cw - 1) / cw;
   SRGPT_CHECK(!ss_out || grid <= SRGPT_ROWSS_STRIDE, SRGPT_ERR_UNSUPPORTED, "skinny: %d blocks do not fit the %d row-statistics slots",
               grid, SRGPT_ROWSS_STRIDE);
-#define SRGPT_SKINNY_GO(NWV, PUBV) \
-  return launch_skinny<SWIGLU, NI, NWV, W8, PUBV>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, grid, cw, ss_in, ss_out, s)
-  if (ss_in != nullptr) {
-    if (waves == 8) SRGPT_SKINNY_GO(8, true);
-    SRGPT_SKINNY_GO(4, true);
+#define SRGPT_SKINNY_GO(NWV, PUBV, PKV) \
+  return launch_skinny<SWIGLU, NI, NWV, W8, PUBV, PKV>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, grid, cw, ss_in, ss_out, gr_shift, s)
+  if (packed) {
+    SRGPT_CHECK(K % (W8 ? 64 : 32) == 0 && (!SWIGLU || N % packed == 0), SRGPT_ERR_UNSUPPORTED,
+                "skinny: the packed weight layout needs K %% %d == 0 (K = %d)%s", W8 ? 64 : 32, K, SWIGLU ? " and whole granules per half" : "");
+    if (ss_in != nullptr) {
+      if (waves == 8) SRGPT_SKINNY_GO(8, true, true);
+      SRGPT_SKINNY_GO(4, true, true);
+    }
+    if (waves == 8) SRGPT_SKINNY_GO(8, false, true);
+    SRGPT_SKINNY_GO(4, false, true);
   }
-  if (waves == 8) SRGPT_SKINNY_GO(8, false);
-  SRGPT_SKINNY_GO(4, false);
+  if (ss_in != nullptr) {
+    if (waves == 8) SRGPT_SKINNY_GO(8, true, false);
+    SRGPT_SKINNY_GO(4, true, false);
+  }
+  if (waves == 8) SRGPT_SKINNY_GO(8, false, false);
+  SRGPT_SKINNY_GO(4, false, false);
 #undef SRGPT_SKINNY_GO
 }
 
 template <bool W8>
 int skinny_dispatch(const void* x, const void* W, const float* wscale, const void* norm_w, float eps, const void* residual,
-                    void* out, int batch, int N, int K, int swiglu, int out_f32, const float* ss_in, float* ss_out, hipStream_t s) {
+                    void* out, int batch, int N, int K, int swiglu, int out_f32, const float* ss_in, float* ss_out, int packed,
+                    hipStream_t s) {
+  // packed: 0 = row-major W [N][K]; 4 / 16 = the packed decode layout with granules of that many rows (srgpt_pack_decode_weights)
+  if (SRGPT_KNOB("SRGPT_SKINNY_PACKED_TIMING", 0)) {  // tuning build: fetch-pattern timing on row-major data (WRONG results)
+    const int ncol = (N + srgpt_device_cus() - 1) / srgpt_device_cus();
+    packed = ncol <= 16 ? SRGPT_KNOB("SRGPT_SKINNY_PACKED_T1", 16) : SRGPT_KNOB("SRGPT_SKINNY_PACKED_TN", 4);
+  }
+  SRGPT_CHECK(packed == 0 || packed == 4 || packed == 8 || packed == 16, SRGPT_ERR_ARG, "skinny: packed layout granule %d (0, 4, 8 or 16)", packed);
   SRGPT_CHECK(batch >= 1 && batch <= 16, SRGPT_ERR_ARG, "skinny: batch %d outside 1..16", batch);
   SRGPT_CHECK(K % 8 == 0 && K >= 8, SRGPT_ERR_ARG, "skinny: K=%d must be a multiple of 8", K);
   SRGPT_CHECK(!ss_in || norm_w, SRGPT_ERR_ARG, "skinny: published row statistics are the RMSNorm's input (norm_w is NULL)");
   SRGPT_CHECK(!ss_out || (!swiglu && !out_f32), SRGPT_ERR_ARG, "skinny: row statistics are published for plain bf16 outputs only");
   if (batch <= 4)
-    return swiglu ? launch_skinny_nw<true, 2, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, nullptr, s)
-                  : launch_skinny_nw<false, 2, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, ss_out, s);
+    return swiglu ? launch_skinny_nw<true, 2, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, nullptr, packed, s)
+                  : launch_skinny_nw<false, 2, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, ss_out, packed, s);
   if (batch <= 8)
-    return swiglu ? launch_skinny_nw<true, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, nullptr, s)
-                  : launch_skinny_nw<false, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, ss_out, s);
-  return swiglu ? launch_skinny_nw<true, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, nullptr, s)
-                : launch_skinny_nw<false, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, ss_out, s);
+    return swiglu ? launch_skinny_nw<true, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, nullptr, packed, s)
+                  : launch_skinny_nw<false, 4, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, ss_out, packed, s);
+  return swiglu ? launch_skinny_nw<true, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, nullptr, packed, s)
+                : launch_skinny_nw<false, 8, W8>(x, W, wscale, norm_w, eps, residual, out, batch, N, K, out_f32, ss_in, ss_out, packed, s);
 }
 
 }  // namespace
@@ -613,14 +675,14 @@ extern "C" int srgpt_skinny_debug_stamps(unsigned long long* host, int n) {
 
 // host entry used by srgpt_gemv (gemv.hip) for batches of up to 16 rows, bf16 weights
 int srgpt_skinny_launch(const void* x, const void* W, const void* norm_w, float eps, const void* residual, void* out,
-                        int batch, int N, int K, int swiglu, int out_f32, const float* ss_in, float* ss_out, hipStream_t s) {
-  return skinny_dispatch<false>(x, W, nullptr, norm_w, eps, residual, out, batch, N, K, swiglu, out_f32, ss_in, ss_out, s);
+                        int batch, int N, int K, int swiglu, int out_f32, const float* ss_in, float* ss_out, int packed, hipStream_t s) {
+  return skinny_dispatch<false>(x, W, nullptr, norm_w, eps, residual, out, batch, N, K, swiglu, out_f32, ss_in, ss_out, packed, s);
 }
 
 // fp8 weights, any batch size (16 rows per weight pass); ss_in / ss_out: the rows' statistics tables (see skinny_kernel)
 int srgpt_skinny_w8_launch(const void* x, const void* W8, const float* wscale, const void* norm_w, float norm_eps,
                            const void* residual, void* out, int batch, int N, int K, int swiglu, int out_f32,
-                           const float* ss_in, float* ss_out, hipStream_t s) {
+                           const float* ss_in, float* ss_out, int packed, hipStream_t s) {
   const size_t on = out_f32 ? sizeof(float) : 2;
   for (int b0 = 0; b0 < batch; b0 += 16) {
     const int nb = batch - b0 < 16 ? batch - b0 : 16;
@@ -628,7 +690,7 @@ int srgpt_skinny_w8_launch(const void* x, const void* W8, const float* wscale, c
                                     residual ? (const char*)residual + (size_t)b0 * N * 2 : nullptr,
                                     (char*)out + (size_t)b0 * N * on, nb, N, K, swiglu, out_f32,
                                     ss_in ? ss_in + (size_t)b0 * SRGPT_ROWSS_STRIDE : nullptr,
-                                    ss_out ? ss_out + (size_t)b0 * SRGPT_ROWSS_STRIDE : nullptr, s));
+                                    ss_out ? ss_out + (size_t)b0 * SRGPT_ROWSS_STRIDE : nullptr, packed, s));
   }
   return SRGPT_OK;
 }
@@ -650,5 +712,50 @@ extern "C" int srgpt_gemv_w8(const void* x, const void* W8, const float* wscale,
   const int valu_max = srgpt_w8_valu_max_batch();
   if (batch <= valu_max && batch <= 2 && K % 16 == 0)  // one row: VALU kernel (gemv_w8.hip), like the bf16 path
     return srgpt_gemv_w8_valu(x, W8, wscale, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, s);
-  return srgpt_skinny_w8_launch(x, W8, wscale, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, nullptr, nullptr, s);
+  return srgpt_skinny_w8_launch(x, W8, wscale, norm_w, norm_eps, residual, out, batch, N, K, swiglu, out_f32, nullptr, nullptr, 0, s);
+}
+
+// ---- the packed decode layout (include/srgpt.h, ABI 9) ----
+namespace {
+// one thread per 16 output bytes: (granule, k block, g, row in granule)
+__global__ __launch_bounds__(256) void pack_decode_kernel(const unsigned char* __restrict__ W, unsigned char* __restrict__ out, int N, int K,
+                                                          int eb, int rows, long long n16) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n16) return;
+  const int kblock = 32 * (2 / eb);           // k per 16-byte lane load: 64 (fp8) / 32 (bf16)
+  const int nkb = K / kblock;
+  const int r = (int)(i % rows), g = (int)(i / rows % 4);
+  const long long t = i / (4 * rows);
+  const int kb = (int)(t % nkb);
+  const long long n = t / nkb * rows + r;
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (n < N) {
+    const unsigned char* src = W + ((size_t)n * K + (size_t)kb * kblock + 8 * g) * eb;
+    if (eb == 2) {
+      v = *reinterpret_cast<const u32x4*>(src);                                    // 8 bf16: k = 32 kb + 8 g .. + 8
+    } else {
+      const u32x2 lo = *reinterpret_cast<const u32x2*>(src), hi = *reinterpret_cast<const u32x2*>(src + 32);  // k = 64 kb (+ 32) + 8 g .. + 8
+      v = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+  }
+  *reinterpret_cast<u32x4*>(out + (size_t)i * 16) = v;
+}
+}  // namespace
+
+extern "C" size_t srgpt_packed_bytes(int N, int K, int elem_bytes, int rows) {
+  if (N <= 0 || K <= 0 || rows <= 0 || (elem_bytes != 1 && elem_bytes != 2)) return 0;
+  return (size_t)((N + rows - 1) / rows) * rows * K * elem_bytes;
+}
+
+extern "C" int srgpt_pack_decode_weights(const void* W, void* out, int N, int K, int elem_bytes, int rows, srgpt_stream_t stream) {
+  SRGPT_CHECK(W && out, SRGPT_ERR_ARG, "srgpt_pack_decode_weights: null pointer");
+  SRGPT_CHECK(elem_bytes == 1 || elem_bytes == 2, SRGPT_ERR_ARG, "srgpt_pack_decode_weights: %d bytes per element (1: fp8, 2: bf16)", elem_bytes);
+  SRGPT_CHECK(rows == 4 || rows == 8 || rows == 16, SRGPT_ERR_ARG, "srgpt_pack_decode_weights: %d rows per granule (4, 8 or 16)", rows);
+  SRGPT_CHECK(N > 0 && K > 0 && K % (elem_bytes == 1 ? 64 : 32) == 0, SRGPT_ERR_ARG,
+              "srgpt_pack_decode_weights: K=%d must be a positive multiple of %d", K, elem_bytes == 1 ? 64 : 32);
+  const long long n16 = (long long)(srgpt_packed_bytes(N, K, elem_bytes, rows) / 16);
+  hipLaunchKernelGGL(pack_decode_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, as_stream(stream), (const unsigned char*)W,
+                     (unsigned char*)out, N, K, elem_bytes, rows, n16);
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
 }

@@ -95,7 +95,8 @@ class SplicePlan:
 
 class SrgptEngine:
     def __init__(self, cfg: SrgptConfig, state_dict: Dict[str, torch.Tensor], device="cuda", dtype=torch.bfloat16,
-                 rope_positions: int = 0, consume_state_dict: bool = False, llm_weight_format: str = "native", parts=None):
+                 rope_positions: int = 0, consume_state_dict: bool = False, llm_weight_format: str = "native", parts=None,
+                 decode_layout: str = "packed"):
         L.load()  # fail loudly if the HIP extension is missing
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         if self.device.type != "cuda":
@@ -106,8 +107,9 @@ class SrgptEngine:
             raise NotImplementedError(f"{cfg.region_extractor_type} not implemented")  # base_extractor.py:160-161
         if cfg.select_feature not in ("cls_patch", "patch"):
             raise ValueError(f"Unexpected select feature: {cfg.select_feature}")
+        # decode_layout "packed": fp8 LLM weights also get MFMA-operand-order copies for the batched decode step (weights.py)
         self.w = PreparedWeights(cfg, state_dict, self.device, dtype, rope_positions, consume=consume_state_dict,
-                                 llm_weight_format=llm_weight_format, parts=parts)
+                                 llm_weight_format=llm_weight_format, parts=parts, decode_layout=decode_layout)
         self._state: Optional[DecodeState] = None
         self._vit_ws: Optional[torch.Tensor] = None
         self.use_graph = True

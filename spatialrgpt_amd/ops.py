@@ -147,18 +147,40 @@ def gemv_rowss_supported(batch: int, fp8: bool = False) -> bool:
     return bool(L.load().srgpt_gemv_rowss_supported(int(batch), L.BF16, int(fp8)))
 
 
+def pack_decode_weights(w, rows: int):
+    """srgpt_pack_decode_weights: the packed decode layout (granules of `rows` = 4 / 8 / 16 weight rows in MFMA-operand order,
+    include/srgpt.h ABI 9) of a row-major matrix [N, K] (uint8 = fp8 bytes, or bf16).  Returns a flat uint8 tensor; a SwiGLU matrix
+    [gate; up] is packed as the one matrix of 2 N rows it is."""
+    _dev(w)
+    if w.dim() != 2 or not w.is_contiguous() or w.dtype not in (torch.uint8, torch.bfloat16):
+        raise ValueError("pack_decode_weights: a contiguous uint8 (fp8) or bf16 matrix")
+    N, K = w.shape
+    eb = w.element_size()
+    lib = L.load()
+    out = torch.empty((int(lib.srgpt_packed_bytes(N, K, eb, int(rows))),), device=w.device, dtype=torch.uint8)
+    L.check(lib.srgpt_pack_decode_weights(_p(w), _p(out), N, K, eb, int(rows), _stream()))
+    return out
+
+
 def gemv_rowss(x, w=None, w8=None, wscale=None, norm_w=None, eps=0.0, residual=None, swiglu=False, out=None, out_f32=False,
-               rowss_in=None, publish=False):
+               rowss_in=None, publish=False, packed_rows=0, n_rows=None):
     """srgpt_gemv_rowss: the decode product of 2+ bf16 rows as the batched decode step runs it.  `rowss_in`: the statistics
     table of x's rows ([B, 512] fp32, from the call that produced x) replaces the RMSNorm's own reduction; `publish`: also
-    return the table of the output rows.  Returns out, or (out, table)."""
+    return the table of the output rows.  `packed_rows` > 0: w / w8 is the flat packed array of pack_decode_weights (n_rows = the
+    matrix' row count, 2 N for SwiGLU).  Returns out, or (out, table)."""
     wt = w8 if w8 is not None else w
     _dev(x, wt, wscale, norm_w, residual, rowss_in)
     _same_dtype("gemv_rowss", x, norm_weight=norm_w, residual=residual)
     if x.dtype != torch.bfloat16:
         raise ValueError("gemv_rowss: bf16 activations only")
     B, K = x.shape
-    N = wt.shape[0] // 2 if swiglu else wt.shape[0]
+    if packed_rows:
+        if n_rows is None:
+            raise ValueError("gemv_rowss: a packed matrix needs n_rows")
+        rows_total = int(n_rows)
+    else:
+        rows_total = wt.shape[0]
+    N = rows_total // 2 if swiglu else rows_total
     if out is None:
         out = torch.empty((B, N), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
     table = torch.empty((B, L.ROWSS_STRIDE), device=x.device, dtype=torch.float32) if publish else None
@@ -166,7 +188,8 @@ def gemv_rowss(x, w=None, w8=None, wscale=None, norm_w=None, eps=0.0, residual=N
                                  or not rowss_in.is_contiguous()):
         raise ValueError("gemv_rowss: rowss_in must be a contiguous fp32 [batch, 512] table")
     L.check(L.load().srgpt_gemv_rowss(_p(_c(x)), _p(w) if w8 is None else None, _p(w8), _p(wscale), _p(norm_w), float(eps),
-                                      _p(residual), _p(out), B, N, K, int(swiglu), int(out_f32), _p(rowss_in), _p(table), _stream()))
+                                      _p(residual), _p(out), B, N, K, int(swiglu), int(out_f32), _p(rowss_in), _p(table),
+                                      int(packed_rows), _stream()))
     return (out, table) if publish else out
 
 

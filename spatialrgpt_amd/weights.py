@@ -51,7 +51,7 @@ class PreparedWeights:
     ALL_PARTS = ("vit", "region", "projector", "llm")
 
     def __init__(self, cfg: SrgptConfig, sd: Dict[str, torch.Tensor], device, dtype, rope_positions: int = 0,
-                 consume: bool = False, llm_weight_format: str = "native", parts=None):
+                 consume: bool = False, llm_weight_format: str = "native", parts=None, decode_layout: str = "packed"):
         """llm_weight_format: "native" (the engine dtype) or "fp8" -- weight-only OCP e4m3fn quantisation of the five
         streamed LLM matrices with one fp32 (power-of-two) scale per output row (BASELINE config 5; bf16 engines only).  The
         fp8 bytes are the ONLY copy of those matrices in HBM: decode streams them (srgpt_gemv_w8), prefill multiplies them
@@ -79,6 +79,9 @@ class PreparedWeights:
         if llm_weight_format == "fp8" and dtype != torch.bfloat16:
             raise ValueError("fp8 LLM weights need a bf16 engine")
         self.llm_weight_format = llm_weight_format
+        if decode_layout not in ("packed", "rowmajor"):
+            raise ValueError(f"unknown decode_layout {decode_layout!r}")
+        self.decode_layout = decode_layout  # fp8 weights: also keep the MFMA-operand-order copies the batched decode step streams
         self._keep: List[object] = []
         code = {torch.float32: L.F32, torch.bfloat16: L.BF16}[dtype]
 
@@ -200,6 +203,21 @@ class PreparedWeights:
             self.lm_head8, self.lm_head_scale, _ = ops.quantize_fp8_rows(self.lm_head)
             self.lm_head = None
             self.llm_q = qd
+            # Packed copies for the batched decode step (2+ sequences per GPU; srgpt_pack_decode_weights, include/srgpt.h ABI 9): the
+            # same fp8 bytes in MFMA-operand order.  The row-major copies stay: prefill (srgpt_gemm_w8 / _w8a8) and the one-row
+            # decode kernel read those -- +6.5 GB of the 288 for an 8B model.  Granule rows per matrix from the measured table
+            # (profiles/r06_skinny_packed.txt): 16 (1 KiB per instruction) where a CU owns a single 16-column tile, else 4.
+            self.llm_pk, self.pk_rows = {}, {}
+            if self.decode_layout == "packed":
+                n_cu = int(L.load().srgpt_device_cus())
+                for k in qd:
+                    rows_total, K = qd[k][0][0].shape
+                    n_out = rows_total // 2 if k == "wgu" else rows_total
+                    rows = 16 if (n_out + n_cu - 1) // n_cu <= 16 else 4
+                    if K % 64 or n_out % rows:
+                        continue  # (tiny test geometries: this product streams the row-major copy)
+                    self.llm_pk[k] = [ops.pack_decode_weights(q8, rows) for q8 in qd[k][0]]
+                    self.pk_rows[k] = rows
         n_pos = rope_positions or cfg.max_position_embeddings
         self.rope_len = n_pos
         self.rope_cos, self.rope_sin = rope_tables(cfg, n_pos, dtype, self.device)
@@ -220,6 +238,12 @@ class PreparedWeights:
                 self._keep += [a8, asc]
                 setattr(lw, k + "8", a8)
                 setattr(lw, k + "_scale", asc)
+            for k, field in (("wqkv", "pk_rows_qkv"), ("wo", "pk_rows_o"), ("wgu", "pk_rows_gu"), ("wdown", "pk_rows_down")):
+                if k in self.llm_pk:
+                    ap = _ptr_array(self.llm_pk[k])
+                    self._keep.append(ap)
+                    setattr(lw, k + "8p", ap)
+                    setattr(lw, field, self.pk_rows[k])
         lw.fp8_act = 1 if self.fp8_act else 0
         self.llm = lw
         self.vocab = self.embed.shape[0]

@@ -24,12 +24,12 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/srgpt.h but not exported"
     assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.srgpt_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.srgpt_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_product_library_exports_nothing_but_the_header():
-    """The product library carries no experiment residue: every exported `srgpt_*` C symbol is declared in include/srgpt.h (one
-    internal cross-file helper apart), and nothing of the tuning build (debug stamps, environment knobs, the VALU pooling kernel's
+    """The product library carries no experiment residue: every exported `srgpt_*` C symbol is declared in include/srgpt.h (cross-file
+    helpers have hidden visibility), and nothing of the tuning build (debug stamps, environment knobs, the VALU pooling kernel's
     bf16 instances) is in it."""
     import subprocess
 
@@ -37,9 +37,10 @@ def test_product_library_exports_nothing_but_the_header():
 
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("srgpt_")}
-    assert exported - set(_declared()) <= {"srgpt_sample_slices"}, exported - set(_declared())
+    assert exported == set(_declared()), exported ^ set(_declared())
     blob = open(_lib.LIB_PATH, "rb").read()
-    for residue in (b"debug_stamps", b"SRGPT_GEMM_", b"SRGPT_REGION_", b"SRGPT_DECODE_", b"region_pool_kernelIDF16b"):
+    for residue in (b"debug_stamps", b"SRGPT_GEMM_", b"SRGPT_REGION_", b"SRGPT_DECODE_", b"SRGPT_SKINNY_", b"SRGPT_GEMV_",
+                    b"region_pool_kernelIDF16b"):
         assert residue not in blob, residue
 
 
@@ -93,10 +94,18 @@ def test_argument_validation_without_gpu():
     rc = lib.srgpt_gemv_w8(16, 16, None, None, 0.0, None, 16, 1, 8, 8, 0, 0, None)  # missing row scales
     assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
     # ABI 8: the row-statistics products validate before they ask the device anything
-    rc = lib.srgpt_gemv_rowss(16, None, None, None, None, 0.0, None, 16, 4, 8, 8, 0, 0, None, None, None)  # neither bf16 nor fp8 weights
+    rc = lib.srgpt_gemv_rowss(16, None, None, None, None, 0.0, None, 16, 4, 8, 8, 0, 0, None, None, 0, None)  # neither bf16 nor fp8 weights
     assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
-    rc = lib.srgpt_gemv_rowss(16, None, 16, None, None, 0.0, None, 16, 4, 8, 8, 0, 0, None, None, None)  # fp8 bytes without row scales
+    rc = lib.srgpt_gemv_rowss(16, None, 16, None, None, 0.0, None, 16, 4, 8, 8, 0, 0, None, None, 0, None)  # fp8 bytes without row scales
     assert rc == _lib.ERR_ARG and b"row scales" in lib.srgpt_last_error()
+    # ABI 9: the packed decode layout
+    rc = lib.srgpt_gemv_rowss(16, None, 16, 16, None, 0.0, None, 16, 4, 8, 8, 0, 0, None, None, 5, None)  # 5 rows per granule
+    assert rc == _lib.ERR_ARG and b"packed_rows" in lib.srgpt_last_error()
+    rc = lib.srgpt_gemv_rowss(16, None, 16, 16, None, 0.0, None, 16, 4, 16, 96, 0, 0, None, None, 4, None)  # fp8: K % 64
+    assert rc == _lib.ERR_ARG and b"packed layout" in lib.srgpt_last_error()
+    assert lib.srgpt_packed_bytes(50, 128, 1, 16) == 64 * 128 and lib.srgpt_packed_bytes(50, 128, 2, 4) == 52 * 128 * 2
+    rc = lib.srgpt_pack_decode_weights(16, 16, 16, 48, 1, 4, None)  # fp8: K % 64
+    assert rc == _lib.ERR_ARG and b"multiple of 64" in lib.srgpt_last_error()
     assert lib.srgpt_decode_attn_ws_floats(1, 32, 128) == 32 * 64 * 130 + 32  # split partials + arrival tickets
     rc = lib.srgpt_gemm_w8(16, 16, None, None, None, 16, 4, 4, 64, 64, 4, 0, 0, None, 0, None)  # missing row scales
     assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()

@@ -427,6 +427,92 @@ def test_gemv_rowss_rejects_what_it_cannot_do():
         ops.gemv_rowss(x4, w=w2, swiglu=True, publish=True)
 
 
+# ------------------------------------------------------------------------------------------------ packed decode layout (ABI 9)
+def packed_layout_reference(w: torch.Tensor, rows: int) -> torch.Tensor:
+    """include/srgpt.h (ABI 9), restated with index arithmetic on the host: out[((n / rows) (K / kblock) + k / kblock) rows 64
+    + ((k % 32) / 8 rows + n % rows) 16 + byte], zeros for the rows that pad N to whole granules."""
+    eb = w.element_size()
+    N, K = w.shape
+    kblock = 64 if eb == 1 else 32
+    Np = (N + rows - 1) // rows * rows
+    src = torch.zeros((Np, K * eb), dtype=torch.uint8)
+    src[:N] = w.contiguous().view(torch.uint8).reshape(N, K * eb)
+    n = torch.arange(Np)[:, None]
+    k = torch.arange(K)[None, :]
+    byte = (k % 8) * 2 if eb == 2 else ((k % 64) // 32) * 8 + k % 8
+    off = ((n // rows) * (K // kblock) + k // kblock) * rows * 64 + ((k % 32) // 8 * rows + n % rows) * 16 + byte
+    out = torch.zeros((Np * K * eb,), dtype=torch.uint8)
+    srcv = src.reshape(Np, K, eb)
+    for j in range(eb):
+        out[(off + j).reshape(-1)] = srcv[:, :, j].reshape(-1)
+    return out
+
+
+@pytest.mark.parametrize("rows", [4, 8, 16])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_pack_decode_weights_is_the_documented_permutation(rows, fp8):
+    ops, L = _ops()
+    for N, K in ((48, 128), (50, 192), (7, 64), (160, 320)):
+        w = _rand((N, K), torch.bfloat16, 3 + N)
+        if fp8:
+            w = torch.randint(0, 256, (N, K), dtype=torch.uint8, generator=torch.Generator().manual_seed(N))
+        got = ops.pack_decode_weights(w.to(DEV), rows).cpu()
+        ref = packed_layout_reference(w, rows)
+        assert got.numel() == ref.numel() == (N + rows - 1) // rows * rows * K * w.element_size()
+        assert torch.equal(got, ref), (N, K, rows, fp8)
+    with pytest.raises(ValueError):  # K must be whole k blocks
+        ops.pack_decode_weights(torch.zeros((16, 48), dtype=torch.uint8, device=DEV), rows)
+
+
+@pytest.mark.parametrize("fp8", [True, False])
+@pytest.mark.parametrize("B,N,K,N2,rows", [(8, 4096, 4096, 6144, 16), (8, 4096, 14336, 28672 // 2, 4), (2, 4096, 4096, 6144, 4),
+                                           (4, 2560, 6912, 1000, 8), (16, 4096, 4096, 336, 16), (5, 1024, 1024, 128, 4),
+                                           (20, 576, 320, 80, 16), (3, 4160, 512, 48, 8)])
+def test_gemv_rowss_packed_equals_row_major_bit_for_bit(fp8, B, N, K, N2, rows):
+    """The packed decode layout changes where the kernel finds its operands, not what it multiplies: every product of
+    srgpt_gemv_rowss -- residual + published statistics, RMSNorm from a table, fp32 logits, SwiGLU -- returns the row-major call's
+    bits for granules of 4 / 8 / 16 rows, fp8 and bf16 weights, 2 ... 20 rows, K with a partial last slice."""
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    if not ops.gemv_rowss_supported(B, fp8):
+        pytest.skip("no hand-off kernel for this batch")
+    x, w = _rand((B, K), dtype, 41).to(DEV), _rand((N, K), dtype, 42, 0.03).to(DEV)
+    r = _rand((B, N), dtype, 43).to(DEV)
+    g = (1 + 0.1 * _rand((N,), torch.float32, 44)).to(dtype).to(DEV)
+    w2 = _rand((N2, N), dtype, 45, 0.03).to(DEV)
+
+    def variants(m):
+        if fp8:
+            q8, sc, _ = ops.quantize_fp8_rows(m)
+            return dict(w8=q8, wscale=sc), dict(w8=ops.pack_decode_weights(q8, rows), wscale=sc, packed_rows=rows, n_rows=m.shape[0])
+        return dict(w=m), dict(w=ops.pack_decode_weights(m, rows), packed_rows=rows, n_rows=m.shape[0])
+
+    rm1, pk1 = variants(w)
+    rm2, pk2 = variants(w2)
+    h, table = ops.gemv_rowss(x, residual=r, publish=True, **rm1)
+    hp, tablep = ops.gemv_rowss(x, residual=r, publish=True, **pk1)
+    assert torch.equal(h, hp) and torch.equal(table, tablep)
+    for kw in (dict(), dict(out_f32=True)) + ((dict(swiglu=True),) if N2 % (2 * rows) == 0 else ()):
+        a = ops.gemv_rowss(h, norm_w=g, eps=1e-5, rowss_in=table, **kw, **rm2)
+        b = ops.gemv_rowss(h, norm_w=g, eps=1e-5, rowss_in=table, **kw, **pk2)
+        assert torch.equal(a, b), kw
+    a = ops.gemv_rowss(h, norm_w=g, eps=1e-5, **rm2)  # statistics computed by the consumer
+    b = ops.gemv_rowss(h, norm_w=g, eps=1e-5, **pk2)
+    assert torch.equal(a, b)
+
+
+def test_gemv_rowss_packed_rejects_bad_geometry():
+    ops, L = _ops()
+    x = _rand((4, 96), torch.bfloat16, 1).to(DEV)
+    w = torch.zeros((64 * 96,), dtype=torch.uint8, device=DEV)
+    sc = torch.ones((64,), device=DEV)
+    with pytest.raises(ValueError):  # fp8: K must be a multiple of 64
+        ops.gemv_rowss(x, w8=w, wscale=sc, packed_rows=4, n_rows=64)
+    with pytest.raises(ValueError):  # 5 rows per granule is not a layout
+        ops.gemv_rowss(_rand((4, 128), torch.bfloat16, 1).to(DEV), w8=torch.zeros((64 * 128,), dtype=torch.uint8, device=DEV), wscale=sc,
+                       packed_rows=5, n_rows=64)
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("rows,cols", [(7, 1152), (3, 4608), (5, 64), (2, 72)])
@@ -730,9 +816,14 @@ def test_batched_decode_step_equals_rowss_composition_bit_for_bit(B, fp8):
     kc, vc = st.kcache.clone(), st.vcache.clone()
 
     def mat(name, i):
+        if fp8 and name in w.llm_pk:  # the packed copy the step streams (the row-major call returns the same bits: test above)
+            return dict(w8=w.llm_pk[name][i], wscale=w.llm_q[name][1][i], packed_rows=w.pk_rows[name], n_rows=w.llm_q[name][0][i].shape[0])
         if fp8:
             return dict(w8=w.llm_q[name][0][i], wscale=w.llm_q[name][1][i])
         return dict(w=w.llm_t[name][i])
+
+    if fp8:
+        assert set(w.llm_pk) == {"wqkv", "wo", "wgu", "wdown"} and w.pk_rows["wo"] == 16 and w.pk_rows["wgu"] == 4
 
     for t in range(G):
         tok = toks[t].reshape(B, 1)
