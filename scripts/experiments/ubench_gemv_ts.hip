@@ -1,4 +1,4 @@
-// Per-wave timeline of the decode GEMV (build: hipcc -DSRGPT_GEMV_TS ubench_gemv_ts.hip ../spatialrgpt_amd/csrc/gemv.hip ../spatialrgpt_amd/csrc/misc.hip)
+// Per-wave timeline of the decode GEMV (build: hipcc -DSRGPT_TUNING_KNOBS -DSRGPT_GEMV_TS ubench_gemv_ts.hip ../spatialrgpt_amd/csrc/gemv.hip ../spatialrgpt_amd/csrc/misc.hip)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -13,7 +13,7 @@
 typedef int (*gemv_fn)(const void*, const void*, const void*, float, const void*, void*, int, int, int, int, int, int, void*);
 typedef int (*gemv_w8_fn)(const void*, const void*, const float*, const void*, float, const void*, void*, int, int, int, int, int, void*);
 typedef int (*gemv_rowss_fn)(const void*, const void*, const void*, const float*, const void*, float, const void*, void*, int, int, int, int, int,
-                             const float*, float*, void*);
+                             const float*, float*, int, void*);
 __global__ void fill_bf16(unsigned* p, size_t n, unsigned seed) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
     auto run = [&](void* W) -> int {
       if (pub && c.N != 128258)
         return gemv_rowss(x, fp8 ? nullptr : W, fp8 ? W : nullptr, fp8 ? sc : nullptr, c.norm ? g : nullptr, 1e-5f, c.res ? res : nullptr, out, B,
-                          c.N, c.K, c.swiglu, c.f32, c.norm ? ss_a : nullptr, c.res ? ss_b : nullptr, s);
+                          c.N, c.K, c.swiglu, c.f32, c.norm ? ss_a : nullptr, c.res ? ss_b : nullptr, 0, s);
       if (fp8) return gemv_w8(x, W, sc, c.norm ? g : nullptr, 1e-5f, c.res ? res : nullptr, out, B, c.N, c.K, c.swiglu, c.f32, s);
       return gemv(x, W, c.norm ? g : nullptr, 1e-5f, c.res ? res : nullptr, out, B, c.N, c.K, c.swiglu, c.f32, 1 /*SRGPT_BF16*/, s);
     };

@@ -43,6 +43,10 @@ int srgpt_skinny_w8_launch(const void* x, const void* W8, const float* wscale, c
                            const float* ss_in, float* ss_out, int packed, hipStream_t s);  // skinny.hip
 int srgpt_w8_valu_max_batch();  // skinny.hip
 
+// (compile-time variants: tuning / micro-benchmark builds only -- a product build that defines one is refused)
+#if !defined(SRGPT_TUNING_KNOBS) && (defined(SRGPT_GEMV_TS) || defined(SRGPT_GEMV_REG_PIPE) || defined(SRGPT_GEMV_PIPE))
+#error "gemv.hip: -DSRGPT_GEMV_* variants need -DSRGPT_TUNING_KNOBS (make TUNING=1, scripts/experiments/ubench_gemv_ts.hip)"
+#endif
 #ifndef SRGPT_GEMV_REG_PIPE
 #define SRGPT_GEMV_REG_PIPE 0  // the same for the register-resident variant (o_proj: its weights are L2-prefetched; measured
                                // 3.036 vs 3.042 ms per token, o_proj 5.0 vs 5.45 us -- off)

@@ -45,6 +45,16 @@ __device__ unsigned long long srgpt_skinny_stamps[16];
 #define SK_STAMP(i) do { } while (0)
 #endif
 
+// Compile-time variants (-DSRGPT_SKINNY_*) and the timing probes below exist for the tuning build only: a product build that
+// defines one of them is refused (one stray flag must not ship a different -- or wrong -- product).
+#ifndef SRGPT_TUNING_KNOBS
+#if defined(SRGPT_SKINNY_DEPTH) || defined(SRGPT_SKINNY_DEPTH_W8) || defined(SRGPT_SKINNY_XREUSE) || defined(SRGPT_SKINNY_PRE) || \
+    defined(SRGPT_SKINNY_PRE_W8) || defined(SRGPT_SKINNY_FS) || defined(SRGPT_SKINNY_PROBE) || defined(SRGPT_SKINNY_CONTIG) || \
+    defined(SRGPT_SKINNY_PK_WPS) || defined(SRGPT_SKINNY_ONE_ACC) || defined(SRGPT_SKINNY_FIX_NSU)
+#error "skinny.hip: -DSRGPT_SKINNY_* variants need the tuning build (make TUNING=1)"
+#endif
+#endif
+
 constexpr int WROWB = 512 + 32;        // bytes per staged weight row: 136 dwords = 8 mod 64 banks -> the lane groups of ds_read_b128
                                        // (MI355X guide, LDS table) hit distinct banks; 528 measured 30 % conflict cycles
 constexpr int WSTAGEB = 16 * WROWB;    // weight stage per wave
@@ -94,7 +104,10 @@ constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumu
 // slices.  4-row granules keep every column split of the row-major kernel (24 q/k/v columns or 28 gate / up pairs per block);
 // 16-row granules (1 KiB contiguous per instruction) stream the single-tile products faster (profiles/r06_skinny_packed.txt).
 template <bool SWIGLU, int NI, int NW, bool W8, bool PUB, bool PK>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const bf16_t* __restrict__ x, const void* __restrict__ Wv,
+#ifndef SRGPT_SKINNY_PK_WPS
+#define SRGPT_SKINNY_PK_WPS 2  // waves per SIMD the packed fp8 4-wave kernel is compiled for (tuning builds: 3 / 4 = 3 / 4 blocks per CU)
+#endif
+__global__ __launch_bounds__(64 * NW, NW == 4 ? (PK && W8 ? SRGPT_SKINNY_PK_WPS : 2) : 1) void skinny_kernel(const bf16_t* __restrict__ x, const void* __restrict__ Wv,
                                                                           const float* __restrict__ wscale,
                                                                           const bf16_t* __restrict__ norm_w, float norm_eps,
                                                                           const bf16_t* __restrict__ residual, void* __restrict__ out,
@@ -359,7 +372,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
     constexpr int NSU = decltype(nsu_c)::value;
     constexpr int NS = SK / 32;           // MFMA k steps per stage
     constexpr int FS = NI == 8 ? 2 : SRGPT_SKINNY_FS;  // k steps whose fragments are read together (16 staged rows: fewer, registers)
-    constexpr bool TWO_ACC = NI < 8;  // even / odd k steps on separate accumulators (16 staged rows: the registers are not there)
+#ifndef SRGPT_SKINNY_ONE_ACC
+#define SRGPT_SKINNY_ONE_ACC 0
+#endif
+    constexpr bool TWO_ACC = NI < 8 && !SRGPT_SKINNY_ONE_ACC;  // even / odd k steps on separate accumulators (16 staged rows: the registers are not there)
     // slots of the activation ring (see load_x): as many slices ahead as the weight ring reaches
     constexpr int XS = NSU == 1 ? DEPTH : (NSU == 2 && DEPTH == 4 ? 2 : 1);
     static_assert(DEPTH % XS == 0, "the slot of a slice must be a compile-time function of its place in the trip");
@@ -549,6 +565,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void skinny_kernel(const 
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) nu += (pass * MAXU + u < ntile) ? 1 : 0;
     if (nu == 0) break;  // uniform per block; later passes are empty too
+#ifdef SRGPT_SKINNY_FIX_NSU  // register / occupancy probe (tuning builds): ONE sub-unit count compiled in -- only shapes with that count compute correctly
+    run_pass(std::integral_constant<int, SRGPT_SKINNY_FIX_NSU>{}, pass, nu);
+    continue;
+#endif
     switch (nu * R) {
       case 1: run_pass(std::integral_constant<int, 1>{}, pass, nu); break;
       case 2: run_pass(std::integral_constant<int, 2>{}, pass, nu); break;
@@ -612,7 +632,7 @@ int launch_skinny_nw(const void* x, const void* W, const float* wscale, const vo
     waves = (norm_w != nullptr && ncol <= 32) ? 8 : 4;
     if (norm_w == nullptr && ncol <= SRGPT_KNOB("SRGPT_SKINNY_W8_RES_COLS", 0)) waves = 8;
   }
-  const int blocks = waves == 8 ? cus : 2 * cus;
+  const int blocks = waves == 8 ? cus : SRGPT_KNOB("SRGPT_SKINNY_BPC", 2) * cus;
   int cw = (N + blocks - 1) / blocks;
   if (cw < 16) cw = 16;
   const int gr_shift = packed == 16 ? 4 : packed == 8 ? 3 : 2;
