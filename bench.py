@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--prompt-len", type=int, default=64)
     ap.add_argument("--max-new-tokens", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pin-as", default=None, metavar="RANK/WORLD",
+                    help="measurement aid: pin this single process to the cpus local rank RANK of WORLD would get (scripts/round6/sibling_load.py)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--batch", type=int, default=1, help="equal-length requests per generate() call per GPU")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8_w8a8"],
@@ -285,6 +287,14 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import torch.distributed as dist
 
+    # every rank gets its own cpus next to its GPU (one node: LOCAL_WORLD_SIZE ranks share the host); reported in config.dist
+    from spatialrgpt_amd.dist import pin_rank_to_cores
+    if args.pin_as:
+        pr, pw = (int(v) for v in args.pin_as.split("/"))
+        affinity = pin_rank_to_cores(pr, pw, device.index)
+    else:
+        affinity = pin_rank_to_cores(local_env, int(os.environ.get("LOCAL_WORLD_SIZE", str(world_env))), device.index)
+
     from spatialrgpt_amd import _lib as L
     from spatialrgpt_amd import ops
     from spatialrgpt_amd.model import LlavaLlamaModel
@@ -341,7 +351,7 @@ def main():
     tokens = world * args.steps * G * args.batch
     value = tokens / dt
     dist_info = {"launcher": "self (bench.py forked its ranks)" if os.environ.get("SRGPT_BENCH_SELF_LAUNCHED") else
-                 ("torch.distributed.run" if world > 1 else "single process"), "world_size_seen": world}
+                 ("torch.distributed.run" if world > 1 else "single process"), "world_size_seen": world, "affinity_rank0": affinity}
     if world > 1:
         mine = torch.tensor([args.steps * G * args.batch / dt_local, float(device.index)], dtype=torch.float64,
                             device=device if dist.get_backend() == "nccl" else "cpu")

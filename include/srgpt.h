@@ -335,9 +335,11 @@ typedef struct {
 int64_t srgpt_sample_ws_bytes(int B);
 int srgpt_sample(const float* logits, srgpt_sampling* sp, int64_t* tok_out, void* ws, int B, int V, srgpt_stream_t stream);
 /* ABI 8: the parameter block lives on the device, so settings outside the served range (top_k > 64; top_p < 1 with top_k = 0) cannot
- * be refused at the call: the kernels raise a sticky bit in the workspace's error word instead of drawing from a silently clamped
- * distribution.  srgpt_sample_status synchronises `stream` and returns SRGPT_ERR_UNSUPPORTED for it (SRGPT_ERR_STATE when more than
- * 256 entries tied at the top-k threshold); inside the decode step the same word is read by srgpt_llm_decode_sync_state. */
+ * be refused at the call: the kernels raise a bit in the workspace's error word instead of drawing from a silently clamped
+ * distribution.  srgpt_sample CLEARS that word when it starts, so srgpt_sample_status -- which synchronises `stream` and returns
+ * SRGPT_ERR_UNSUPPORTED for the bit (SRGPT_ERR_STATE when more than 256 entries tied at the top-k threshold) -- reports the MOST RECENT
+ * srgpt_sample call on that workspace only: check after each draw whose settings may be out of range.  Inside the decode step the
+ * word is the state's own and is never cleared once raised (sticky); srgpt_llm_decode_sync_state reports it. */
 int srgpt_sample_status(const void* ws, int B, srgpt_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

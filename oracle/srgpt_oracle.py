@@ -97,8 +97,9 @@ LM = "llm."
 #     26-34) over HF SiglipVisionModel (third-party; patch conv + learned pos-emb + pre-LN encoder).
 # ------------------------------------------------------------------------------------------------
 
-def vit_forward(w: Dict[str, torch.Tensor], cfg: SrgptConfig, images: torch.Tensor) -> torch.Tensor:
-    """images [N,3,S,S] -> hidden_states[select_layer] = [N, grid^2, C] cast back to images.dtype."""
+def vit_forward(w: Dict[str, torch.Tensor], cfg: SrgptConfig, images: torch.Tensor, collect_hidden: Optional[list] = None) -> torch.Tensor:
+    """images [N,3,S,S] -> hidden_states[select_layer] = [N, grid^2, C] cast back to images.dtype.
+    collect_hidden: a list that receives the input of every layer that runs and the last one's output (per-layer parity tests)."""
     wd = w[VT + "embeddings.patch_embedding.weight"].dtype
     clip = cfg.tower == "clip"
     x = F.conv2d(images.to(wd), w[VT + "embeddings.patch_embedding.weight"],
@@ -115,6 +116,8 @@ def vit_forward(w: Dict[str, torch.Tensor], cfg: SrgptConfig, images: torch.Tens
     H, hd = cfg.vit_heads, cfg.vit_head_dim
     for i in range(n_run):
         p = f"{VT}encoder.layers.{i}."
+        if collect_hidden is not None:
+            collect_hidden.append(x)
         r = x
         h = F.layer_norm(x, (cfg.vit_hidden,), w[p + "layer_norm1.weight"], w[p + "layer_norm1.bias"], cfg.vit_eps)
         N, L, C = h.shape
@@ -135,6 +138,8 @@ def vit_forward(w: Dict[str, torch.Tensor], cfg: SrgptConfig, images: torch.Tens
             h = F.gelu(h, approximate="tanh")  # SigLIP hidden_act = gelu_pytorch_tanh
         h = F.linear(h, w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"])
         x = r + h
+    if collect_hidden is not None:
+        collect_hidden.append(x)
     if cfg.select_feature == "patch":
         x = x[:, 1:]
     elif cfg.select_feature != "cls_patch":

@@ -205,8 +205,8 @@ __global__ __launch_bounds__(1024) void sample_select_kernel(const srgpt_samplin
   __shared__ int sidx[SMP_LIST];
   __shared__ unsigned n_valid, n_list;
   // settings the device sampler does not serve must not draw from a silently different distribution: top_k beyond the
-  // candidate slots would be clamped, and a top-p filter without top-k would be ignored by the Gumbel path -- sticky error bit 4,
-  // reported by srgpt_llm_decode_sync_state / srgpt_sample_status
+  // candidate slots would be clamped, and a top-p filter without top-k would be ignored by the Gumbel path -- error bit 4, reported
+  // by srgpt_llm_decode_sync_state (the state's word: sticky) / srgpt_sample_status (the workspace's word: the last srgpt_sample call)
   if (blockIdx.x == 0 && threadIdx.x == 0 && (sp->top_k > SMP_K || (sp->top_k <= 0 && sp->top_p < 1.f))) atomicOr(err, 4);
   const int topk = min(sp->top_k, SMP_K);
   if (topk <= 0) return;  // Gumbel-max mode: the greedy merge (advance_kernel) picks

@@ -31,6 +31,77 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     return rank, world, local
 
 
+def _parse_cpulist(text: str) -> List[int]:
+    """sysfs cpulist ("0-63,128-191") -> sorted cpu ids"""
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return sorted(set(out))
+
+
+def gpu_numa_cpus(device_index: int, sysfs: str = "/sys") -> Optional[List[int]]:
+    """cpus of the NUMA node the GPU hangs off (sysfs `local_cpulist` of its PCI function), or None when the platform does not say
+    (no PCI ids from the runtime, numa_node == -1, containers without /sys/bus/pci)."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        base = os.path.join(sysfs, "bus", "pci", "devices", bdf)
+        with open(os.path.join(base, "numa_node")) as f:
+            if int(f.read().strip()) < 0:
+                return None
+        with open(os.path.join(base, "local_cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        return cpus or None
+    except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
+        return None
+
+
+def plan_rank_affinity(local_rank: int, local_world: int, allowed: Sequence[int], numa_cpus: Optional[Sequence[int]] = None,
+                       ranks_on_node: Optional[Sequence[int]] = None) -> List[int]:
+    """The cpu set rank `local_rank` of `local_world` should run on: a DISJOINT share of the allowed cpus, taken from its GPU's NUMA
+    node when that is known.  ranks_on_node: the local ranks whose GPUs share this NUMA node (they split its cpus between them);
+    unknown topology: the allowed set is cut into local_world contiguous shares.  Never empty: falls back to the allowed set."""
+    allowed = sorted(set(int(c) for c in allowed))
+    if not allowed or local_world <= 1:
+        return allowed
+    pool, peers = allowed, list(range(local_world))
+    if numa_cpus:
+        near = [c for c in allowed if c in set(numa_cpus)]
+        if near and ranks_on_node and local_rank in ranks_on_node and len(near) >= len(ranks_on_node):
+            pool, peers = near, sorted(ranks_on_node)
+    k, n = peers.index(local_rank) if local_rank in peers else local_rank % len(peers), len(peers)
+    share = pool[k * len(pool) // n:(k + 1) * len(pool) // n]
+    return share or allowed
+
+
+def pin_rank_to_cores(local_rank: int, local_world: int, device_index: Optional[int] = None) -> dict:
+    """Give this rank's process (and the threads it starts from here on) its own cpus next to its GPU.  N Python processes issue
+    ~500 launches per request prefix each with < 0.1 ms of slack (profiles/r05_prefix_bs1.txt): left to the scheduler they migrate
+    across sockets and share cores.  The reference's eval fan-out (scripts/srgpt/eval/srgpt_bench.sh:23-34) leaves placement to the
+    OS; this is the MI355X-node version of it.  Returns what was done, for the bench line (config.dist)."""
+    info = {"pinned": False, "local_rank": local_rank, "local_world": local_world}
+    if not hasattr(os, "sched_setaffinity") or local_world <= 1:
+        return info
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        numa = gpu_numa_cpus(device_index) if device_index is not None and torch.cuda.is_available() else None
+        peers = None
+        if numa is not None:
+            peers = [r for r in range(local_world) if gpu_numa_cpus(r % max(torch.cuda.device_count(), 1)) == numa]
+        cpus = plan_rank_affinity(local_rank, local_world, allowed, numa, peers)
+        os.sched_setaffinity(0, cpus)
+        # one launcher thread + a helper or two: torch's intra-op pool must not spawn a thread per visible core
+        torch.set_num_threads(max(1, min(len(cpus), 8)))
+        info.update(pinned=True, cpus=f"{cpus[0]}-{cpus[-1]}" if cpus == list(range(cpus[0], cpus[-1] + 1)) else cpus[:64],
+                    n_cpus=len(cpus), numa_known=numa is not None)
+    except OSError as e:  # (a cgroup that forbids it: run unpinned and say so)
+        info["error"] = str(e)
+    return info
+
+
 def barrier(local: Optional[int] = None, group=None) -> None:
     """dist.barrier that names this rank's device under the RCCL backend: without `device_ids` the nccl backend guesses the device
     from the global rank (and warns), which is wrong the moment ranks and devices are not numbered alike."""

@@ -275,9 +275,12 @@ class BeamScorer437:
         out_s, out_t, out_i = [], [], []
         for b in range(self.batch):
             if self.done[b]:
+                # a finished batch item keeps ITS OWN rows (HF pads with beam index 0 = row 0 of the whole batch; the caller here
+                # permutes the KV cache by these indices, and a finished item of a ragged batch must not inherit row 0's shorter cache:
+                # its logits would be read from unwritten positions)
                 out_s += [0.0] * nb
                 out_t += [pad_token_id if pad_token_id is not None else 0] * nb
-                out_i += [0] * nb
+                out_i += [b * nb + j for j in range(nb)]
                 continue
             kept = 0
             for rank, (tok, sc, idx) in enumerate(zip(next_tokens[b], next_scores[b], next_indices[b])):
@@ -343,16 +346,18 @@ def beam_sample_candidates(scores: torch.Tensor, n: int, generator: Optional[tor
 def beam_generate(first_logits: torch.Tensor, step, batch: int, num_beams: int, max_new_tokens: int,
                   eos_token_ids: Optional[List[int]], pad_token_id: Optional[int], do_sample: bool = False, temperature=None,
                   top_k=None, top_p=None, generator: Optional[torch.Generator] = None, length_penalty: float = 1.0,
-                  early_stopping=False, stopping_criteria=None, warp_before_beam_scores: bool = False) -> torch.Tensor:
+                  early_stopping=False, stopping_criteria=None, warp_before_beam_scores: bool = True) -> torch.Tensor:
     """`generate(num_beams > 1)` of the reference's callers -- `--num_beams` of eval_spatial.py:231-235, eval_region_cls.py:318-322,
     model_vqa.py:72-76, which pass `do_sample = temperature > 0` with `--temperature` defaulting to 0.2: the default flags plus
     `--num_beams 3` are BEAM-SAMPLE -- as transformers 4.37.2 runs them (GenerationMixin.beam_search / .beam_sample +
     BeamSearchScorer), over a decoder fed `inputs_embeds` (ids start empty; lengths count new tokens).
 
     Every step: scores = log_softmax(logits) (+ the running beam scores); beam search takes the max(2, 1 + #eos) * num_beams best
-    (beam, token) continuations per batch item; beam-sample warps the summed scores (temperature -> top-k -> top-p, per beam row:
-    4.37.2 applies the warpers AFTER adding the beam scores -- `warp_before_beam_scores=True` gives the later releases' order),
-    draws 2 * num_beams continuations without replacement from their softmax and sorts them by score.  BeamScorer437.process keeps
+    (beam, token) continuations per batch item; beam-sample warps the token scores (temperature -> top-k -> top-p, per beam row) and
+    THEN adds the running beam scores -- `logits_warper(logits_processor(log_softmax))  + beam_scores`, the order of the releases
+    since the "temperature also scales the beam scores" fix of 2023 (the pinned 4.37.2 wheel cannot be inspected offline; the 5.15
+    here, which minted tests/golden/beam_kat.npz, has this order; `warp_before_beam_scores=False` gives the older releases' warp of
+    the summed scores) --, draws 2 * num_beams continuations without replacement from their softmax and sorts them by score.  BeamScorer437.process keeps
     the first num_beams that do not end in an EOS id and files the EOS ones that rank among the first num_beams as hypotheses.
 
     first_logits fp32 [batch * num_beams, V]; step(tokens int64 [batch * num_beams], beam_idx int64 [batch * num_beams]) -> logits of

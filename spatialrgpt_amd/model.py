@@ -338,6 +338,10 @@ class LlavaLlamaModel:
     def forward(self, input_ids=None, images=None, masks=None, depths=None, attention_mask=None, position_ids=None,
                 past_key_values=None, seqlens_in_batch=None, inputs_embeds=None, labels=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, return_dict=None, dpo_forward=False):
+        # HF resolves use_cache=None from config.use_cache (LlamaConfig default True; the reference forwards to LlamaForCausalLM, which
+        # does `use_cache if use_cache is not None else self.config.use_cache`, modeling_llama.py:1017-1020 of the vendored file)
+        if use_cache is None:
+            use_cache = bool(getattr(self.config, "use_cache", True))
         if past_key_values is not None:
             # incremental step over the state a previous forward(use_cache=True) returned (what HF's generate loop does with
             # the reference model: llava_arch.py:355-385 early-out, then the LLM with a cache)

@@ -116,3 +116,24 @@ def test_bench_eight_rank_dry_run_names_the_global_batch(preset, batch, weights)
     assert j["gathered_rows"] == 8 * batch and j["llm_weights"] == weights
     assert f"configs[{preset[-1]}]" in j["workload"]
     assert j["per_rank_rows"] == [[r_, batch * 16] for r_ in range(8)]
+
+
+def test_rank_affinity_plan_gives_disjoint_shares_next_to_the_gpu():
+    """spatialrgpt_amd.dist.plan_rank_affinity (bench.py pins every rank with it): disjoint shares that cover the allowed cpus; with a
+    known topology the ranks of one NUMA node split THAT node's cpus; never an empty set."""
+    from spatialrgpt_amd.dist import _parse_cpulist, plan_rank_affinity
+
+    assert _parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    allowed = list(range(256))
+    shares = [plan_rank_affinity(r, 8, allowed) for r in range(8)]
+    assert sorted(c for s in shares for c in s) == allowed and all(len(s) == 32 for s in shares)
+    # two sockets: GPUs 0-3 on node 0 (cpus 0-63 + their hyperthreads 128-191), 4-7 on node 1
+    node0 = list(range(0, 64)) + list(range(128, 192))
+    node1 = [c for c in allowed if c not in node0]
+    s = [plan_rank_affinity(r, 8, allowed, node0 if r < 4 else node1, [0, 1, 2, 3] if r < 4 else [4, 5, 6, 7]) for r in range(8)]
+    assert all(set(s[r]) <= set(node0 if r < 4 else node1) for r in range(8))
+    assert sorted(c for x in s for c in x) == allowed
+    # a cgroup that exposes 8 cpus to 8 ranks: one each; fewer cpus than ranks: shares may repeat but are never empty
+    assert [plan_rank_affinity(r, 8, list(range(8))) for r in range(8)] == [[c] for c in range(8)]
+    assert all(plan_rank_affinity(r, 8, [3, 4]) for r in range(8))
+    assert plan_rank_affinity(0, 1, allowed) == allowed

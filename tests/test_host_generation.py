@@ -304,5 +304,5 @@ def test_beam_sample_through_the_oracle_is_seeded_and_respects_eos():
             hit = [j for j, t in enumerate(row) if t in eos]
             if hit:  # the token at the stop position is eos[0]; everything behind it is padding
                 assert row[hit[0]] == eos[0] and all(t == PAD for t in row[hit[0] + 1:])
-    # the later releases' warper order is available and also runs
-    go(one, 1, temperature=0.2, top_k=50, top_p=None, warp_before_beam_scores=True)
+    # the older releases' warper order (warp the summed scores) is available and also runs
+    go(one, 1, temperature=0.2, top_k=50, top_p=None, warp_before_beam_scores=False)
