@@ -777,14 +777,18 @@ extern "C" int64_t srgpt_decode_attn_ws_floats(int B, int Hq, int D) {
 // next_w = NULL -> no prefetch.  batch > 1 goes through the skinny kernel: no prefetch there (measured, common.h).
 int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
                               const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D, int max_pos, int dtype,
-                              const void* next_w, int next_n, int next_k, int next_fp8, srgpt_stream_t stream) {
+                              const void* next_w, int next_n, int next_k, int next_fp8, int next_packed_rows, srgpt_stream_t stream) {
   SRGPT_CHECK(qkv && kcache && vcache && pos && cos_tab && sin_tab && out && ws, SRGPT_ERR_ARG,
               "srgpt_decode_attention: null pointer");
   SRGPT_CHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, SRGPT_ERR_ARG, "srgpt_decode_attention: bad heads");
   // 0 = off; 2 = all of o_proj (measured 3.189 / 3.169 / 3.138 ms per token at 0 / 1 / 2 rounds)
   const int pf_rounds = SRGPT_KNOB("SRGPT_DECODE_PREFETCH_ROUNDS", 2);
-  const DecodePrefetch pf = dtype == SRGPT_BF16 ? srgpt_prefetch_for_gemv(next_w, next_n, next_k, 0, next_fp8, B, pf_rounds, 0)
-                                                : srgpt_prefetch_for_gemv(nullptr, 0, 0, 0, 0, B, 0, 0);
+  // batched decode on packed fp8 weights (round 6): o_proj's 16-row tiles are contiguous and tile p belongs to block p of the next
+  // launch -- the whole 16.8-MB matrix fits the 32 MB of L2; SRGPT_DECODE_PREFETCH_TILES = loads a prefetch wave keeps in flight (0: off)
+  const int pf_tiles = SRGPT_KNOB("SRGPT_DECODE_PREFETCH_TILES", 0);
+  const DecodePrefetch pf = dtype != SRGPT_BF16 ? srgpt_prefetch_for_gemv(nullptr, 0, 0, 0, 0, B, 0, 0)
+                            : (next_packed_rows == 16 && B > 1) ? srgpt_prefetch_for_packed_tiles(next_w, next_n, next_k, next_fp8 ? 1 : 2, pf_tiles)
+                                                                : srgpt_prefetch_for_gemv(next_w, next_n, next_k, 0, next_fp8, B, pf_rounds, 0);
   if (dtype == SRGPT_BF16)
     return launch_decode<bf16_t>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos, pf,
                                  as_stream(stream));
@@ -806,7 +810,7 @@ extern "C" int srgpt_decode_attention(const void* qkv, void* kcache, void* vcach
                                       const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D,
                                       int max_pos, int dtype, srgpt_stream_t stream) {
   return srgpt_decode_attention_pf(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos, dtype, nullptr, 0,
-                                   0, 0, stream);
+                                   0, 0, 0, stream);
 }
 
 extern "C" int srgpt_attention(const void* q, const void* k, const void* v, void* o, int B, int Tq, int Tk, int Hq,

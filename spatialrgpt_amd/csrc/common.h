@@ -247,6 +247,8 @@ struct SrgptPrefetch {
   int n_rows;            // rows of the matrix: the row index is clamped (fp8 column pairs of an odd N would touch row N)
   int batch;             // 1-KiB loads a wave keeps in flight (1: one at a time -- the trickle that leaves the host launch's own
                          // loads alone; 2 / 4 / 8: faster, at the price of queueing in front of them)
+  int tile_bytes;        // > 0: TILE mode (round 6) -- the next launch is the batched MFMA product on a PACKED matrix whose block p
+                         // streams the contiguous tile p (16 rows x K): prefetch block p pulls that tile, its waves interleaved
 };
 
 template <int NB>
@@ -266,7 +268,32 @@ __device__ __forceinline__ void srgpt_prefetch_rows(const SrgptPrefetch& pf, int
       }
     }
 }
+// tile mode: block p pulls tile p (+ k * gemv_grid), wave w the 1-KiB chunks w, w + nw, ...
+template <int NB>
+__device__ __forceinline__ void srgpt_prefetch_tiles(const SrgptPrefetch& pf, int p, int wave, int lane) {
+  const int nw = (int)blockDim.x >> 6, chunks = pf.tile_bytes >> 10;
+  int done = 0;
+  for (int t = p; t < pf.n_units && done < pf.rounds; t += pf.gemv_grid, ++done) {
+    const char* tb = pf.base + (size_t)t * pf.tile_bytes + lane * 16;
+    for (int c0 = wave; c0 < chunks; c0 += nw * NB) {
+      u32x4 v[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) v[c] = *reinterpret_cast<const u32x4*>(tb + ((size_t)min(c0 + c * nw, chunks - 1) << 10));
+#pragma unroll
+      for (int c = 0; c < NB; ++c) asm volatile("" ::"v"(v[c]));  // keep the loads; the data is dropped
+    }
+  }
+}
 __device__ __forceinline__ void srgpt_prefetch_block(const SrgptPrefetch& pf, int p, int wave, int lane) {
+  if (pf.tile_bytes > 0) {
+    switch (pf.batch) {
+      case 8: srgpt_prefetch_tiles<8>(pf, p, wave, lane); break;
+      case 4: srgpt_prefetch_tiles<4>(pf, p, wave, lane); break;
+      case 2: srgpt_prefetch_tiles<2>(pf, p, wave, lane); break;
+      default: srgpt_prefetch_tiles<1>(pf, p, wave, lane); break;
+    }
+    return;
+  }
   switch (pf.batch) {
     case 8: srgpt_prefetch_rows<8>(pf, p, wave, lane); break;
     case 4: srgpt_prefetch_rows<4>(pf, p, wave, lane); break;
@@ -283,7 +310,7 @@ extern "C" int srgpt_device_cus(void);
 // to the skinny kernel in round 3, the VALU mapping's prefetch costs 1.6 % per step: profiles/r03_skinny_min_batch.txt).
 static inline SrgptPrefetch srgpt_prefetch_for_gemv(const void* W, int N, int K, int swiglu, int fp8, int batch, int rounds,
                                                     int prefix_bytes) {
-  SrgptPrefetch pf{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1, 1};
+  SrgptPrefetch pf{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1, 1, 0};
   const long long row_bytes = fp8 ? (long long)K : 2LL * K;
   if (!W || batch > 1 || rounds <= 0 || row_bytes % 1024 != 0 || (fp8 && swiglu)) return pf;
   const int cus = srgpt_device_cus();
@@ -302,5 +329,19 @@ static inline SrgptPrefetch srgpt_prefetch_for_gemv(const void* W, int N, int K,
   pf.nblocks = grid;
   pf.n_rows = swiglu ? 2 * N : N;
   pf.batch = SRGPT_KNOB("SRGPT_DECODE_PREFETCH_BATCH", 2);  // measured 1 / 2 / 4 / 8: 3.016 / 2.948 / 2.986 / 3.000 ms per token (profiles/r03_decode_attention.txt)
+  return pf;
+}
+// descriptor for "the next launch is the batched MFMA product (skinny.hip) over a PACKED matrix of 16-row granules, one tile per block"
+// (o_proj / down_proj of the batched fp8 decode step): block p of that launch -- XCD p % 8, like prefetch block p -- streams tile p
+static inline SrgptPrefetch srgpt_prefetch_for_packed_tiles(const void* Wp, int N, int K, int elem_bytes, int batch_loads) {
+  SrgptPrefetch pf{nullptr, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1, 1, 0};
+  const long long tile = 16LL * K * elem_bytes;
+  if (!Wp || batch_loads <= 0 || tile % 1024 != 0 || N % 16 != 0 || N / 16 > srgpt_device_cus()) return pf;
+  pf.base = reinterpret_cast<const char*>(Wp);
+  pf.tile_bytes = (int)tile;
+  pf.n_units = N / 16;
+  pf.gemv_grid = pf.nblocks = N / 16;
+  pf.rounds = 1;
+  pf.batch = batch_loads;
   return pf;
 }

@@ -7,7 +7,7 @@
 
 int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const int* pos, const void* cos_tab,
                               const void* sin_tab, void* out, float* ws, int B, int Hq, int Hkv, int D, int max_pos, int dtype,
-                              const void* next_w, int next_n, int next_k, int next_fp8, srgpt_stream_t stream);  // attn.hip
+                              const void* next_w, int next_n, int next_k, int next_fp8, int next_packed_rows, srgpt_stream_t stream);  // attn.hip
 void* srgpt_decode_attn_sync_words(float* ws, int B, int Hq, int D, size_t* bytes);  // attn.hip
 int srgpt_sample_launch(const float* logits, const srgpt_sampling* sp, int64_t* tok, void* ws, float* pv, int* pi, int* err, int B, int V,
                         hipStream_t s);  // sample.hip
@@ -592,7 +592,7 @@ static int decode_step_impl(const srgpt_llm_weights* w, srgpt_llm_state* st, srg
     // (profiles/r03_fused_attention_oproj.txt)
     SRGPT_TRY(srgpt_decode_attention_pf(d.qkvd, kc, vc, st->pos, w->rope_cos, w->rope_sin, d.attnd, d.dws, B, Hq, Hkv, D,
                                         st->max_pos, dt, pk(w->wo8p, i) ? pk(w->wo8p, i) : (w8 ? w->wo8[i] : w->wo[i]), Hd, Hq * D,
-                                        w8 ? 1 : 0, stream));
+                                        w8 ? 1 : 0, pk(w->wo8p, i) ? w->pk_rows_o : 0, stream));
     SRGPT_TRY(mv(d.attnd, w->wo[i], w8 ? w->wo8[i] : nullptr, w8 ? w->wo_scale[i] : nullptr, nullptr, d.xd, d.xd, Hd,
                  Hq * D, 0, 0, nullptr, ss_attn, pk(w->wo8p, i), w->pk_rows_o));
     SRGPT_TRY(mv(d.xd, w->wgu[i], w8 ? w->wgu8[i] : nullptr, w8 ? w->wgu_scale[i] : nullptr, w->mlp_norm[i], nullptr,
