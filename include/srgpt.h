@@ -300,6 +300,11 @@ int srgpt_splice_gather(const int* desc, const int* stats, int B, int Tcap, int 
                         const void* embed, const void* image_features, const void* mask_embeds, const void* depth_embeds,
                         const int64_t* labels, int P, int64_t ignore_index, void* out, int64_t* labels_out,
                         unsigned char* attn_mask_out, srgpt_stream_t stream);
+/* ABI 9: beam search's cache permutation on the device (HF `_reorder_cache`): kcache / vcache [layers, batch * num_beams, kv_heads,
+ * max_pos, head_dim]; row r of the first `live` positions of every layer := row beam_idx[r] (int64, device; an index never leaves
+ * its batch item's num_beams rows).  In place, one launch; 2 ... 8 beams (else SRGPT_ERR_UNSUPPORTED: permute on the caller's side). */
+int srgpt_kv_beam_reorder(void* kcache, void* vcache, const int64_t* beam_idx, int layers, int batch, int num_beams, int kv_heads,
+                          int max_pos, int head_dim, int live, int dtype, srgpt_stream_t stream);
 int srgpt_scatter_rows(const void* src, const int* src_idx, const int* idx, void* dst, int n, int cols,
                        int dtype, srgpt_stream_t stream);
 int srgpt_silu_mul(const void* gu, void* out, int rows, int inter, int dtype, srgpt_stream_t stream);

@@ -111,6 +111,7 @@ _SIGNATURES = {
     "srgpt_s2d": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "srgpt_im2col": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "srgpt_embed_rows": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "srgpt_kv_beam_reorder": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "srgpt_scatter_rows": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "srgpt_silu_mul": (i32, [vp, vp, i32, i32, i32, vp]),
     "srgpt_argmax": (i32, [vp, vp, i32, i32, vp]),

@@ -54,7 +54,12 @@ constexpr int G_LDS = 2 * G_BUF;          // 128 KiB
 // ds_read_b128), one 16-byte read = 16 consecutive k of a row = the B operands of TWO MFMAs after v_cvt_scalef32_pk_bf16_fp8
 // (scale 1), so the A operand takes its 16-byte chunks in the matching order (chunk 4j + 2 hi + e for MFMA 2j + e);
 // the row scale multiplies the accumulator in the epilogue (exact: the bf16 value of code * 2^k is code * 2^k).
-template <bool W8>
+// PERSIST (round 6): one block per CU walks a list of tiles (its XCD's run, strided by the blocks of that XCD).  At K = 1152 (the ViT
+// and deconvolution products: 18 K tiles) a tile's K loop is ~9 us and its block launch + two-K-tile prologue + epilogue ~5 us
+// more (profiles/r05_vit_batched_gemm.txt: 0.63 - 0.79 PF/s against 1.1 at K = 4096): here the prologue DMAs of tile t + 1 are
+// issued right after tile t's last barrier -- every fragment read has retired, both K-tile buffers are free -- and land while tile
+// t's epilogue stores go out; no block dispatch between tiles.
+template <bool W8, bool PERSIST>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __restrict__ A, const void* __restrict__ Wv,
                                                                int K, int lda, Epilogue e, int gx, int gy) {
   const bf16_t* W = reinterpret_cast<const bf16_t*>(Wv);
@@ -66,17 +71,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
   const int wr = wave >> 2, wc = wave & 3;
 
   // ---- block -> tile: XCD-contiguous runs (bijective for any grid size), 8-row bands inside a run ----
-  int by, bx;
-  {
-    const int nwg = gx * gy, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  // PERSIST: the block walks tiles run_start + (bid >> 3) + j * (blocks per XCD) of its XCD's run (the grid is a multiple of 8)
+  const int nwg = gx * gy, bid = blockIdx.x;
+  const int xcd = bid & 7, runq = nwg >> 3, runr = nwg & 7;
+  const int run_start = xcd < runr ? xcd * (runq + 1) : runr * (runq + 1) + (xcd - runr) * runq;
+  const int run_len = runq + (xcd < runr ? 1 : 0);
+  const int tstep = PERSIST ? (int)(gridDim.x >> 3) : run_len;  // (not persistent: one tile)
+  int tpos = bid >> 3;                                          // position inside the run
+  int m0, n0;
+  auto tile_origin = [&](int pos) {
+    const int wg = run_start + pos;
     const int band = wg / (8 * gx), idx = wg - band * 8 * gx;
     const int hb = min(8, gy - band * 8);
-    by = band * 8 + idx % hb;
-    bx = idx / hb;
-  }
-  const int m0 = by * G_BM, n0 = bx * G_BN;
+    m0 = (band * 8 + idx % hb) * G_BM;
+    n0 = (idx / hb) * G_BN;
+  };
+  tile_origin(tpos);
 
   const int nk_all = K / G_BK;
   const int kt0 = e.splits > 1 ? (int)blockIdx.y * e.tiles_per_split : 0;
@@ -90,16 +100,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
   const bf16_t* pw[4];
   const bf16_t* pa[4];
   const unsigned char* pw8[2];  // fp8 W: group g = rows 16g .. 16g+15 (64 B each); this wave stages groups w and 8 + w
+  auto set_sources = [&]() {  // for the tile at (m0, n0)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int gw_ = wave + 8 * i;                                  // W: 0..7, 8..15, 16..23, 24..31
-    const int ga_ = (i & 1) * 16 + (i >> 1) * 8 + wave;            // A: w, 16+w, 8+w, 24+w
-    pw[i] = W + (size_t)min(n0 + gw_ * 8 + lr, e.N - 1) * K + lc * 8;
-    pa[i] = A + (size_t)min(m0 + ga_ * 8 + lr, e.M - 1) * lda + lc * 8;
-  }
+    for (int i = 0; i < 4; ++i) {
+      const int gw_ = wave + 8 * i;                                  // W: 0..7, 8..15, 16..23, 24..31
+      const int ga_ = (i & 1) * 16 + (i >> 1) * 8 + wave;            // A: w, 16+w, 8+w, 24+w
+      pw[i] = W + (size_t)min(n0 + gw_ * 8 + lr, e.N - 1) * K + lc * 8;
+      pa[i] = A + (size_t)min(m0 + ga_ * 8 + lr, e.M - 1) * lda + lc * 8;
+    }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)  // lane -> row lane >> 2 of the group, physical chunk lane & 3; (row >> 2) & 3 = (lane >> 4) & 3
-    pw8[i] = W8p + (size_t)min(n0 + (wave + 8 * i) * 16 + (lane >> 2), e.N - 1) * K + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+    for (int i = 0; i < 2; ++i)  // lane -> row lane >> 2 of the group, physical chunk lane & 3; (row >> 2) & 3 = (lane >> 4) & 3
+      pw8[i] = W8p + (size_t)min(n0 + (wave + 8 * i) * 16 + (lane >> 2), e.N - 1) * K + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+  };
+  set_sources();
   auto dma = [&](const void* src, int lds_off) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(lds + lds_off), 16, 0, 0);
@@ -154,34 +167,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
   for (int j = 0; j < 2; ++j) koff8[j] = l31 * 64 + (((2 * j + hi) ^ ((l31 >> 2) & 3)) << 4);
 
   f32x16 acc[4][2];
-  {
-    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc[i][0] = z;
-      acc[i][1] = z;
-    }
-  }
   bf16x8 fw[2][4], fa[2][4];
   u32x4 raw8[2][2];  // W8: the tile's fp8 W fragments as read from LDS
+  const bool late = wr == 1;  // the late half runs one phase behind the early half; the two waves of a SIMD are in different halves
 
-  // ---- prologue: tile kt0 complete, W + A rows 0,1 of tile kt0+1 (its A rows 2,3 are staged in phase 0 of tile kt0) ----
-  stage(S0{}, kt0);
-  stage(S1{}, kt0);
-  stage(S2{}, kt0);
-  stage(S3{}, kt0);
-  if (kt0 + 1 < nk) {
-    stage(S0{}, kt0 + 1);
-    stage(S1{}, kt0 + 1);
-    stage(S2{}, kt0 + 1);
-    if constexpr (W8) G_VMCNT(4); else G_VMCNT(6);
-  } else {
-    G_VMCNT(0);
-  }
-  G_BARRIER();
-  // the late half runs one phase behind the early half; the two waves of a SIMD must be in different halves
-  const bool late = wr == 1;
-  if (late) G_BARRIER();
+  // ---- prologue requests of a tile: K tile kt0 complete, W + A rows 0,1 of K tile kt0+1 (its A rows 2,3 are staged in phase 0 of kt0) ----
+  auto prologue_requests = [&]() {
+    stage(S0{}, kt0);
+    stage(S1{}, kt0);
+    stage(S2{}, kt0);
+    stage(S3{}, kt0);
+    if (kt0 + 1 < nk) {
+      stage(S0{}, kt0 + 1);
+      stage(S1{}, kt0 + 1);
+      stage(S2{}, kt0 + 1);
+    }
+  };
+  prologue_requests();
+  bool first_tile = true;
 
   // Phase P (0 / 1) of K tile kt = m-tiles 2P, 2P+1 of the wave x both n-tiles x K = 64: 16 MFMAs on FOUR accumulators (the same
   // accumulator comes round every 4th MFMA: back-to-back dependent 32x32x16 MFMAs at distance 2 stall ~8 cycles each).
@@ -275,32 +278,63 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
 
-  for (int kt = kt0; kt < nk; ++kt) {
-    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
-    phase(P0{}, kt, more1, more2);
-    phase(P1{}, kt, more1, more2);
-  }
-  if (!late) G_BARRIER();  // pairs with the last barrier of the late half
-
-  // ---- epilogue.  D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
-#pragma clang loop unroll(full)
-  for (int i = 0; i < 4; ++i)
-#pragma clang loop unroll(full)
-    for (int jn = 0; jn < 2; ++jn) {
-      const f32x16 a = acc[i][jn];
-      const int n = n0 + wc * 64 + jn * 32 + l31;
-      const int mb = m0 + wr * 128 + i * 32 + 4 * hi;
-      if (e.splits > 1) {
-        float* slab = e.partial + (size_t)blockIdx.y * e.M * e.N;
-#pragma clang loop unroll(full)
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (m < e.M && n < e.N) slab[(size_t)m * e.N + n] = a[r];
-        }
-      } else {
-        epilogue_tile32<bf16_t>(e, mb, n, a);
+  for (;;) {
+    {
+      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i][0] = z;
+        acc[i][1] = z;
       }
     }
+    // K tile kt0 has landed (first tile: the 6 requests of kt0+1 may still fly; later tiles: the requests were issued in front of
+    // the previous tile's epilogue stores -- vmcnt counts those too and only goes to 63, so everything is waited for: the stores
+    // had the whole request latency to drain)
+    if (first_tile && kt0 + 1 < nk) {
+      if constexpr (W8) G_VMCNT(4); else G_VMCNT(6);
+    } else {
+      G_VMCNT(0);
+    }
+    first_tile = false;
+    G_BARRIER();
+    if (late) G_BARRIER();
+    for (int kt = kt0; kt < nk; ++kt) {
+      const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+      phase(P0{}, kt, more1, more2);
+      phase(P1{}, kt, more1, more2);
+    }
+    if (!late) G_BARRIER();  // pairs with the last barrier of the late half: every fragment read of this tile has retired
+
+    const int em0 = m0, en0 = n0;  // the finished tile's origin
+    tpos += tstep;
+    const bool more_tiles = PERSIST && tpos < run_len;
+    if (more_tiles) {  // the next tile's first requests go out BEFORE this tile's stores
+      tile_origin(tpos);
+      set_sources();
+      prologue_requests();
+    }
+
+    // ---- epilogue.  D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 4; ++i)
+#pragma clang loop unroll(full)
+      for (int jn = 0; jn < 2; ++jn) {
+        const f32x16 a = acc[i][jn];
+        const int n = en0 + wc * 64 + jn * 32 + l31;
+        const int mb = em0 + wr * 128 + i * 32 + 4 * hi;
+        if (e.splits > 1) {
+          float* slab = e.partial + (size_t)blockIdx.y * e.M * e.N;
+#pragma clang loop unroll(full)
+          for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            if (m < e.M && n < e.N) slab[(size_t)m * e.N + n] = a[r];
+          }
+        } else {
+          epilogue_tile32<bf16_t>(e, mb, n, a);
+        }
+      }
+    if (!more_tiles) break;
+  }
 }
 
 }  // namespace
@@ -310,14 +344,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const bf16_t* __r
 int srgpt_gemm256_launch(const void* A, const void* W, int K, int lda, const Epilogue& e, hipStream_t s) {
   const int gx = cdiv(e.N, G_BN), gy = cdiv(e.M, G_BM);
   const bool w8 = e.wscale != nullptr;  // fp8 weight bytes + per-row scales
-#define G_LAUNCH(W8V)                                                                                                     \
+  // persistent form: more tiles than CUs and no split-K -- one block per CU (a multiple of 8: the XCD runs), each walks its tiles
+  const int cus = srgpt_device_cus() & ~7;
+  const bool persist = e.splits <= 1 && gx * gy > cus && cus >= 8 && SRGPT_KNOB("SRGPT_GEMM_PERSIST", 1) != 0;
+#define G_LAUNCH(W8V, PV)                                                                                                 \
   do {                                                                                                                    \
     static std::atomic<uint64_t> attr_done{0};                                                                            \
-    SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)gemm_bf16_256_kernel<W8V>, G_LDS));                            \
-    hipLaunchKernelGGL((gemm_bf16_256_kernel<W8V>), dim3(gx * gy, e.splits > 1 ? e.splits : 1), dim3(512), G_LDS, s,      \
-                       (const bf16_t*)A, W, K, lda, e, gx, gy);                                                           \
+    SRGPT_TRY(srgpt_ensure_dyn_lds(attr_done, (const void*)gemm_bf16_256_kernel<W8V, PV>, G_LDS));                        \
+    hipLaunchKernelGGL((gemm_bf16_256_kernel<W8V, PV>), dim3(PV ? cus : gx * gy, e.splits > 1 ? e.splits : 1), dim3(512), \
+                       G_LDS, s, (const bf16_t*)A, W, K, lda, e, gx, gy);                                                 \
   } while (0)
-  if (w8) G_LAUNCH(true); else G_LAUNCH(false);
+  if (persist) {
+    if (w8) G_LAUNCH(true, true); else G_LAUNCH(false, true);
+  } else {
+    if (w8) G_LAUNCH(true, false); else G_LAUNCH(false, false);
+  }
 #undef G_LAUNCH
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;

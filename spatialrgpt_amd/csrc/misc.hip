@@ -147,6 +147,41 @@ __global__ void rope_kv_append_kernel(T* __restrict__ qkv, T* __restrict__ kcach
   }
 }
 
+
+// Beam search: the live KV-cache rows follow the beams the search kept (HF `_reorder_cache`, which the reference inherits through
+// GenerationMixin.beam_search / beam_sample at llava_llama.py:212).  In place, ONE launch for K and V: a thread owns 16 bytes of one
+// cached position of one (layer, kv head) and moves them for ALL beams of a batch item -- every source row is in its registers
+// before any destination row is written, and beam indices never leave their batch item, so no block depends on another.
+template <int NB>
+__global__ __launch_bounds__(256) void kv_beam_reorder_kernel(unsigned char* __restrict__ kc, unsigned char* __restrict__ vc,
+                                                              const int64_t* __restrict__ beam_idx, int rows, int Hkv, int max_pos,
+                                                              int row16 /* 16-byte pieces per cached position */, int live) {
+  const int item = blockIdx.y, hl = blockIdx.z;  // batch item; (layer * Hkv + head)
+  const int layer = hl / Hkv, head = hl - layer * Hkv;
+  const long long piece = (long long)blockIdx.x * 256 + threadIdx.x;  // over live * row16
+  if (piece >= (long long)live * row16) return;
+  int src[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) src[j] = (int)beam_idx[item * NB + j];
+  const size_t row_stride = (size_t)Hkv * max_pos * row16, layer_stride = (size_t)rows * row_stride;
+  const size_t base = (size_t)layer * layer_stride + (size_t)head * max_pos * row16 + (size_t)piece;
+  u32x4* k16 = reinterpret_cast<u32x4*>(kc);
+  u32x4* v16 = reinterpret_cast<u32x4*>(vc);
+  u32x4 kk[NB], vv[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    kk[j] = k16[base + (size_t)src[j] * row_stride];
+    vv[j] = v16[base + (size_t)src[j] * row_stride];
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (src[j] != item * NB + j) {  // (a beam that continues its own row has nothing to move)
+      k16[base + (size_t)(item * NB + j) * row_stride] = kk[j];
+      v16[base + (size_t)(item * NB + j) * row_stride] = vv[j];
+    }
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, NAME, ...)                   \
@@ -167,6 +202,34 @@ extern "C" int srgpt_embed_rows(const void* table, const int64_t* ids, void* out
   SRGPT_CHECK(cols % (dtype == SRGPT_BF16 ? 8 : 4) == 0, SRGPT_ERR_ARG, "srgpt_embed_rows: cols not 16-byte multiple");
 #define L() hipLaunchKernelGGL(embed_rows_kernel<T>, dim3(n), dim3(256), 0, as_stream(stream), (const T*)table, ids, (T*)out, cols)
   DISPATCH_T(dtype, L);
+#undef L
+  SRGPT_LAUNCH_CHECK();
+  return SRGPT_OK;
+}
+
+extern "C" int srgpt_kv_beam_reorder(void* kcache, void* vcache, const int64_t* beam_idx, int layers, int batch, int num_beams,
+                                     int kv_heads, int max_pos, int head_dim, int live, int dtype, srgpt_stream_t stream) {
+  SRGPT_CHECK(kcache && vcache && beam_idx, SRGPT_ERR_ARG, "srgpt_kv_beam_reorder: null pointer");
+  SRGPT_CHECK(layers > 0 && batch > 0 && kv_heads > 0 && max_pos > 0 && head_dim > 0 && live >= 0 && live <= max_pos, SRGPT_ERR_ARG,
+              "srgpt_kv_beam_reorder: bad shape");
+  const int eb = dtype == SRGPT_BF16 ? 2 : dtype == SRGPT_F32 ? 4 : 0;
+  SRGPT_CHECK(eb != 0 && (head_dim * eb) % 16 == 0, SRGPT_ERR_ARG, "srgpt_kv_beam_reorder: rows must be whole 16-byte pieces");
+  SRGPT_CHECK(num_beams >= 2 && num_beams <= 8, SRGPT_ERR_UNSUPPORTED, "srgpt_kv_beam_reorder: %d beams (2 ... 8)", num_beams);
+  if (live == 0) return SRGPT_OK;
+  const int row16 = head_dim * eb / 16;
+  const dim3 grid((unsigned)(((long long)live * row16 + 255) / 256), (unsigned)batch, (unsigned)(layers * kv_heads));
+#define L(NB)                                                                                                                    \
+  hipLaunchKernelGGL(kv_beam_reorder_kernel<NB>, grid, dim3(256), 0, as_stream(stream), (unsigned char*)kcache, (unsigned char*)vcache, \
+                     beam_idx, batch * num_beams, kv_heads, max_pos, row16, live)
+  switch (num_beams) {
+    case 2: L(2); break;
+    case 3: L(3); break;
+    case 4: L(4); break;
+    case 5: L(5); break;
+    case 6: L(6); break;
+    case 7: L(7); break;
+    default: L(8); break;
+  }
 #undef L
   SRGPT_LAUNCH_CHECK();
   return SRGPT_OK;

@@ -58,7 +58,8 @@ __device__ unsigned long long srgpt_skinny_stamps[16];
 constexpr int WROWB = 512 + 32;        // bytes per staged weight row: 136 dwords = 8 mod 64 banks -> the lane groups of ds_read_b128
                                        // (MI355X guide, LDS table) hit distinct banks; 528 measured 30 % conflict cycles
 constexpr int WSTAGEB = 16 * WROWB;    // weight stage per wave
-constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumulated per pass
+constexpr int MAXSU = 4;               // sub-units (16-row weight tiles) accumulated per pass (8 for one 8-wave SwiGLU block per CU that
+                                       // walks K once: measured equal, profiles/r06_skinny_gateup_8wave.txt)
 
 #ifndef SRGPT_SKINNY_DEPTH
 #define SRGPT_SKINNY_DEPTH 2           // register ring depth of weight stages (tuning builds override)

@@ -491,7 +491,8 @@ class LlavaLlamaModel:
         1: the benchmarked path is the greedy loop); `sampling` (temperature / top_k / top_p) makes it beam-SAMPLE, which is what those
         CLIs ask for under their default `--temperature 0.2`.  HF 4.37.2 semantics in spatialrgpt_amd/generation.beam_generate; here
         only the device side: every batch item's prompt is prefilled once per beam (HF's `_expand_inputs_for_generation`), each step
-        runs the HIP decode step on batch * num_beams rows, and the live KV-cache rows follow the beam indices the search picked.
+        runs the HIP decode step on batch * num_beams rows, and the live KV-cache rows follow the beam indices the search picked
+        (srgpt_kv_beam_reorder: in place, one launch).
         The beam bookkeeping itself (log-softmax, warpers, top-k / Gumbel-top-k over num_beams * vocab, a [batch, 2 * num_beams]
         hand-over to the host scorer per step) is torch: a rarely used, latency-tolerant mode -- not part of the measured path."""
         import ctypes as C
@@ -513,8 +514,9 @@ class LlavaLlamaModel:
             # temporary for K and again for V every token)
             if not torch.equal(beam_idx, ident):
                 n = max(st.host_len)
-                st.kcache[:, :, :, :n].copy_(st.kcache[:, :, :, :n].index_select(1, beam_idx))
-                st.vcache[:, :, :, :n].copy_(st.vcache[:, :, :, :n].index_select(1, beam_idx))
+                if not ops.kv_beam_reorder(st.kcache, st.vcache, beam_idx, num_beams, n):  # (> 8 beams: torch ops)
+                    st.kcache[:, :, :, :n].copy_(st.kcache[:, :, :, :n].index_select(1, beam_idx))
+                    st.vcache[:, :, :, :n].copy_(st.vcache[:, :, :, :n].index_select(1, beam_idx))
             return eng.step(st, tokens[:, None])
 
         gen = None

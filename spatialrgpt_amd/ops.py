@@ -142,6 +142,19 @@ def gemv_w8(x, w8, wscale, norm_w=None, eps=0.0, residual=None, swiglu=False, ou
     return out
 
 
+def kv_beam_reorder(kcache, vcache, beam_idx, num_beams: int, live: int) -> bool:
+    """srgpt_kv_beam_reorder: in-place permutation of the live cache rows by the beam indices (kcache / vcache [layers, batch *
+    num_beams, kv_heads, max_pos, head_dim], beam_idx int64 [batch * num_beams] on the device).  False: this beam count is not
+    served by the kernel (the caller permutes with torch ops)."""
+    if not 2 <= num_beams <= 8:
+        return False
+    _dev(kcache, vcache, beam_idx)
+    Ly, R, Hkv, P, D = kcache.shape
+    L.check(L.load().srgpt_kv_beam_reorder(_p(kcache), _p(vcache), _p(beam_idx.to(torch.int64).contiguous()), Ly, R // num_beams,
+                                           int(num_beams), Hkv, P, D, int(live), dt_code(kcache), _stream()))
+    return True
+
+
 def gemv_rowss_supported(batch: int, fp8: bool = False) -> bool:
     """does a (batch, bf16 activations, bf16 / fp8 weights) decode product take the kernel with the row-statistics hand-off?"""
     return bool(L.load().srgpt_gemv_rowss_supported(int(batch), L.BF16, int(fp8)))

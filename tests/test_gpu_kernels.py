@@ -867,3 +867,23 @@ def test_decode_attention_bits_do_not_depend_on_cache_capacity(B, Hq, Hkv, P):
         outs.append(ops.decode_attention(allq[:, P].contiguous(), kc, vc, posd, cos_t, sin_t, Hq, Hkv, D))
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+# ------------------------------------------------------------------------------------------------ beam cache permutation (ABI 9)
+@pytest.mark.parametrize("nb,B,dtype", [(2, 1, torch.bfloat16), (3, 2, torch.bfloat16), (5, 3, torch.bfloat16), (8, 1, torch.float32), (4, 2, torch.float32)])
+def test_kv_beam_reorder_equals_index_select(nb, B, dtype):
+    """srgpt_kv_beam_reorder against HF's `_reorder_cache` arithmetic (index_select over the row axis), in place, live positions only:
+    positions past `live` keep their old bytes; indices stay inside their batch item; identity rows are untouched."""
+    ops, L = _ops()
+    Ly, Hkv, P, D, live = 3, 4, 70, 128 if dtype == torch.bfloat16 else 64, 37
+    g = torch.Generator().manual_seed(nb * 10 + B)
+    kc = torch.randn((Ly, B * nb, Hkv, P, D), generator=g).to(dtype).to(DEV)
+    vc = torch.randn((Ly, B * nb, Hkv, P, D), generator=g).to(dtype).to(DEV)
+    idx = torch.cat([b * nb + torch.randint(0, nb, (nb,), generator=g) for b in range(B)]).to(DEV)
+    idx[0] = 0  # (one identity row)
+    want_k, want_v = kc.clone(), vc.clone()
+    want_k[:, :, :, :live] = kc[:, :, :, :live].index_select(1, idx)
+    want_v[:, :, :, :live] = vc[:, :, :, :live].index_select(1, idx)
+    assert ops.kv_beam_reorder(kc, vc, idx, nb, live)
+    assert torch.equal(kc, want_k) and torch.equal(vc, want_v)
+    assert not ops.kv_beam_reorder(kc, vc, torch.arange(B * nb, device=DEV), 9 if (B * nb) % 9 == 0 else 11, live)  # served by torch

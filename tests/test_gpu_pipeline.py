@@ -372,17 +372,22 @@ def test_incremental_forward_with_cached_state_equals_generate():
 
 def test_forward_returns_a_causal_lm_output_like_the_reference():
     """llava_llama.py:177-192 returns transformers' CausalLMOutputWithPast: attribute / key / index access over the fields that are
-    set, `return_dict=False` -> the tuple (loss first when labels are given), past_key_values only under use_cache,
-    attentions None (FlashAttention2 returns none either)."""
+    set, `return_dict=False` -> the tuple (loss first when labels are given), past_key_values under use_cache -- which, left None,
+    resolves to config.use_cache (True at inference) as in LlamaForCausalLM.forward --, attentions None (FlashAttention2 returns
+    none either)."""
     model, cfg, dtype, w, inp, ref = _engine("tiny_fp32.npz")
     d = _to_dev(inp)
     am = torch.ones_like(d["input_ids"])
     kw = dict(input_ids=d["input_ids"], images=d["images"], masks=d["masks"], depths=d["depths"], attention_mask=am)
-    out = model(**kw)
+    out = model(**kw, use_cache=False)
     assert out.keys() == ["logits"] and out.past_key_values is None and out.attentions is None and out.loss is None
     assert out[0] is out.logits and out["logits"] is out.logits and "loss" not in out
-    tup = model(**kw, return_dict=False)
+    tup = model(**kw, use_cache=False, return_dict=False)
     assert isinstance(tup, tuple) and len(tup) == 1 and torch.equal(tup[0], out.logits)
+    dflt = model(**kw)  # use_cache=None -> config.use_cache (True): the cache comes back, and a [B, 1] step can continue from it
+    assert dflt.keys() == ["logits", "past_key_values"] and torch.equal(dflt.logits, out.logits)
+    nxt = model(input_ids=dflt.logits[:, -1].argmax(-1, keepdim=True), past_key_values=dflt.past_key_values)
+    assert nxt.logits.shape == (1, 1, out.logits.shape[-1])
     labels = d["input_ids"].clone()
     labels[labels < 0] = -100
     o2 = model(**kw, labels=labels, use_cache=True, output_hidden_states=True, output_attentions=True)
