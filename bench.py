@@ -375,11 +375,25 @@ def main():
         wgu = eng.w.llm_q["wgu"][0] if fp8 else eng.w.llm_t["wgu"]
         wsc = eng.w.llm_q["wgu"][1] if fp8 else [None] * len(wgu)
 
+        # 2+ rows: as the batched decode step launches it -- RMSNorm statistics from the published table (srgpt_gemv_rowss), the
+        # packed (MFMA-operand-order) copy of the fp8 matrix when the engine holds one
+        use_rowss = rows > 1 and ops.gemv_rowss_supported(rows, fp8)
+        pk = getattr(eng.w, "llm_pk", {}).get("wgu") if fp8 else None
+        table = torch.zeros((rows, L.ROWSS_STRIDE), device=device)
+        table[:, 0] = x.float().pow(2).sum(-1)
+
         def gateup(i):
-            if fp8:
-                ops.gemv_w8(x, wgu[i], wsc[i], norm_w=eng.w.llm_t["mlp_norm"][i], eps=cfg.rms_eps, swiglu=True, out=outb)
+            nw = eng.w.llm_t["mlp_norm"][i]
+            if use_rowss:
+                if pk is not None:
+                    kw = dict(w8=pk[i], wscale=wsc[i], packed_rows=eng.w.pk_rows["wgu"], n_rows=wgu[i].shape[0])
+                else:
+                    kw = dict(w8=wgu[i], wscale=wsc[i]) if fp8 else dict(w=wgu[i])
+                ops.gemv_rowss(x, norm_w=nw, eps=cfg.rms_eps, swiglu=True, out=outb, rowss_in=table, **kw)
+            elif fp8:
+                ops.gemv_w8(x, wgu[i], wsc[i], norm_w=nw, eps=cfg.rms_eps, swiglu=True, out=outb)
             else:
-                ops.gemv(x, wgu[i], norm_w=eng.w.llm_t["mlp_norm"][i], eps=cfg.rms_eps, swiglu=True, out=outb)
+                ops.gemv(x, wgu[i], norm_w=nw, eps=cfg.rms_eps, swiglu=True, out=outb)
 
         for i in range(len(wgu)):  # warm (JIT-free, but first-touch TLB)
             gateup(i)
@@ -432,7 +446,7 @@ def main():
             else:
                 traffic_src = (f"none: {os.path.relpath(pmc, ROOT)} was recorded for another kernel source (sha256 "
                                f"{str(rec.get('kernel_source_sha256'))[:12]} != {kernel_source_sha256()[:12]}); re-run scripts/profile_round.sh")
-        kname = (("skinny_kernel<swiglu, W8>" if rows > 1 else "gemv_w8_kernel<swiglu>") if fp8 else
+        kname = (("skinny_kernel<swiglu, W8" + (", packed>" if pk is not None else ">") if rows > 1 else "gemv_w8_kernel<swiglu>") if fp8 else
                  ("skinny_kernel<swiglu>" if rows > 1 else f"gemv_kernel<bf16,{rows},swiglu>"))
         roof = {"bound": "hbm", "kernel": f"{kname} (decode gate/up projection at {rows} activation row(s), 54% of streamed bytes"
                                           + (", fp8 weights)" if fp8 else ")"),
