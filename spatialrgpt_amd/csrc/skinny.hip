@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (PK && W8 ? SRGPT_SKINNY_PK_WPS 
   const int cwb = min(cw, N - c0);                     // its column count (the last block may own fewer)
   const int ntile = (cwb + CPT - 1) / CPT;             // tiles, the last one possibly partial
   const int npass = (ntile + MAXU - 1) / MAXU;
-  const bool do_norm = norm_w != nullptr;
+  const bool do_norm = PUB || norm_w != nullptr;  // (published statistics are the RMSNorm's: a compile-time fact for those instances)
   const int lrow = lane >> 5, lchunk = lane & 31;  // staging loads: lane -> (row parity, 16-byte chunk of the 512-byte row piece)
   const int xchunk = lchunk;
   auto xrow_of = [&](int j) { return 2 * j + lrow; };
@@ -167,6 +167,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (PK && W8 ? SRGPT_SKINNY_PK_WPS 
     }
     gr[slot] = *reinterpret_cast<const u32x4*>((do_norm ? norm_w : x) + kg);  // unconditional: see the note on counted waits below
   };
+  // PUB instances (the decode step's RMSNorm products): 1 / rms of the rows this lane stages (rows 2 j + lrow) in registers once the
+  // statistics are known -- read from LDS inside stage_x they cost an LDS round trip + lgkmcnt(0) per row pair and slice in the K
+  // loop -- and the two roundings on element PAIRS (v_pk_mul_f32, one v_cvt_pk_bf16_f32 per rounding of a pair: 8 instead of 11
+  // VALU per two elements; same operations, same bits).  The other instances keep the scalar form: with bf16 weights their 8-row
+  // residual kernels are at the register limit and the extra live values spilled (o / down 9.2 / 22.6 -> 9.9 / 24.4 us, round 6).
+  constexpr bool REGNORM = PUB && NI <= 4;  // (16 staged rows: the registers are not there either)
+  float rsr[REGNORM ? XL : 1];
+  auto load_rs = [&]() {
+    if constexpr (REGNORM) {
+#pragma unroll
+      for (int j = 0; j < XL; ++j) rsr[j] = rs_s[xrow_of(j)];
+    }
+  };
   auto stage_x = [&](auto slot_c, int sl, bool valid) {
     constexpr int slot = decltype(slot_c)::value;
     const bool kvalid = valid && sl * SK + xchunk * 8 < K;
@@ -174,16 +187,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (PK && W8 ? SRGPT_SKINNY_PK_WPS 
     for (int j = 0; j < XL; ++j) {
       u32x4 v = xr[slot][j];
       if (do_norm) {
-        const float rsj = rs_s[xrow_of(j)];
+        if constexpr (REGNORM) {
+          const float rsj = rsr[j];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          // weight * hidden.to(dtype): two roundings, like the GEMV prologue
-          const float lo = bf16lo(gr[slot][q]) * rnd<bf16_t>(bf16lo(v[q]) * rsj);
-          const float hi = bf16hi(gr[slot][q]) * rnd<bf16_t>(bf16hi(v[q]) * rsj);
-          bf16x2 p;
-          p[0] = (bf16_t)lo;
-          p[1] = (bf16_t)hi;
-          v[q] = __builtin_bit_cast(unsigned int, p);
+          for (int q = 0; q < 4; ++q) {
+            // weight * hidden.to(dtype): two roundings, like the GEMV prologue
+            f32x2 xv = {bf16lo(v[q]), bf16hi(v[q])};
+            xv = xv * f32x2{rsj, rsj};
+            const unsigned int hb = __builtin_bit_cast(unsigned int, __builtin_convertvector(xv, bf16x2));
+            f32x2 o = f32x2{bf16lo(gr[slot][q]), bf16hi(gr[slot][q])} * f32x2{bf16lo(hb), bf16hi(hb)};
+            v[q] = __builtin_bit_cast(unsigned int, __builtin_convertvector(o, bf16x2));
+          }
+        } else {
+          const float rsj = rs_s[xrow_of(j)];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float lo = bf16lo(gr[slot][q]) * rnd<bf16_t>(bf16lo(v[q]) * rsj);
+            const float hi = bf16hi(gr[slot][q]) * rnd<bf16_t>(bf16hi(v[q]) * rsj);
+            bf16x2 p;
+            p[0] = (bf16_t)lo;
+            p[1] = (bf16_t)hi;
+            v[q] = __builtin_bit_cast(unsigned int, p);
+          }
         }
       }
       if (!kvalid) v = u32x4{0u, 0u, 0u, 0u};  // k past K contributes zeros (the weight loads there are clamped)
@@ -378,7 +403,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (PK && W8 ? SRGPT_SKINNY_PK_WPS 
 #endif
     constexpr bool TWO_ACC = NI < 8 && !SRGPT_SKINNY_ONE_ACC;  // even / odd k steps on separate accumulators (16 staged rows: the registers are not there)
     // slots of the activation ring (see load_x): as many slices ahead as the weight ring reaches
-    constexpr int XS = NSU == 1 ? DEPTH : (NSU == 2 && DEPTH == 4 ? 2 : 1);
+    // (fp8 only: with bf16 weights a stage is twice the registers and the 8-row single-tile kernel spills under a second slot --
+    //  o / down 9.2 / 22.6 -> 9.9 / 24.4 us at 8 bf16 rows, profiles/r06_skinny_norm_staging.txt)
+    constexpr int XS = !W8 ? 1 : NSU == 1 ? DEPTH : (NSU == 2 && DEPTH == 4 ? 2 : 1);
     static_assert(DEPTH % XS == 0, "the slot of a slice must be a compile-time function of its place in the trip");
     if (!x0_ready) load_x(std::integral_constant<int, 0>{}, sl_of(0));
     if constexpr (XS > 1) load_x(std::integral_constant<int, 1>{}, sl_of(min(1, max(cnt - 1, 0))));
@@ -418,9 +445,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (PK && W8 ? SRGPT_SKINNY_PK_WPS 
     };
     // pass 0: the first weight stage goes out behind the statistics' own loads (in-order return: the reduction waits for its
     // activations only), so its HBM latency overlaps the reduction and the two block barriers -- as in the GEMV's prologue
-    if (PUB && pass == 0) pub_stats([&]() { issue_w(wb[0], 0, sl_of(0), 0, cnt > 0); });
-    else if (PRE && pass == 0 && do_norm) rms_stats([&]() { issue_w(wb[0], 0, sl_of(0), 0, cnt > 0); });
-    else issue_w(wb[0], pass, sl_of(0), 0, cnt > 0);
+    if (PUB && pass == 0) {
+      pub_stats([&]() { issue_w(wb[0], 0, sl_of(0), 0, cnt > 0); });
+      load_rs();
+    } else if (PRE && pass == 0 && do_norm) {
+      rms_stats([&]() { issue_w(wb[0], 0, sl_of(0), 0, cnt > 0); });
+      load_rs();
+    } else {
+      issue_w(wb[0], pass, sl_of(0), 0, cnt > 0);
+    }
 #pragma unroll
     for (int f = 1; f < DEPTH - 1; ++f)
       issue_w(wb[f % DEPTH], pass, sl_of(f / NSU), f % NSU, f / NSU < cnt);
@@ -560,7 +593,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (PK && W8 ? SRGPT_SKINNY_PK_WPS 
     __syncthreads();  // the reduction buffer aliases the wave-private stages of the next pass
   };
 
-  if (!PUB && !PRE && do_norm) rms_stats([]() {});
+  if (!PUB && !PRE && do_norm) {
+    rms_stats([]() {});
+    load_rs();
+  }
   for (int pass = 0; pass < npass; ++pass) {
     int nu = 0;
 #pragma unroll
