@@ -787,7 +787,9 @@ int srgpt_decode_attention_pf(const void* qkv, void* kcache, void* vcache, const
   // launch -- the whole 16.8-MB matrix fits the 32 MB of L2; SRGPT_DECODE_PREFETCH_TILES = loads a prefetch wave keeps in flight (0: off)
   const int pf_tiles = SRGPT_KNOB("SRGPT_DECODE_PREFETCH_TILES", 0);
   const DecodePrefetch pf = dtype != SRGPT_BF16 ? srgpt_prefetch_for_gemv(nullptr, 0, 0, 0, 0, B, 0, 0)
-                            : (next_packed_rows == 16 && B > 1) ? srgpt_prefetch_for_packed_tiles(next_w, next_n, next_k, next_fp8 ? 1 : 2, pf_tiles)
+                            // (16 consecutive rows of a ROW-MAJOR matrix are one contiguous tile too: block p of the batched product
+                            //  streams rows 16 p .. 16 p + 15)
+                            : ((next_packed_rows == 16 || next_packed_rows == 0) && B > 1) ? srgpt_prefetch_for_packed_tiles(next_w, next_n, next_k, next_fp8 ? 1 : 2, pf_tiles)
                                                                 : srgpt_prefetch_for_gemv(next_w, next_n, next_k, 0, next_fp8, B, pf_rounds, 0);
   if (dtype == SRGPT_BF16)
     return launch_decode<bf16_t>(qkv, kcache, vcache, pos, cos_tab, sin_tab, out, ws, B, Hq, Hkv, D, max_pos, pf,

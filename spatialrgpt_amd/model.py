@@ -297,9 +297,16 @@ class LlavaLlamaModel:
         return self.engine.embed_tokens
 
     def resize_token_embeddings(self, embed_size):
+        """llava_arch.py accessor -> HF `resize_token_embeddings` (the reference's loader calls it on the live model after adding
+        `<mask>` / `<depth>`, builder.py:186-199): embed_tokens and lm_head to `embed_size` rows, common rows kept, new rows = the mean
+        of the old ones (as the loader initialises the rows it adds).  Pooled decode states (their logits rows are vocabulary-sized) are dropped; a `past_key_values` handle
+        returned before the resize must not be stepped afterwards."""
+        embed_size = int(embed_size)
         if embed_size != self.engine.w.vocab:
-            raise NotImplementedError("resize_token_embeddings after load is not supported; the loader sizes the "
-                                      "embedding for the added <mask>/<depth> tokens")
+            self.engine.w.resize_vocab(embed_size)
+            self.engine._state = None
+            self.config.vocab_size = embed_size
+        return self.engine.embed_tokens
 
     def freezed_module_patch(self):
         return None

@@ -248,6 +248,43 @@ class PreparedWeights:
         self.llm = lw
         self.vocab = self.embed.shape[0]
 
+    def resize_vocab(self, n: int) -> None:
+        """HF `resize_token_embeddings` on the live weights (the reference's loader calls it after adding `<mask>` / `<depth>`,
+        builder.py:186-199 -> PreTrainedModel._get_resized_embeddings / _get_resized_lm_head): embed_tokens and lm_head grow or shrink to
+        `n` rows, the common rows are kept, new rows = the mean of the old rows -- what spatialrgpt_amd.builder gives the rows it adds
+        at load (transformers' mean-resizing; 4.37.2 drew them N(0, initializer_range): untrained rows either way).
+        fp8 lm_head: the new rows are quantised with the loader's rule and appended."""
+        old = self.embed.shape[0]
+        if n == old:
+            return
+        if n <= 0:
+            raise ValueError(f"resize_token_embeddings({n})")
+        keep = min(old, n)
+
+        def resized(t):
+            out = torch.empty((n, t.shape[1]), device=t.device, dtype=t.dtype)
+            out[:keep] = t[:keep]
+            if n > keep:
+                out[keep:] = t.float().mean(0, keepdim=True).to(t.dtype)
+            return out
+
+        self.embed = resized(self.embed)
+        lw = self.llm
+        if self.llm_q is None:
+            self.lm_head = resized(self.lm_head)
+            lw.lm_head = self.lm_head.data_ptr()
+        else:
+            from . import ops
+            q8, sc = self.lm_head8[:keep], self.lm_head_scale[:keep]
+            if n > keep:
+                fresh = self.dequantised("lm_head").float().mean(0, keepdim=True).to(self.dtype).expand(n - keep, -1).contiguous()
+                nq, nsc, _ = ops.quantize_fp8_rows(fresh)
+                q8, sc = torch.cat([q8, nq], 0), torch.cat([sc, nsc], 0)
+            self.lm_head8, self.lm_head_scale = q8.contiguous(), sc.contiguous()
+            lw.lm_head8, lw.lm_head_scale = self.lm_head8.data_ptr(), self.lm_head_scale.data_ptr()
+        lw.embed, lw.vocab = self.embed.data_ptr(), n
+        self.vocab = n
+
     def dequantised(self, name: str, layer: int = 0) -> torch.Tensor:
         """bf16 values of an fp8-held matrix ("wqkv" | "wo" | "wgu" | "wdown" | "lm_head"): code * scale, exact in bf16."""
         if self.llm_q is None:

@@ -348,3 +348,37 @@ def test_component_factories_compose_to_the_whole_model_bit_for_bit():
     assert torch.equal(proj2(lres), image_features)
     rex3 = AutoModel.from_pretrained(os.path.join(root, "region_extractor"), torch_dtype=torch.float32)
     assert torch.equal(rex3.feature_refinement(tower_features)[0], hres)
+
+
+@pytest.mark.parametrize("fmt", ["native", "fp8"])
+def test_resize_token_embeddings_on_the_live_model(fmt):
+    """builder.py:199 calls `model.resize_token_embeddings(len(tokenizer))` on the LIVE model: embed_tokens and lm_head follow (common
+    rows kept bit for bit, new rows = the mean row), generation runs with ids in the new range, shrinking back restores the logits."""
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.model import LlavaLlamaModel
+    from spatialrgpt_amd.weights import synth_state_dict
+
+    cfg = SrgptConfig(vit_hidden=64, vit_inter=176, vit_layers=2, vit_heads=4, image_size=42, patch_size=14, hidden=128, inter=256,
+                      layers=2, heads=4, kv_heads=2, vocab=300, mask_token_id=298, depth_token_id=299)
+    dt = torch.bfloat16
+    model = LlavaLlamaModel(cfg, synth_state_dict(cfg, seed=4, dtype=dt, device="cuda"), device="cuda", dtype=dt, rope_positions=128,
+                            llm_weight_format=fmt)
+    w = model.engine.w
+    ids = torch.tensor([[1, 17, 45, 250, 7]], device="cuda")
+    am = torch.ones_like(ids)
+    base = model(input_ids=ids, attention_mask=am, use_cache=False).logits.clone()
+    emb0 = w.embed.clone()
+    head0 = (w.dequantised("lm_head") if fmt == "fp8" else w.lm_head).clone()
+    model.resize_token_embeddings(305)
+    assert w.vocab == 305 == w.embed.shape[0] and model.config.vocab_size == 305
+    assert torch.equal(w.embed[:300], emb0) and torch.equal(w.embed[300:], emb0.float().mean(0, keepdim=True).to(dt).expand(5, -1))
+    head1 = w.dequantised("lm_head") if fmt == "fp8" else w.lm_head
+    assert head1.shape[0] == 305 and torch.equal(head1[:300], head0)
+    grown = model(input_ids=ids, attention_mask=am, use_cache=False).logits
+    assert grown.shape[-1] == 305 and torch.equal(grown[..., :300], base)
+    out = model.generate(torch.tensor([[1, 304, 302, 9]], device="cuda"), do_sample=False, max_new_tokens=3, eos_token_id=None)
+    assert out.shape == (1, 3) and int(out.max()) < 305
+    model.resize_token_embeddings(300)
+    assert torch.equal(model(input_ids=ids, attention_mask=am, use_cache=False).logits, base)
+    with pytest.raises(IndexError):
+        model.generate(torch.tensor([[1, 302]], device="cuda"), do_sample=False, max_new_tokens=1)
