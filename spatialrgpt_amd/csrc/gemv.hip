@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void gemv_kernel(const T* __restrict__ x, c
 // slots (NIT is a template parameter: static register indexing, exact batch sizes).  Residual elements of the wave's first
 // units are fetched up front by lanes 0..3 and broadcast with a shuffle.
 // ------------------------------------------------------------------------------------------------
-template <bool SWIGLU, bool NORM, int NIT>
+template <bool SWIGLU, bool NORM, int NIT, int UB = 8>
 __global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
                                                           const bf16_t* __restrict__ norm_w, float norm_eps,
                                                           const bf16_t* __restrict__ residual, void* __restrict__ out, int N,
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restri
   typedef bf16_t T;
   constexpr int VEC = 8;
   constexpr int R = SWIGLU ? 2 : 1;
-  constexpr int U = 8 / R;
+  constexpr int U = UB / R;
   constexpr int RES_MAXU = 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunks = K / VEC;
@@ -383,6 +383,12 @@ __global__ __launch_bounds__(256, 2) void gemv_reg_kernel(const bf16_t* __restri
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    if constexpr (NIT > 16) {
+      // long rows: the activations are loop-invariant, and left alone the compiler hoists their bf16 -> fp32 unpacking out of the
+      // unit loop -- twice the registers for x (224 at K = 14336) and the kernel spills; opaque per unit, the packed form stays
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) asm volatile("" : "+v"(xp[j]));
+    }
     auto batch = [&](auto it0_c) {
       constexpr int it0 = decltype(it0_c)::value;
 #if !SRGPT_GEMV_REG_PIPE
@@ -449,6 +455,11 @@ bool launch_gemv_reg(int nit, int grid, hipStream_t s, const void* x, const void
     SRGPT_REG_CASE(8);   // K = 4096
     SRGPT_REG_CASE(14);  // K = 6912
     default: break;
+  }
+  if (!SWIGLU && !NORM && nit == 28 && SRGPT_KNOB("SRGPT_GEMV_REG_LONG", 0)) {  // K = 14336 (tuning builds): 112 VGPRs of activations, batches of 7
+    hipLaunchKernelGGL((gemv_reg_kernel<false, false, 28, 7>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)W,
+                       (const bf16_t*)norm_w, eps, (const bf16_t*)residual, out, N, K, out_f32);
+    return true;
   }
   return false;  // longer rows (K = 11008, 14336: 88-112 VGPRs of activations, spills when unrolled) stay on the LDS kernel
 #undef SRGPT_REG_CASE
