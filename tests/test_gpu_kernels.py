@@ -787,7 +787,7 @@ def test_decode_step_equals_per_op_composition_bit_for_bit(geom):
     assert L.load().srgpt_llm_decode_sync_state(C.byref(w.llm), C.byref(st.c), ops._stream()) == 0, L.last_error()
 
 
-@pytest.mark.parametrize("B,fp8", [(2, False), (8, False), (8, True), (3, True), (20, False)])
+@pytest.mark.parametrize("B,fp8", [(2, False), (8, False), (8, True), (3, True), (20, False), (20, True)])
 def test_batched_decode_step_equals_rowss_composition_bit_for_bit(B, fp8):
     """The batched decode step (2+ rows: o_proj / down_proj publish the rows' sums of squares, the next RMSNorm reads them) must be
     BIT-identical to the same layers composed from srgpt_gemv_rowss + srgpt_decode_attention, step after step; layer 0's q/k/v
