@@ -1,0 +1,112 @@
+"""Seeded random REQUESTS through the whole path -- both tower passes, refinement, pooling, projector, splice, prefill, greedy
+decode -- against the oracle on the CPU (fp32, tiny widths, the true 27 x 27 patch grid): batches of 1..4 prompts with a text-only
+prompt among them, 0..4 regions per image, `masks[i] = None`, `depths=None`, ragged prompt lengths under LEFT padding (the one
+ragged form in which HF's `logits[:, -1]` is every row's own last token: llava_arch.py:575-600, modeling_llama.py:1127-1133).
+The fixtures pin single shapes; this sweeps the combinations.  SRGPT_FUZZ_CASES=<n> widens the sweep (default 10 cases)."""
+import os
+
+import pytest
+import torch
+
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+IMAGE_TOKEN_INDEX = -200
+CFG = dict(vit_hidden=64, vit_inter=176, vit_layers=2, vit_heads=4, image_size=378, patch_size=14, hidden=64, inter=160, layers=2,
+           heads=4, kv_heads=2, vocab=128, mask_token_id=120, depth_token_id=121, rope_theta=500000.0)
+G = 5
+
+
+def _request(seed):
+    """-> dict(input_ids [B,P], attention_mask | None, images [Nimg,3,S,S], depths | None, masks list(len Nimg), side)"""
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    S = CFG["image_size"]
+    B = ri(1, 4)
+    have_depths = ri(0, 4) != 0
+    rows, masks = [], []
+    has_img = [ri(0, 4) != 0 for _ in range(B)]
+    if not any(has_img):
+        has_img[ri(0, B - 1)] = True
+    for b in range(B):
+        txt = lambda n: torch.randint(3, 118, (n,), generator=g).tolist()  # noqa: E731
+        seq = [1] + txt(ri(1, 6))
+        if has_img[b]:
+            seq += [IMAGE_TOKEN_INDEX] + txt(ri(0, 4))
+            k = ri(0, 4)
+            none_entry = k == 0  # no regions: None (an EMPTY mask tensor raises in the reference's F.interpolate, base_extractor.py:53-58)
+            m = torch.zeros((k, S, S))
+            for r in range(k):
+                hh, ww = ri(S // 8, S // 2), ri(S // 8, S // 2)
+                y0, x0 = ri(0, S - hh), ri(0, S - ww)
+                m[r, y0:y0 + hh, x0:x0 + ww] = 1.0
+                seq += txt(ri(0, 3)) + [CFG["mask_token_id"]] + ([CFG["depth_token_id"]] if have_depths else [])
+            masks.append(None if none_entry else m)
+        seq += txt(ri(1, 5))
+        rows.append(seq)
+    P = max(len(r) for r in rows)
+    ragged = any(len(r) != P for r in rows)
+    ids = torch.zeros((B, P), dtype=torch.long)
+    am = torch.zeros((B, P), dtype=torch.bool)
+    for b, r in enumerate(rows):  # left padding
+        ids[b, P - len(r):] = torch.tensor(r)
+        am[b, P - len(r):] = True
+    n_img = sum(has_img)
+    images = (torch.randn((n_img, 3, S, S), generator=g).clamp_(-1, 1) * 32).round().div(32)
+    depths = None
+    if have_depths:
+        depths = (torch.randn((n_img, 1, S, S), generator=g).clamp_(-1, 1) * 32).round().div(32).expand(-1, 3, -1, -1).contiguous()
+    return dict(input_ids=ids, attention_mask=am if (ragged or ri(0, 1)) else None, images=images, depths=depths, masks=masks,
+                text_only_rows=[b for b in range(B) if not has_img[b]])
+
+
+@pytest.fixture(scope="module")
+def pair():
+    from oracle import srgpt_oracle as so
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.model import LlavaLlamaModel
+
+    ocfg = so.SrgptConfig(**CFG, padding_side="left")
+    w = so.synth_weights(ocfg, seed=11, dtype=torch.float32, std=0.08)  # wider than N(0, 0.02): decisions with margins
+    model = LlavaLlamaModel(SrgptConfig(**CFG, padding_side="left"), dict(w), device=DEV, dtype=torch.float32, rope_positions=512)
+    return so, ocfg, w, model
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SRGPT_FUZZ_CASES", "10")))))
+def test_random_request_equals_the_oracle(pair, seed):
+    so, ocfg, w, model = pair
+    r = _request(1000 + seed)
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    ids_o, st = so.generate(w, ocfg, r["input_ids"], r["images"], r["depths"], r["masks"], r["attention_mask"], max_new_tokens=G,
+                            eos_token_id=None, return_stages=True)
+    # (1) the spliced embeddings and mask
+    emb, am, _ = model.engine.prepare_inputs(dev(r["input_ids"]), dev(r["images"]), dev(r["depths"]), [dev(m) for m in r["masks"]],
+                                             dev(r["attention_mask"]))
+    ref = st["inputs_embeds"]
+    assert emb.shape == ref.shape, (emb.shape, ref.shape)
+    assert_close(emb, ref, 2e-4 * float(ref.abs().max()), 0, f"seed {seed}: inputs_embeds")
+    # (2) greedy ids: equal, or first different where the oracle's own top-2 margin is inside the fp32 tolerance of the logits
+    out = model.generate(dev(r["input_ids"]), images=dev(r["images"]), depths=dev(r["depths"]), masks=[dev(m) for m in r["masks"]],
+                         attention_mask=dev(r["attention_mask"]), do_sample=False, max_new_tokens=G, eos_token_id=None).cpu()
+    assert out.shape == ids_o.shape
+    sl = st["step_logits"]  # [B, G, V]
+    tol = 4e-4 * float(sl.abs().max())
+    for b in range(out.shape[0]):
+        for t in range(G):
+            if int(out[b, t]) != int(ids_o[b, t]):
+                top2 = sl[b, t].topk(2).values
+                assert float(top2[0] - top2[1]) <= tol, f"seed {seed}: row {b} step {t}: {out[b].tolist()} vs {ids_o[b].tolist()}"
+                break  # a flipped near-tie changes every later input of this row
+
+
+def test_an_empty_mask_tensor_raises_like_the_reference(pair):
+    """`masks[i]` with zero regions is `None` in the reference's callers; an EMPTY [0, S, S] tensor makes its MaskPooling raise a
+    RuntimeError (F.interpolate on an empty batch, base_extractor.py:53-58) -- here too, instead of a silent no-region image."""
+    so, ocfg, w, model = pair
+    r = _request(1006)  # one prompt, one image
+    empty = [torch.zeros((0, CFG["image_size"], CFG["image_size"]))]
+    with pytest.raises(RuntimeError):
+        so.prepare_inputs(w, ocfg, r["input_ids"], r["images"], r["depths"], empty, r["attention_mask"])
+    with pytest.raises(RuntimeError):
+        model.engine.prepare_inputs(r["input_ids"].to(DEV), r["images"].to(DEV), r["depths"].to(DEV), [empty[0].to(DEV)], None)
