@@ -1,0 +1,89 @@
+"""Seeded random SHAPES through the kernel families' checks of tests/test_gpu_kernels.py (the same checkers: fp32 torch / the oracle's
+functions on the CPU, the same tolerances) -- the parametrised lists there pin the shapes the dispatch rules were written around; this
+draws the ones nobody thought of (ragged N, K tails of every tile size, odd head counts, cache lengths at no boundary), within each
+entry point's documented constraints (include/srgpt.h).  SRGPT_FUZZ_CASES=<n> widens the sweep (default 6 draws per family)."""
+import os
+
+import pytest
+import torch
+
+from tests import test_gpu_kernels as tk
+
+pytestmark = pytest.mark.gpu
+N_CASES = int(os.environ.get("SRGPT_FUZZ_CASES", "6"))
+
+
+def _draw(seed):
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    pick = lambda xs: xs[ri(0, len(xs) - 1)]  # noqa: E731
+    return ri, pick
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_gemm_random_shapes(seed):
+    ri, pick = _draw(7000 + seed)
+    dtype = pick([torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.float32])
+    M = pick([ri(1, 64), ri(65, 400), ri(225, 272), ri(384, 1600), ri(1, 3000)])
+    N = pick([ri(1, 300), ri(100, 5000), 8 * ri(1, 1200)])
+    K = (8 if dtype == torch.bfloat16 else 4) * pick([ri(1, 40), ri(8, 600), ri(100, 1800)])
+    if M * N > 6_000_000:
+        N = max(1, 6_000_000 // M)
+    tk._gemm_case(dtype, M, N, K)
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_gemv_random_shapes(seed):
+    ri, pick = _draw(7100 + seed)
+    dtype = pick([torch.bfloat16, torch.bfloat16, torch.float32])
+    B = pick([1, 1, ri(2, 4), ri(5, 16), ri(17, 33)])
+    K = 8 * pick([ri(1, 64), ri(32, 700), ri(256, 1800)])
+    while B * K * (2 if dtype == torch.bfloat16 else 4) > 140 * 1024 and B <= 4:  # the VALU kernel stages all rows in LDS
+        K -= 512
+    N = pick([ri(1, 200), ri(100, 9000), ri(1000, 40000)])
+    tk.test_gemv_variants(dtype, B, N, K)
+    tk.test_gemv_swiglu(dtype, B, max(1, N // 2), K)
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_gemv_w8_random_shapes(seed):
+    ri, pick = _draw(7200 + seed)
+    B = pick([1, ri(2, 4), ri(5, 8), ri(9, 16), ri(17, 24)])
+    K = 8 * pick([ri(2, 64), ri(32, 700), ri(256, 1800)])
+    N = pick([ri(1, 200), ri(100, 9000), ri(1000, 33000)])
+    tk.test_gemv_w8_variants(B, N, K)
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_attention_random_shapes(seed):
+    ri, pick = _draw(7300 + seed)
+    dtype = pick([torch.bfloat16, torch.bfloat16, torch.float32])
+    Hkv = ri(1, 4)
+    Hq = Hkv * pick([1, 1, 2, 3, 4, 8])
+    D = pick([16, 32, 64, 72, 80, 96, 128])
+    causal = bool(ri(0, 1))
+    Tk = pick([ri(1, 70), ri(60, 800), ri(700, 2300)])
+    Tq = Tk if (not causal or ri(0, 2)) else ri(1, Tk)
+    B = ri(1, 3) if Tk < 900 else 1
+    tk.test_attention(dtype, B, Tq, Tk, Hq, Hkv, D, causal)
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_decode_attention_random_shapes(seed):
+    ri, pick = _draw(7400 + seed)
+    dtype = pick([torch.bfloat16, torch.bfloat16, torch.float32])
+    Hkv = ri(1, 8)
+    Hq = Hkv * pick([1, 2, 4, 8])
+    D = pick([16, 32, 64, 128, 128, 128])
+    max_pos = pick([512, 1024, 2048, 4096])
+    P = pick([ri(0, 70), ri(0, max_pos - 1), ri(max_pos // 2, max_pos - 1)])
+    B = ri(1, 4) if P < 1500 else 1
+    tk.test_rope_append_and_decode_attention(dtype, B, Hq, Hkv, D, P, max_pos)
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_norms_random_shapes(seed):
+    ri, pick = _draw(7500 + seed)
+    dtype = pick([torch.bfloat16, torch.float32])
+    cols = (8 if dtype == torch.bfloat16 else 4) * pick([ri(1, 40), ri(30, 700), ri(500, 2000)])
+    tk.test_layernorm_rmsnorm(dtype, ri(1, 300), cols)
