@@ -137,8 +137,8 @@ int srgpt_gemm_w8a8(const void* A8, const float* ascale, const void* W8, const f
                     const void* residual, void* C, int M, int N, int K, int lda, int ldc, int out_f32, void* ws,
                     int64_t ws_bytes, srgpt_stream_t stream);
 
-/* Decode-only fused GEMVs (any batch; one bf16 / fp8 row: VALU kernel, 2+ rows: MFMA kernel, 16 rows per weight pass), weights
- * streamed once from HBM:
+/* Decode-only fused GEMVs (any batch; one bf16 / fp8 row: VALU kernel, 2+ rows: MFMA kernel, 16 rows per weight pass -- all rows of
+ * one call on the same kernel), weights streamed once per pass from HBM:
  *   norm_w != NULL : x <- RMSNorm(x) * norm_w first (modeling_llama.py:61-75) (rounded to dtype like torch)
  *   swiglu != 0    : W = [gate rows(N); up rows(N)], out[n] = silu(gate.x) * (up.x) (modeling_llama.py:221)
  *   residual       : out = residual + (W x)   (decoder layer residual adds, modeling_llama.py:650-684)

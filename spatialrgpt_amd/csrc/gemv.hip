@@ -535,7 +535,8 @@ int dispatch_b(const void* x, const void* W, const void* norm_w, float eps, cons
       const void* xb = (const char*)x + (size_t)b0 * K * sizeof(T);
       const void* rb = residual ? (const char*)residual + (size_t)b0 * N * sizeof(T) : nullptr;
       void* ob = (char*)out + (size_t)b0 * N * on;
-      if (mfma && (nb > 4 || nb >= skinny_min))
+      // (a single-row tail of a longer batch -- 17, 33 rows -- stays on the kernel its other rows took, as srgpt_gemv_rowss does)
+      if (mfma && (nb > 4 || nb >= skinny_min || b0 > 0))
         SRGPT_TRY(srgpt_skinny_launch(xb, W, norm_w, eps, rb, ob, nb, N, K, swiglu, out_f32, nullptr, nullptr, 0, s));
       else
         SRGPT_TRY((dispatch_b<T>(xb, W, norm_w, eps, rb, ob, nb, N, K, swiglu, out_f32, s)));

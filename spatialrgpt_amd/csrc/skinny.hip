@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (PK && W8 ? SRGPT_SKINNY_PK_WPS 
   u32x4 xr[XSMAX][XL];
   u32x4 gr[XSMAX];
   auto load_x = [&](auto slot_c, int sl) {
-    constexpr int slot = decltype(slot_c)::value;
+    constexpr int slot = decltype(slot_c)::value < XSMAX ? decltype(slot_c)::value : 0;  // (slots >= XS are never requested: the clamp only keeps -Warray-bounds quiet about discarded calls)
     int kg = min(sl * SK + xchunk * 8, K - 8);
     asm volatile("" : "+v"(kg));  // keep the row products out of loop-invariant registers (see issue_w)
 #pragma unroll

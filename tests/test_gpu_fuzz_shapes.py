@@ -87,3 +87,48 @@ def test_norms_random_shapes(seed):
     dtype = pick([torch.bfloat16, torch.float32])
     cols = (8 if dtype == torch.bfloat16 else 4) * pick([ri(1, 40), ri(30, 700), ri(500, 2000)])
     tk.test_layernorm_rmsnorm(dtype, ri(1, 300), cols)
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_fused_gemm_random_shapes(seed):
+    """the one-call forms against their two launches, BIT for bit, wherever the dispatch sends the shape"""
+    ri, pick = _draw(7600 + seed)
+    dtype = pick([torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.float32])
+    M = pick([ri(1, 64), ri(65, 400), ri(225, 272), ri(384, 1500)])
+    K = 8 * pick([ri(1, 40), ri(8, 600), ri(100, 1800)])
+    N = 8 * pick([ri(1, 64), ri(32, 1100), ri(512, 2100)])
+    while M * N > 4_000_000:
+        N //= 2
+    N = max(8, N // 8 * 8)
+    tk.test_gemm_norm_equals_the_two_launches(dtype, M, N, K, bool(ri(0, 1)))
+    tk.test_gemm_swiglu_equals_the_two_launches(dtype, M, max(8, N // 16 * 8), K)  # srgpt_silu_mul: rows of whole 16-byte chunks
+    Hkv = ri(1, 4)
+    Hq, D = Hkv * pick([1, 2, 4, 8]), pick([32, 64, 128])
+    B = ri(1, 3)
+    T = pick([ri(1, 40), ri(30, 300), ri(225, 272)])
+    tk.test_gemm_rope_kv_append_equals_the_two_launches(dtype, B, T, Hq, Hkv, D, min(K, 4096), bool(ri(0, 1)))
+    if dtype == torch.bfloat16:
+        tk.test_gemm_w8_equals_gemm_on_dequantised_weights(M, N, K)
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_row_statistics_and_packed_layout_random_shapes(seed):
+    ri, pick = _draw(7700 + seed)
+    fp8 = bool(ri(0, 1))
+    B = pick([ri(2, 4), ri(5, 8), ri(9, 16), ri(17, 20)])
+    N = 64 * pick([ri(1, 16), ri(8, 100)])        # the consumer's K: whole 64-k blocks (fp8) / 32-k blocks (bf16)
+    K = 64 * pick([ri(1, 16), ri(8, 230)])
+    rows = pick([4, 8, 16])
+    N2 = 2 * rows * pick([ri(1, 20), ri(10, 500)])
+    tk.test_gemv_rowss_handoff(fp8, B, N, K, pick([N2, ri(1, 3000)]))
+    tk.test_gemv_rowss_packed_equals_row_major_bit_for_bit(fp8, B, N, K, N2, rows)
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_region_pool_and_loss_random_shapes(seed):
+    ri, pick = _draw(7800 + seed)
+    dtype = pick([torch.bfloat16, torch.float32])
+    fw = pick([24, 27, 48, 64, 96, 108])
+    S = fw * pick([1, 2, 3, 4]) if ri(0, 1) else pick([96, 192, 224, 336, 384, 448])
+    tk.test_region_pool_true_shape_vs_oracle(dtype, ri(1, 20), S, fw, 8 * ri(1, 160))
+    tk.test_cross_entropy_vs_torch(ri(1, 80), pick([ri(2, 300), ri(300, 40000), 128258]))

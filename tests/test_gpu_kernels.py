@@ -361,7 +361,8 @@ def test_gemv_w8_swiglu(B, N, K):
 # ------------------------------------------------------------------------------------------------ row-statistics hand-off (ABI 8)
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("B,N,K,N2", [(2, 4096, 4096, 6144), (8, 4096, 14336, 28672 // 2), (4, 2560, 6912, 1000), (16, 4096, 4096, 333),
-                                      (5, 1000, 1024, 130), (20, 520, 264, 77), (3, 4104, 512, 40)])
+                                      (5, 1000, 1024, 130), (20, 520, 264, 77), (3, 4104, 512, 40),
+                                      (17, 576, 1280, 1040)])  # 16 rows + a single-row tail: the tail stays on the MFMA kernel in srgpt_gemv too (found by tests/test_gpu_fuzz_shapes.py)
 def test_gemv_rowss_handoff(fp8, B, N, K, N2):
     """srgpt_gemv_rowss: (1) the table a residual product publishes sums, per row, to sum(out^2) of the bf16 rows it wrote -- slots
     past its grid zero; (2) the output itself is srgpt_gemv's, bit for bit; (3) a consumer normalising from that table agrees with
