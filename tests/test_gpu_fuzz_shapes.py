@@ -132,3 +132,14 @@ def test_region_pool_and_loss_random_shapes(seed):
     S = fw * pick([1, 2, 3, 4]) if ri(0, 1) else pick([96, 192, 224, 336, 384, 448])
     tk.test_region_pool_true_shape_vs_oracle(dtype, ri(1, 20), S, fw, 8 * ri(1, 160))
     tk.test_cross_entropy_vs_torch(ri(1, 80), pick([ri(2, 300), ri(300, 40000), 128258]))
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_decode_step_composition_and_invariants_random(seed):
+    """the graph-captured batched step == the per-entry composition at ANY row count (17 = 16 + a single-row tail included); decode
+    attention bits independent of the cache capacity; the beam permutation for every beam count the kernel serves"""
+    ri, pick = _draw(7900 + seed)
+    tk.test_batched_decode_step_equals_rowss_composition_bit_for_bit(pick([ri(2, 16), ri(2, 16), 17, ri(18, 24)]), bool(ri(0, 1)))
+    Hkv = pick([1, 2, 4, 8, 20])
+    tk.test_decode_attention_bits_do_not_depend_on_cache_capacity(ri(1, 3), Hkv * pick([1, 2, 4, 8] if Hkv < 20 else [1]), Hkv, ri(1, 760))  # the smallest cache of that test holds 768 positions
+    tk.test_kv_beam_reorder_equals_index_select(ri(2, 8), ri(1, 3), pick([torch.bfloat16, torch.float32]))
