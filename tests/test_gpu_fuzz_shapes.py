@@ -143,3 +143,28 @@ def test_decode_step_composition_and_invariants_random(seed):
     Hkv = pick([1, 2, 4, 8, 20])
     tk.test_decode_attention_bits_do_not_depend_on_cache_capacity(ri(1, 3), Hkv * pick([1, 2, 4, 8] if Hkv < 20 else [1]), Hkv, ri(1, 760))  # the smallest cache of that test holds 768 positions
     tk.test_kv_beam_reorder_equals_index_select(ri(2, 8), ri(1, 3), pick([torch.bfloat16, torch.float32]))
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_fp8_matrix_pipe_random_shapes(seed):
+    """W8A8 prefill pieces: the fused quantisers against their two launches (bit for bit), the fp8 GEMM against fp64 on the dequantised
+    operands (K in whole 128-k tiles, at least two)"""
+    from tests import test_gpu_fp8_mfma as tf
+    ri, pick = _draw(8000 + seed)
+    M = pick([ri(1, 64), ri(65, 400), ri(225, 300), ri(384, 2100)])
+    tf.test_quant_rows_fused_rmsnorm_is_the_two_launches_bit_for_bit(max(2, min(M, 300)), 8 * pick([ri(1, 64), ri(32, 700), ri(256, 2048)]))
+    tf.test_quant_rows_fused_swiglu_is_the_two_launches_bit_for_bit(max(2, min(M, 300)), 8 * pick([ri(1, 64), ri(32, 700), ri(256, 2048)]))
+    K = 128 * pick([ri(2, 8), ri(4, 40), ri(16, 112)])
+    N = pick([ri(1, 300), ri(100, 3000), 8 * ri(1, 800)])
+    while M * N * K > 2_500_000_000:  # the fp64 reference runs on the host
+        N = max(1, N // 2)
+    tf.test_gemm_w8a8_equals_gemm_of_dequantised_operands(M, N, K)
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_sampler_kept_set_random_settings(seed):
+    from tests import test_gpu_sampling as ts
+    ri, pick = _draw(8100 + seed)
+    temperature = pick([0.05, 0.2, 0.7, 1.0, 1.3, 2.5]) * (1 + 0.01 * ri(0, 30))
+    top_p = pick([None, None, 1.0, 0.01 * ri(2, 99)])
+    ts.test_kept_set_equals_hf_warpers(temperature, ri(1, 64), top_p, pick([ri(70, 2000), ri(2000, 40000), ri(40000, 160000)]))

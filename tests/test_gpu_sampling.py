@@ -60,7 +60,7 @@ def test_kept_set_equals_hf_warpers(temperature, top_k, top_p, V):
             # short rows, not for long ones -- observed: V = 70 keeps the highest index, V = 1000 the middle one), i.e. not defined
             # by HF either; the kept VALUES must agree, and only members of that one tie group may differ
             vals = {float(lg[b, i]) for i in diff}
-            assert len(vals) == 1 and b == 2, (b, sorted(diff)[:10], vals)
+            assert len(vals) == 1 and b in (1, 2), (b, sorted(diff)[:10], vals)  # (rows 1 and 2 hold the planted tie groups)
         # best first: scores non-increasing
         sc = (lg[b].cpu() / temperature)[got]
         assert bool((sc[:-1] >= sc[1:]).all())
