@@ -261,6 +261,40 @@ def pil_bicubic_tables(in_size: int, out_size: int):
     return bounds, coef
 
 
+def _pil_resize_u8_restated(arr: np.ndarray, out_h: int, out_w: int, vertical_first: bool = False) -> np.ndarray:
+    """Pillow's two-pass 8-bit bicubic resize of a uint8 [H, W, C] array as integer arithmetic on pil_bicubic_tables (what the device
+    kernels run), in either pass order.  Host-side check / calibration only (numpy, slow)."""
+    def one_pass(a, axis, out_size):
+        bounds, coef = pil_bicubic_tables(a.shape[axis], out_size)
+        a = np.moveaxis(a, axis, 0).astype(np.int64)
+        out = np.empty((out_size,) + a.shape[1:], np.uint8)
+        for i in range(out_size):
+            x0, n = int(bounds[i, 0]), int(bounds[i, 1])
+            acc = (1 << 21) + np.tensordot(coef[i, :n].astype(np.int64), a[x0:x0 + n], axes=(0, 0))
+            out[i] = np.clip(acc >> 22, 0, 255)
+        return np.moveaxis(out, 0, axis)
+    if vertical_first:
+        return one_pass(one_pass(arr, 0, out_h), 1, out_w)
+    return one_pass(one_pass(arr, 1, out_w), 0, out_h)
+
+
+@functools.lru_cache(maxsize=1)
+def pil_resizes_tall_images_vertically_first() -> bool:
+    """Image.resize of recent Pillow releases (seen in 12.2: `if self.size[1] > self.size[0] * 100 and size[1] < self.size[1]`) shrinks
+    an image more than 100 times taller than wide in two separate resizes, rows first -- the intermediate rounding then happens in
+    the other order and the pixels differ from the horizontal-first result by up to ~20 codes.  The release that introduced it is
+    not pinned anywhere (the reference does not pin Pillow), so the INSTALLED library is asked once with a 303 x 3 probe image."""
+    from PIL import Image
+    arr = ((np.arange(303 * 3 * 3, dtype=np.int64) * 2654435761) % 251).astype(np.uint8).reshape(303, 3, 3)
+    ref = np.asarray(Image.fromarray(arr).resize((7, 101), Image.BICUBIC))
+    if np.array_equal(ref, _pil_resize_u8_restated(arr, 101, 7, vertical_first=False)):
+        return False
+    if np.array_equal(ref, _pil_resize_u8_restated(arr, 101, 7, vertical_first=True)):
+        return True
+    raise RuntimeError("the installed Pillow resizes a 303 x 3 image like neither pass order of its published two-pass resampler; "
+                       "process_images_device cannot promise the host path's pixels for such shapes")
+
+
 @functools.lru_cache(maxsize=64)
 def cv2_nearest_index(in_size: int, out_size: int):
     """cv2.resize(..., INTER_NEAREST) source index per destination index: min(floor(dst * (1 / (out / in))), in - 1),
@@ -297,6 +331,12 @@ def process_images_device(images, image_processor, model_cfg, device="cuda", dty
             bg[(side - h) // 2:(side - h) // 2 + h, (side - w) // 2:(side - w) // 2 + w] = arr
             arr = bg
         H, W = arr.shape[:2]
+        # an image more than 100 times taller than wide that shrinks vertically: recent Pillow resizes its rows FIRST (see
+        # pil_resizes_tall_images_vertically_first).  Same kernels on the transposed image -- their first pass then runs along the
+        # original rows' axis -- and the result transposed back
+        rows_first = H > 100 * W and S_h < H and pil_resizes_tall_images_vertically_first()
+        if rows_first:
+            arr, H, W, S_h, S_w = arr.transpose(1, 0, 2), W, H, S_w, S_h
         src = torch.from_numpy(np.array(arr, dtype=np.uint8, order="C")).to(device)  # PIL buffers are read-only: copy
         hb, hc = _dev_tables(pil_bicubic_tables(W, S_w), device)
         vb, vc = _dev_tables(pil_bicubic_tables(H, S_h), device)
@@ -307,6 +347,8 @@ def process_images_device(images, image_processor, model_cfg, device="cuda", dty
                                                  mean.data_ptr(), std.data_ptr(), float(image_processor.rescale_factor),
                                                  int(bool(getattr(image_processor, "do_normalize", True))), ops.dt_code(out),
                                                  ops._stream()))
+        if rows_first:
+            out, S_h, S_w = out.transpose(1, 2).contiguous(), S_w, S_h
         outs.append(out)
     return torch.stack(outs, 0)
 

@@ -168,3 +168,37 @@ def test_sampler_kept_set_random_settings(seed):
     temperature = pick([0.05, 0.2, 0.7, 1.0, 1.3, 2.5]) * (1 + 0.01 * ri(0, 30))
     top_p = pick([None, None, 1.0, 0.01 * ri(2, 99)])
     ts.test_kept_set_equals_hf_warpers(temperature, ri(1, 64), top_p, pick([ri(70, 2000), ri(2000, 40000), ri(40000, 160000)]))
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_preprocessing_random_sizes(seed):
+    """process_images_device / process_regions_device on raw uint8 of ANY size == the host path (PIL bicubic + rescale / normalise; the
+    cv2-nearest restatement; the pad mode's soft-edged square) bit for bit -- up- and down-sampling, extreme aspect ratios, tiny inputs"""
+    import numpy as np
+    from PIL import Image
+    from types import SimpleNamespace
+
+    from spatialrgpt_amd.mm_utils import (SrgptImageProcessor, process_images, process_images_device, process_regions,
+                                          process_regions_device)
+
+    ri, pick = _draw(8200 + seed)
+    rng = np.random.default_rng(8200 + seed)
+    size = pick([384, 384, 336, 378, 224])
+    proc = SrgptImageProcessor(size=size)
+    dim = lambda: pick([ri(2, 40), ri(30, 500), ri(300, 1300)])  # noqa: E731
+    shapes = [(dim(), dim()) for _ in range(3)]
+    for mode in ("resize", "pad", None):
+        cfg = SimpleNamespace(image_aspect_ratio=mode, image_processor=proc)
+        ims = [Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in shapes]
+        ref = process_images(ims, proc, cfg)
+        got = process_images_device(ims, proc, cfg, device="cuda", dtype=torch.float32)
+        assert got.shape == ref.shape and torch.equal(got.cpu(), ref), (mode, shapes, size, float((got.cpu() - ref).abs().max()))
+    for mode in ("resize", "pad"):
+        cfg = SimpleNamespace(image_aspect_ratio=mode, image_processor=proc)
+        h, w = dim(), dim()
+        hi = pick([1, 255])
+        mk = [(rng.random((h, w)) > 0.6).astype(np.uint8) * hi for _ in range(ri(1, 4))]
+        mk[0][h // 4:h // 2 + 1, w // 4:w // 2 + 1] = hi
+        refm = process_regions(mk, proc, cfg)
+        gotm = process_regions_device(mk, proc, cfg, device="cuda", dtype=torch.float32)
+        assert gotm.shape == refm.shape and torch.equal(gotm.cpu(), refm), (mode, (h, w), size, float((gotm.cpu() - refm).abs().max()))

@@ -182,6 +182,27 @@ def test_pil_bicubic_tables_random_sizes_match_pillow():
         assert np.array_equal(out, ref), (w_in, w_out)
 
 
+def test_two_pass_resize_order_follows_the_installed_pillow():
+    """Whole images, both passes: the integer two-pass resize the device kernels run (mm_utils._pil_resize_u8_restated on
+    pil_bicubic_tables) == Image.resize of the INSTALLED Pillow for random sizes, including images more than 100 times taller than
+    wide that shrink vertically -- recent releases resize those rows first (found by tests/test_gpu_fuzz_shapes.py: up to 22 codes
+    off with the passes in the usual order), which mm_utils.pil_resizes_tall_images_vertically_first asks the library itself."""
+    from PIL import Image
+
+    from spatialrgpt_amd.mm_utils import _pil_resize_u8_restated, pil_resizes_tall_images_vertically_first
+
+    rows_first = pil_resizes_tall_images_vertically_first()
+    rng = np.random.default_rng(11)
+    shapes = [(1078, 4), (500, 3), (4, 1078), (600, 5), (600, 8), (379, 3), (400, 4), (401, 4), (202, 2), (150, 1)]
+    shapes += [(int(rng.integers(1, 500)), int(rng.integers(1, 500))) for _ in range(12)]
+    for h, w in shapes:
+        oh, ow = (int(rng.integers(1, 400)), int(rng.integers(1, 400))) if rng.random() < 0.5 else (96, 96)
+        arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(arr).resize((ow, oh), Image.BICUBIC))
+        vf = rows_first and h > 100 * w and oh < h
+        assert np.array_equal(_pil_resize_u8_restated(arr, oh, ow, vertical_first=vf), ref), ((h, w), (oh, ow), vf)
+
+
 def test_bench_presets_map_to_baseline_configs(monkeypatch):
     """bench.py's presets / flags name the BASELINE.json configuration they measure (no GPU needed: argument plumbing only)."""
     import importlib
