@@ -163,7 +163,7 @@ def test_every_flag_combination_of_the_eval_clis_generates():
 
 
 @pytest.mark.parametrize("geom", ["vila15_8b", "llama2_7b", "sheared_3b", "clip_l14_336", "vila15_8b-fp8"])
-def test_true_width_truncated_depth_bf16_vs_oracle(geom):
+def test_true_width_truncated_depth_bf16_vs_oracle(geom, batch=1, regions=8, prompt_len=64, seed=2):
     """The three LLM layer geometries of the reference's recipes at TRUE width -- VILA1.5-8B (hidden 4096, GQA 32/8, inter
     14336), Llama-2-7B (MHA 32/32, inter 11008), Sheared-LLaMA-2.7B (hidden 2560, 20 heads, inter 6912) -- behind the
     SigLIP-so400m-width tower (plus the CLIP-L/14-336 tower in front of the 8B geometry), with 2 LLM / 2 ViT layers and a 16k vocab, bf16, one full request: stage tensors within bf16
@@ -181,7 +181,7 @@ def test_true_width_truncated_depth_bf16_vs_oracle(geom):
         kw.update(vit_hidden=1024, vit_inter=4096, vit_heads=16, image_size=336, vit_eps=1e-5, tower="clip", select_feature="patch")
     ocfg = so.SrgptConfig(**kw)
     w = so.synth_weights(ocfg, seed=11, dtype=torch.bfloat16)
-    ids, images, depths, masks = so.synth_inputs(ocfg, batch=1, regions=8, prompt_len=64, seed=2, dtype=torch.bfloat16)
+    ids, images, depths, masks = so.synth_inputs(ocfg, batch=batch, regions=regions, prompt_len=prompt_len, seed=seed, dtype=torch.bfloat16)
     fp8 = geom.endswith("-fp8")  # weight-only fp8 LLM matrices: the oracle runs on dequant(quant(W)), the engine quantises itself
     model = LlavaLlamaModel(SrgptConfig(**kw), dict(w), device=DEV, dtype=torch.bfloat16, rope_positions=1024,
                             llm_weight_format="fp8" if fp8 else "native")
@@ -192,7 +192,7 @@ def test_true_width_truncated_depth_bf16_vs_oracle(geom):
     ref_ids, st = so.generate(w, ocfg, ids, images, depths, masks, max_new_tokens=G, return_stages=True, model_dtype=torch.bfloat16)
     got = {}
     emb, _, _ = model.engine.prepare_inputs(ids.to(DEV), images.to(DEV), depths.to(DEV), [m.to(DEV) for m in masks], None, stages=got)
-    assert emb.shape == (1, 259, kw.get("hidden", 4096))
+    assert emb.shape == (batch, prompt_len - 1 + 196, kw.get("hidden", 4096))
 
     def chk(a, b, what, rel=4e-2):
         assert_close(a, b, rel * (float(b.float().abs().max()) + 1e-6), 0, what)
@@ -204,7 +204,7 @@ def test_true_width_truncated_depth_bf16_vs_oracle(geom):
     chk(got["image_features"], st["image_features"], "projector")
     chk(emb, st["inputs_embeds"], "inputs_embeds")
     stt, logits, _ = model.engine.prefill(st["inputs_embeds"].to(DEV), max_new=G + 1, all_logits=True)
-    chk(logits, st["prefill_logits"], "prefill logits (T = 259)")
+    chk(logits, st["prefill_logits"], f"prefill logits (T = {emb.shape[1]})")
     # decode path under teacher forcing with the oracle's ids: every step compared, no exit at the first flip
     from tests.util import logit_parity_report, teacher_forced_decode_logits
 

@@ -110,3 +110,18 @@ def test_an_empty_mask_tensor_raises_like_the_reference(pair):
         so.prepare_inputs(w, ocfg, r["input_ids"], r["images"], r["depths"], empty, r["attention_mask"])
     with pytest.raises(RuntimeError):
         model.engine.prepare_inputs(r["input_ids"].to(DEV), r["images"].to(DEV), r["depths"].to(DEV), [empty[0].to(DEV)], None)
+
+
+@pytest.mark.parametrize("seed", list(range(max(2, int(os.environ.get("SRGPT_FUZZ_CASES", "10")) // 4))))
+def test_random_true_width_request_equals_the_oracle_bf16(seed):
+    """tests/test_gpu_edge_cases.py's true-width, truncated-depth bf16 comparison (stage tensors, prefill logits at every position,
+    teacher-forced decode logits) on random request SHAPES: 1..3 prompts, 1..12 regions, prompts of 40..130 ids -- 235..325 spliced
+    rows per prompt, across the row counts at which the prefill products change kernels (225 / 272 / 288 / 384 rows and their batch
+    multiples) -- for the three LLM geometries and the fp8 weight format"""
+    from tests import test_gpu_edge_cases as te
+    g = torch.Generator().manual_seed(5000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    geom = ["vila15_8b", "llama2_7b", "sheared_3b", "vila15_8b-fp8", "clip_l14_336"][ri(0, 4)]
+    regions = ri(1, 12)
+    te.test_true_width_truncated_depth_bf16_vs_oracle(geom, batch=ri(1, 3), regions=regions, prompt_len=max(ri(40, 130), 3 * regions + 8),
+                                                      seed=100 + seed)
