@@ -98,6 +98,27 @@ def test_random_request_equals_the_oracle(pair, seed):
                 top2 = sl[b, t].topk(2).values
                 assert float(top2[0] - top2[1]) <= tol, f"seed {seed}: row {b} step {t}: {out[b].tolist()} vs {ids_o[b].tolist()}"
                 break  # a flipped near-tie changes every later input of this row
+    # (3) forward(labels=...) (llava_llama.py:100-192): spliced labels equal, loss within 2e-5, logits at the valid positions
+    g = torch.Generator().manual_seed(seed)
+    labels = torch.randint(0, CFG["vocab"], r["input_ids"].shape, generator=g)
+    labels[torch.rand(labels.shape, generator=g) < 0.3] = -100
+    am_in = r["attention_mask"] if r["attention_mask"] is not None else torch.ones_like(r["input_ids"], dtype=torch.bool)  # forward() needs one (llava_llama.py:131)
+    # a row's FIRST token carries no target: under left padding its shifted partner is the logits of a padding position, which
+    # the reference's varlen attention leaves at lm_head(0) = 0 (as here) and the oracle's masked eager attention does not
+    labels[torch.arange(labels.shape[0]), am_in.int().argmax(dim=1)] = -100
+    image_features, mask_embeds, depth_embeds, _ = so.encode_visual(w, ocfg, r["images"], r["depths"], r["masks"])
+    _, am_o, _, new_labels = so.splice(w, ocfg, r["input_ids"], r["attention_mask"], image_features, mask_embeds, depth_embeds,
+                                       have_depths=r["depths"] is not None, labels=labels)
+    loss_o = so.causal_lm_loss(st["prefill_logits"], new_labels)
+    out_f = model(input_ids=dev(r["input_ids"]), images=dev(r["images"]), masks=[dev(m) for m in r["masks"]], depths=dev(r["depths"]),
+                  attention_mask=dev(am_in), labels=dev(labels))
+    if bool(torch.isnan(loss_o)):
+        assert bool(torch.isnan(out_f.loss))
+    else:
+        assert abs(float(out_f.loss) - float(loss_o)) <= 2e-5 * max(1.0, abs(float(loss_o))), (float(out_f.loss), float(loss_o))
+    keep = torch.ones(ref.shape[:2], dtype=torch.bool) if am_o is None else am_o.bool()
+    lo = st["prefill_logits"]
+    assert_close(out_f.logits.cpu()[keep], lo[keep], 4e-4 * float(lo.abs().max()), 0, f"seed {seed}: forward logits at the valid positions")
 
 
 def test_an_empty_mask_tensor_raises_like_the_reference(pair):
