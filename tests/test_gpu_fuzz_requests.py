@@ -26,9 +26,9 @@ def _request(seed):
     B = ri(1, 4)
     have_depths = ri(0, 4) != 0
     rows, masks = [], []
-    has_img = [ri(0, 4) != 0 for _ in range(B)]
+    has_img = [int(ri(0, 4) != 0) for _ in range(B)]  # images per prompt
     if not any(has_img):
-        has_img[ri(0, B - 1)] = True
+        has_img[ri(0, B - 1)] = 1
     for b in range(B):
         txt = lambda n: torch.randint(3, 118, (n,), generator=g).tolist()  # noqa: E731
         seq = [1] + txt(ri(1, 6))
@@ -37,12 +37,23 @@ def _request(seed):
             k = ri(0, 4)
             none_entry = k == 0  # no regions: None (an EMPTY mask tensor raises in the reference's F.interpolate, base_extractor.py:53-58)
             m = torch.zeros((k, S, S))
+            kt = k if ri(0, 3) else ri(0, k)  # sometimes fewer <mask> ids than region embeddings (the surplus is unused, llava_arch.py:470-485)
             for r in range(k):
                 hh, ww = ri(S // 8, S // 2), ri(S // 8, S // 2)
                 y0, x0 = ri(0, S - hh), ri(0, S - ww)
                 m[r, y0:y0 + hh, x0:x0 + ww] = 1.0
-                seq += txt(ri(0, 3)) + [CFG["mask_token_id"]] + ([CFG["depth_token_id"]] if have_depths else [])
+                if r < kt:
+                    seq += txt(ri(0, 3)) + [CFG["mask_token_id"]] + ([CFG["depth_token_id"]] if have_depths else [])
             masks.append(None if none_entry else m)
+            if ri(0, 4) == 0:
+                # a second image in the same prompt: its rows are spliced at its sentinel; the prompt's <mask> / <depth> ids all take
+                # the FIRST image's region embeddings (mask_embeds[cur_image_idx] is read before the images are walked)
+                seq += txt(ri(0, 2)) + [IMAGE_TOKEN_INDEX]
+                k2 = ri(0, 2)
+                m2 = torch.zeros((k2, S, S))
+                m2[:, S // 4:S // 2, S // 3:S // 2] = 1.0
+                masks.append(m2 if k2 else None)
+                has_img[b] += 1
         seq += txt(ri(1, 5))
         rows.append(seq)
     P = max(len(r) for r in rows)
@@ -107,8 +118,13 @@ def test_random_request_equals_the_oracle(pair, seed):
     # the reference's varlen attention leaves at lm_head(0) = 0 (as here) and the oracle's masked eager attention does not
     labels[torch.arange(labels.shape[0]), am_in.int().argmax(dim=1)] = -100
     image_features, mask_embeds, depth_embeds, _ = so.encode_visual(w, ocfg, r["images"], r["depths"], r["masks"])
-    _, am_o, _, new_labels = so.splice(w, ocfg, r["input_ids"], r["attention_mask"], image_features, mask_embeds, depth_embeds,
+    _, am_o, _, new_labels = so.splice(w, ocfg, r["input_ids"], am_in, image_features, mask_embeds, depth_embeds,
                                        have_depths=r["depths"] is not None, labels=labels)
+    if r["attention_mask"] is None:
+        # no mask in, none out (llava_arch.py:614-617) -- even when the spliced rows differ in length (a two-image prompt next to a
+        # one-image prompt): steps (1) and (2) ran the LLM over the padding like the reference; forward() gets the all-ones mask
+        _, st = so.generate(w, ocfg, r["input_ids"], r["images"], r["depths"], r["masks"], am_in, max_new_tokens=1, eos_token_id=None,
+                            return_stages=True)
     loss_o = so.causal_lm_loss(st["prefill_logits"], new_labels)
     out_f = model(input_ids=dev(r["input_ids"]), images=dev(r["images"]), masks=[dev(m) for m in r["masks"]], depths=dev(r["depths"]),
                   attention_mask=dev(am_in), labels=dev(labels))
