@@ -162,3 +162,14 @@ def test_random_true_width_request_equals_the_oracle_bf16(seed):
     regions = ri(1, 12)
     te.test_true_width_truncated_depth_bf16_vs_oracle(geom, batch=ri(1, 3), regions=regions, prompt_len=max(ri(40, 130), 3 * regions + 8),
                                                       seed=100 + seed)
+
+
+@pytest.mark.parametrize("seed", list(range(max(2, int(os.environ.get("SRGPT_FUZZ_CASES", "10")) // 3))))
+def test_ragged_prefill_random_lengths(seed):
+    """srgpt_llm_prefill_ragged + batched decode == every row alone (tests/test_gpu_pipeline.py's check) for random batches of 1..6
+    rows of 1..300 positions, fp32 and bf16"""
+    from tests import test_gpu_pipeline as tp
+    g = torch.Generator().manual_seed(6000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    lens = [[ri(1, 30), ri(20, 300), ri(200, 300)][ri(0, 2)] for _ in range(ri(1, 6))]
+    tp.test_ragged_prefill_and_batched_decode_equal_single_rows([torch.float32, torch.bfloat16][ri(0, 1)], lens=lens)

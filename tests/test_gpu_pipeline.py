@@ -258,7 +258,7 @@ def test_fp8_weight_decode_vs_oracle_on_dequantised_weights(batch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_ragged_prefill_and_batched_decode_equal_single_rows(dtype):
+def test_ragged_prefill_and_batched_decode_equal_single_rows(dtype, lens=(37, 20, 5)):
     """srgpt_llm_prefill_ragged (right-padded batch + per-row lengths) followed by batched decode steps gives every row the
     logits it gets when it runs alone (varlen semantics of modeling_llama.py:540-608): causal attention never sees the
     padding, positions continue at lens[b]."""
@@ -274,9 +274,9 @@ def test_ragged_prefill_and_batched_decode_equal_single_rows(dtype):
     eng = SrgptEngine(SrgptConfig(**kw), dict(w), device=DEV, dtype=dtype, rope_positions=512)
     lib = L.load()
     g = torch.Generator().manual_seed(7)
-    lens = [37, 20, 5]
+    lens = list(lens)
     T, G = max(lens), 4
-    x = (torch.randn((3, T, 512), generator=g) * 0.5).to(dtype)
+    x = (torch.randn((len(lens), T, 512), generator=g) * 0.5).to(dtype)
     for b, n in enumerate(lens):
         x[b, n:] = 77.0  # garbage in the padding must not matter
 
