@@ -173,3 +173,78 @@ def test_ragged_prefill_random_lengths(seed):
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
     lens = [[ri(1, 30), ri(20, 300), ri(200, 300)][ri(0, 2)] for _ in range(ri(1, 6))]
     tp.test_ragged_prefill_and_batched_decode_equal_single_rows([torch.float32, torch.bfloat16][ri(0, 1)], lens=lens)
+
+
+def test_a_long_lived_model_answers_like_a_fresh_one():
+    """State carried between requests (the pooled decode state and its cache capacity, the captured graphs, workspaces, the attention's
+    arrival tickets, the sampler's counters) must not leak into the next answer: ONE model serves a random sequence of requests --
+    batch 1..4, 0..4 regions, greedy / seeded sampling / 2 beams / a stopping criterion, 1..12 new tokens -- and every answer equals
+    the answer of a model built fresh for that request alone (same weights).  tests/test_gpu_soak.py compares repeats of a request on
+    the same model; this compares against a model with no history.  SRGPT_FUZZ_CASES scales the sequence length (default 30 calls)."""
+    from oracle import srgpt_oracle as so  # weights only
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.model import LlavaLlamaModel
+
+    ocfg = so.SrgptConfig(**CFG, padding_side="left")
+    w = so.synth_weights(ocfg, seed=11, dtype=torch.float32, std=0.08)
+    build = lambda: LlavaLlamaModel(SrgptConfig(**CFG, padding_side="left"), dict(w), device=DEV, dtype=torch.float32, rope_positions=512)  # noqa: E731
+    veteran = build()
+    g = torch.Generator().manual_seed(77)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    n_calls = 3 * int(os.environ.get("SRGPT_FUZZ_CASES", "10"))
+    dev = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    for call in range(n_calls):
+        r = _request(3000 + ri(0, 40))  # a small pool of requests: shapes recur with other shapes in between
+        mode = ["greedy", "greedy", "sample", "beam", "criterion"][ri(0, 4)]
+        n_new = ri(1, 12)
+        kw = dict(do_sample=False)
+        if mode == "sample":
+            kw = dict(do_sample=True, temperature=0.8, top_k=20, top_p=0.9)
+        elif mode == "beam":
+            kw = dict(do_sample=False, num_beams=2)
+        elif mode == "criterion":
+            kw = dict(do_sample=False, stopping_criteria=[lambda ids_, s_: ids_.shape[1] >= 3])
+        args = dict(images=dev(r["images"]), depths=dev(r["depths"]), masks=[dev(m) for m in r["masks"]],
+                    attention_mask=dev(r["attention_mask"]), max_new_tokens=n_new, eos_token_id=None, **kw)
+        torch.manual_seed(call)  # the sampler's Philox seed is drawn from torch's CPU generator
+        a = veteran.generate(dev(r["input_ids"]), **args)
+        torch.manual_seed(call)
+        b = build().generate(dev(r["input_ids"]), **args)
+        assert a.shape == b.shape and torch.equal(a, b), f"call {call} ({mode}, batch {r['input_ids'].shape[0]}, {n_new} new): {a.tolist()} vs fresh {b.tolist()}"
+
+
+@pytest.mark.parametrize("fmt", ["native", "fp8"])
+def test_a_long_lived_true_width_model_answers_like_a_fresh_one(fmt):
+    """the same at TRUE width in bf16 / fp8 weights (2 LLM + 2 ViT layers, 16k vocabulary): the MFMA decode attention with its tickets,
+    the batched products with their row-statistics tables and packed weights, the captured graphs of several batch sizes"""
+    from oracle import srgpt_oracle as so  # weights / inputs only
+    from spatialrgpt_amd.config import SrgptConfig
+    from spatialrgpt_amd.model import LlavaLlamaModel
+
+    kw = dict(vit_layers=2, layers=2, vocab=16386, mask_token_id=16384, depth_token_id=16385)
+    ocfg = so.SrgptConfig(**kw)
+    w = so.synth_weights(ocfg, seed=11, dtype=torch.bfloat16)
+    build = lambda: LlavaLlamaModel(SrgptConfig(**kw), dict(w), device=DEV, dtype=torch.bfloat16, rope_positions=1024,  # noqa: E731
+                                    llm_weight_format=fmt)
+    veteran = build()
+    g = torch.Generator().manual_seed(78)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    for call in range(int(os.environ.get("SRGPT_FUZZ_CASES", "10"))):
+        B, K = [1, 1, 2, 3, 4, 8][ri(0, 5)], ri(1, 8)
+        ids, images, depths, masks = so.synth_inputs(ocfg, batch=B, regions=K, prompt_len=max(ri(40, 100), 3 * K + 8), seed=ri(0, 5),
+                                                     dtype=torch.bfloat16)
+        mode = ["greedy", "greedy", "sample", "beam"][ri(0, 3)]
+        kwg = dict(do_sample=False)
+        if mode == "sample":
+            kwg = dict(do_sample=True, temperature=0.8, top_k=20, top_p=0.9)
+        elif mode == "beam":
+            kwg = dict(do_sample=False, num_beams=2)
+        args = dict(images=images.to(DEV), depths=depths.to(DEV), masks=[m.to(DEV) for m in masks], max_new_tokens=ri(1, 10),
+                    eos_token_id=None, **kwg)
+        torch.manual_seed(call)
+        a = veteran.generate(ids.to(DEV), **args)
+        torch.manual_seed(call)
+        fresh = build()
+        b = fresh.generate(ids.to(DEV), **args)
+        del fresh
+        assert a.shape == b.shape and torch.equal(a, b), f"call {call} ({mode}, batch {B}): {a.tolist()} vs fresh {b.tolist()}"
