@@ -109,6 +109,15 @@ def test_random_request_equals_the_oracle(pair, seed):
                 top2 = sl[b, t].topk(2).values
                 assert float(top2[0] - top2[1]) <= tol, f"seed {seed}: row {b} step {t}: {out[b].tolist()} vs {ids_o[b].tolist()}"
                 break  # a flipped near-tie changes every later input of this row
+    # (2b) an EOS id some row actually produces: rows finish at different steps, finished rows are padded (HF: pad_token_id defaults to
+    #      the eos id), the loop ends when every row has finished -- only where (2) found the ids equal (same trajectories)
+    if torch.equal(out, ids_o):
+        eos = int(ids_o[seed % ids_o.shape[0], 1 + seed % (G - 1)])
+        want = so.generate(w, ocfg, r["input_ids"], r["images"], r["depths"], r["masks"], r["attention_mask"], max_new_tokens=G,
+                           eos_token_id=eos)
+        got = model.generate(dev(r["input_ids"]), images=dev(r["images"]), depths=dev(r["depths"]), masks=[dev(m) for m in r["masks"]],
+                             attention_mask=dev(r["attention_mask"]), do_sample=False, max_new_tokens=G, eos_token_id=eos).cpu()
+        assert got.shape == want.shape and torch.equal(got, want), f"seed {seed}: eos {eos}: {got.tolist()} vs {want.tolist()}"
     # (3) forward(labels=...) (llava_llama.py:100-192): spliced labels equal, loss within 2e-5, logits at the valid positions
     g = torch.Generator().manual_seed(seed)
     labels = torch.randint(0, CFG["vocab"], r["input_ids"].shape, generator=g)
