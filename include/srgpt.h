@@ -21,6 +21,7 @@
 #ifndef SRGPT_H_
 #define SRGPT_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

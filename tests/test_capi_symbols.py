@@ -133,3 +133,19 @@ def test_argument_validation_without_gpu():
     assert rc == _lib.ERR_ARG and b"null" in lib.srgpt_last_error()
     rc = lib.srgpt_gemm_swiglu(16, 16, 16, 4, 64, 64, None, None, 0, _lib.BF16, None)  # a shape that needs the [M, 2 I] scratch
     assert rc == _lib.ERR_ARG and b"scratch" in lib.srgpt_last_error()
+
+
+def test_public_header_is_self_contained_c_and_cxx(tmp_path):
+    """include/srgpt.h is what a maintainer's cgo / JNI / ctypes-gen / C++ binding includes: it must compile on its own as C99 and as
+    C++17 (round 6: `size_t` had come in without <stddef.h>)."""
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cc, std, ext in (("gcc", "-std=c99", "c"), ("g++", "-std=c++17", "cpp")):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not installed")
+        src = tmp_path / f"hdr.{ext}"
+        src.write_text('#include "include/srgpt.h"\nint main(void) { return srgpt_abi_version == 0; }\n')
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-I", root, str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
